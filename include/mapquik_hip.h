@@ -1,0 +1,146 @@
+/*
+ * mapquik_hip.h -- C ABI of the MI355X (gfx950) implementation of mapquik's hot path:
+ * k-min-mer seeding -> unique-k-min-mer index lookup -> Match runs -> pseudo-chain -> PAF columns.
+ *
+ * This is the drop-in boundary.  The reference (ekimb/mapquik, Rust) has no FFI of its own; the
+ * internal seam these entry points replace is the pair called from the seq_io worker closures
+ * (src/closures.rs:46-51,100-104):
+ *     mers::ref_extract (ref_idx, &[u8], &Params, &Index) -> usize            src/mers.rs:15
+ *     mers::find_matches(q_id, q_len, &[u8], &ref_map, &ReadOnlyIndex, &Params) -> Option<String>   src/mers.rs:77
+ * in batch form (many sequences per call), with plain pointers and sizes only.
+ * INTEGRATION.md shows the `extern "C"` block a Rust maintainer would add.
+ *
+ * Conventions
+ *   - Sequences are bytes exactly as the reference's seam receives them: upper-cased ASCII
+ *     (src/closures.rs:63,106).  Any byte other than A,C,G,T hashes as ntHash seed 0.
+ *   - All functions return 0 (or a non-negative count) on success and a negative MQ_E* code on error;
+ *     mq_last_error() returns a thread-local message.  Nothing throws across the boundary.
+ *   - The caller owns every buffer it passes; the library owns device memory behind mq_index.
+ *   - The compute path is HIP only.  There is no CPU fallback: without a usable GPU every compute entry
+ *     point fails with MQ_ENODEVICE.
+ *   - Limits (checked, MQ_EINVAL otherwise): 1 <= l <= 64, 1 <= k <= 32, sequence length < 2^32.
+ */
+#ifndef MAPQUIK_HIP_H
+#define MAPQUIK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MQ_ABI_VERSION 1
+
+#define MQ_OK 0
+#define MQ_EINVAL (-1)
+#define MQ_ENODEVICE (-2)
+#define MQ_EHIP (-3)
+#define MQ_ENOMEM (-4)
+#define MQ_ESTATE (-5)
+#define MQ_EOVERFLOW (-6)
+
+/* Params (src/main.rs:33-47); defaults src/main.rs:174-188.  I/O-only members (b, q, threads, debug) are host-side. */
+typedef struct mq_params {
+    uint32_t k;       /* k-min-mer length, default 5 */
+    uint32_t l;       /* minimizer length, default 31 */
+    double   density; /* FH density, default 0.01 */
+    uint32_t use_hpc; /* 1 unless --nohpc */
+    uint32_t c;       /* minimum chain length, default 4 */
+    uint32_t s;       /* minimum matching seeds, default 11 */
+    uint32_t g;       /* maximum gap difference, default 2000 */
+    uint32_t reserved;
+} mq_params;
+
+/* One k-min-mer as the reference's KminmerHash exposes it (fields used at src/index.rs:57-58,101). 24 bytes. */
+typedef struct mq_kminmer {
+    uint64_t hash;
+    uint32_t start;
+    uint32_t end;
+    uint32_t offset;
+    uint32_t rev;
+} mq_kminmer;
+
+/* Result of find_matches for one read: the numeric PAF columns of src/mers.rs:181.  40 bytes.
+ * status 0 => the reference returns None (no line is written, src/closures.rs:119-121). */
+#define MQ_HIT_UNMAPPED 0u
+#define MQ_HIT_MAPPED 1u
+#define MQ_HIT_OVERFLOW 2u /* more Match runs than the per-read scratch holds: result NOT computed (loud, never silent) */
+typedef struct mq_hit {
+    uint32_t status;
+    uint32_t ref_id;     /* index passed to mq_index_add_ref */
+    uint32_t rc;         /* 1 => '-' */
+    uint32_t mapq;       /* 0 or 60 */
+    uint32_t q_start;    /* column 3 */
+    uint32_t q_end;      /* column 4 (inclusive, as the reference prints it) */
+    uint32_t r_start;    /* column 8 */
+    uint32_t r_end;      /* column 9 (inclusive) */
+    uint32_t score;      /* column 10: number of matching k-min-mers */
+    uint32_t n_kminmers; /* k-min-mers extracted from the read (diagnostic) */
+} mq_hit;
+
+typedef struct mq_index mq_index; /* opaque: Index / ReadOnlyIndex (src/index.rs:73-128) + ref_map (src/closures.rs:30) */
+
+typedef struct mq_index_stats {
+    uint64_t n_refs;
+    uint64_t n_kminmers;  /* total inserted, sum of mq_index_add_ref returns */
+    uint64_t n_keys;      /* distinct hashes (incl. tombstones) */
+    uint64_t n_unique;    /* Index::get_count(): non-tombstones (src/index.rs:90-92) */
+    uint64_t table_slots; /* power of two */
+    uint64_t table_bytes;
+    uint64_t slot_bytes;
+} mq_index_stats;
+
+const char *mq_last_error(void);
+int mq_abi_version(void);
+/* number of HIP devices visible; 0 or negative => no compute possible */
+int mq_device_count(void);
+void mq_params_default(mq_params *p); /* src/main.rs:174-188 */
+
+/* Index::new (src/index.rs:78-88) on HIP device `device`. */
+mq_index *mq_index_new(const mq_params *params, int device);
+void mq_index_free(mq_index *idx);
+
+/* index_mers closure (src/closures.rs:46-51) = ref_extract (src/mers.rs:15-38) + ref_map.insert.
+ * Returns the number of k-min-mers of this reference (the "Indexed reference {}: {} k-min-mers." count) or <0.
+ * ref_id values must be distinct; seq is host memory (mq_index_add_ref) or device memory (.._device). */
+int64_t mq_index_add_ref(mq_index *idx, uint32_t ref_id, const char *name, const uint8_t *seq, uint64_t len);
+int64_t mq_index_add_ref_device(mq_index *idx, uint32_t ref_id, const char *name, const uint8_t *d_seq, uint64_t len);
+
+/* get_count + into_read_only (src/closures.rs:92-94): dedup (a hash seen twice is a tombstone,
+ * src/index.rs:94-104), build the HBM-resident table.  Returns the unique count or <0. */
+int64_t mq_index_finalize(mq_index *idx);
+int mq_index_get_stats(const mq_index *idx, mq_index_stats *out);
+int mq_index_ref_info(const mq_index *idx, uint32_t ref_id, const char **name, uint64_t *len);
+
+/* find_matches (src/mers.rs:77-102) for n reads.  bases: concatenated reads; offsets: n+1 prefix offsets.
+ * Host-buffer form: copies in, runs, copies out, synchronises. */
+int mq_map_batch(mq_index *idx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out);
+/* Device-resident form: all pointers are device memory on the index's device; asynchronous on `stream`
+ * (a hipStream_t, may be NULL).  max_len = longest read in the batch (0 => computed on the host is not possible:
+ * must be given).  No allocation happens here unless the scratch has to grow for a larger max_len / n. */
+int mq_map_batch_device(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint32_t max_len,
+                        mq_hit *d_out, void *stream);
+/* Pre-size the per-launch scratch so that mq_map_batch_device never allocates. */
+int mq_map_reserve(mq_index *idx, uint32_t max_len);
+
+/* Parity/debug: the k-min-mers of each sequence as KminmersIterator yields them (src/mers.rs:41-54).
+ * kmm_offsets (n+1, host) gives each sequence's capacity window in `out`; counts[i] receives the true count. */
+int mq_kminmers_batch(mq_index *idx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, const uint64_t *kmm_offsets,
+                      mq_kminmer *out, uint32_t *counts);
+
+/* Parity/debug: probe the finalized table (ReadOnlyIndex::get, src/index.rs:118-126).  found[i]=1 on a live hit;
+ * entries[i] = {hash, start, end, offset, rev=rc} with ref ids in ref_ids[i]. */
+int mq_index_lookup(mq_index *idx, const uint64_t *hashes, uint32_t n, uint8_t *found, mq_kminmer *entries, uint32_t *ref_ids);
+
+/* The format! of src/mers.rs:181 (no newline).  Returns the length or <0. */
+int mq_format_paf(const mq_index *idx, const char *q_id, uint64_t q_len, const mq_hit *hit, char *buf, size_t cap);
+
+/* Timing of the last mq_map_batch_device launch sequence on its stream, from HIP events recorded around the
+ * kernels (milliseconds).  Synchronises on the end event. */
+int mq_last_map_ms(mq_index *idx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

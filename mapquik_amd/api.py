@@ -1,0 +1,256 @@
+"""ctypes binding of libmapquik_hip.so + host mirror of the reference's interface for the hot path.
+
+Reference seam (Rust): mers::ref_extract (src/mers.rs:15), mers::find_matches (src/mers.rs:77), Index/ReadOnlyIndex
+(src/index.rs:73-128), Params (src/main.rs:33-47).  Same names and argument meaning here; errors raise MapquikError
+(the reference panics).  There is NO CPU fallback: if the HIP library or a GPU is missing, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+MQ_HIT_UNMAPPED, MQ_HIT_MAPPED, MQ_HIT_OVERFLOW = 0, 1, 2
+
+hit_dtype = np.dtype([("status", "<u4"), ("ref_id", "<u4"), ("rc", "<u4"), ("mapq", "<u4"), ("q_start", "<u4"), ("q_end", "<u4"),
+                      ("r_start", "<u4"), ("r_end", "<u4"), ("score", "<u4"), ("n_kminmers", "<u4")])
+kminmer_dtype = np.dtype([("hash", "<u8"), ("start", "<u4"), ("end", "<u4"), ("offset", "<u4"), ("rev", "<u4")])
+assert hit_dtype.itemsize == 40 and kminmer_dtype.itemsize == 24
+
+# every symbol include/mapquik_hip.h declares
+EXPORTS = ["mq_last_error", "mq_abi_version", "mq_device_count", "mq_params_default", "mq_index_new", "mq_index_free",
+           "mq_index_add_ref", "mq_index_add_ref_device", "mq_index_finalize", "mq_index_get_stats", "mq_index_ref_info",
+           "mq_map_batch", "mq_map_batch_device", "mq_map_reserve", "mq_kminmers_batch", "mq_index_lookup", "mq_format_paf",
+           "mq_last_map_ms"]
+
+
+class MapquikError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """src/main.rs:33-47; defaults src/main.rs:174-188."""
+    _fields_ = [("k", C.c_uint32), ("l", C.c_uint32), ("density", C.c_double), ("use_hpc", C.c_uint32), ("c", C.c_uint32),
+                ("s", C.c_uint32), ("g", C.c_uint32), ("reserved", C.c_uint32)]
+
+    def __init__(self, k=5, l=31, density=0.01, use_hpc=True, c=4, s=11, g=2000):
+        super().__init__(k, l, density, 1 if use_hpc else 0, c, s, g, 0)
+
+
+class IndexStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_refs", "n_kminmers", "n_keys", "n_unique", "table_slots", "table_bytes", "slot_bytes")]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load (building if stale) the HIP library.  Raises MapquikError when it cannot be built or loaded."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _build.LIB
+    if path is None:
+        try:
+            _build.build()
+        except Exception as e:  # no hipcc on this box: fine if a prebuilt .so travelled with the snapshot
+            if not os.path.exists(p):
+                raise MapquikError("libmapquik_hip.so is missing and could not be built: %s" % e)
+    try:
+        L = C.CDLL(p)
+    except OSError as e:
+        raise MapquikError("cannot load %s: %s" % (p, e))
+    vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+    L.mq_last_error.restype = C.c_char_p
+    L.mq_abi_version.restype = C.c_int
+    L.mq_device_count.restype = C.c_int
+    L.mq_params_default.argtypes = [C.POINTER(Params)]
+    L.mq_index_new.restype = vp
+    L.mq_index_new.argtypes = [C.POINTER(Params), C.c_int]
+    L.mq_index_free.argtypes = [vp]
+    L.mq_index_add_ref.restype = C.c_int64
+    L.mq_index_add_ref.argtypes = [vp, u32, C.c_char_p, vp, u64]
+    L.mq_index_add_ref_device.restype = C.c_int64
+    L.mq_index_add_ref_device.argtypes = [vp, u32, C.c_char_p, vp, u64]
+    L.mq_index_finalize.restype = C.c_int64
+    L.mq_index_finalize.argtypes = [vp]
+    L.mq_index_get_stats.argtypes = [vp, C.POINTER(IndexStats)]
+    L.mq_index_ref_info.argtypes = [vp, u32, C.POINTER(C.c_char_p), C.POINTER(u64)]
+    L.mq_map_batch.argtypes = [vp, vp, vp, u32, vp]
+    L.mq_map_batch_device.argtypes = [vp, vp, vp, u32, u32, vp, vp]
+    L.mq_map_reserve.argtypes = [vp, u32]
+    L.mq_kminmers_batch.argtypes = [vp, vp, vp, u32, vp, vp, vp]
+    L.mq_index_lookup.argtypes = [vp, vp, u32, vp, vp, vp]
+    L.mq_format_paf.argtypes = [vp, C.c_char_p, u64, vp, C.c_char_p, C.c_size_t]
+    L.mq_last_map_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    if path is None:
+        _lib = L
+    return L
+
+
+def _err(L, what):
+    return MapquikError("%s: %s" % (what, (L.mq_last_error() or b"").decode(errors="replace")))
+
+
+def device_count():
+    return load_library().mq_device_count()
+
+
+def _seq(seq):
+    if isinstance(seq, (bytes, bytearray, memoryview)):
+        return np.frombuffer(bytes(seq), dtype=np.uint8)
+    return np.ascontiguousarray(seq, dtype=np.uint8)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Index:
+    """Index + ReadOnlyIndex (src/index.rs:73-128) + ref_map (src/closures.rs:30), resident in HBM."""
+
+    def __init__(self, params=None, device=0):
+        self._L = load_library()
+        self.params = params or Params()
+        self._h = self._L.mq_index_new(C.byref(self.params), device)
+        if not self._h:
+            raise _err(self._L, "mq_index_new")
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mq_index_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def handle(self):
+        return self._h
+
+    def add_ref(self, ref_idx, name, seq):
+        """index_mers closure (src/closures.rs:46-51): returns the reference's k-min-mer count."""
+        s = _seq(seq)
+        n = self._L.mq_index_add_ref(self._h, ref_idx, name.encode(), _p(s), s.size)
+        if n < 0:
+            raise _err(self._L, "mq_index_add_ref")
+        return n
+
+    def add_ref_device(self, ref_idx, name, d_ptr, length):
+        n = self._L.mq_index_add_ref_device(self._h, ref_idx, name.encode(), C.c_void_p(d_ptr), length)
+        if n < 0:
+            raise _err(self._L, "mq_index_add_ref_device")
+        return n
+
+    def finalize(self):
+        """get_count + into_read_only (src/closures.rs:92-94): returns the unique k-min-mer count."""
+        n = self._L.mq_index_finalize(self._h)
+        if n < 0:
+            raise _err(self._L, "mq_index_finalize")
+        return n
+
+    def stats(self):
+        st = IndexStats()
+        if self._L.mq_index_get_stats(self._h, C.byref(st)) != 0:
+            raise _err(self._L, "mq_index_get_stats")
+        return {n: getattr(st, n) for n, _ in IndexStats._fields_}
+
+    def ref_info(self, ref_id):
+        name, ln = C.c_char_p(), C.c_uint64()
+        if self._L.mq_index_ref_info(self._h, ref_id, C.byref(name), C.byref(ln)) != 0:
+            raise _err(self._L, "mq_index_ref_info")
+        return name.value.decode(), ln.value
+
+    def map_batch(self, bases, offsets):
+        """find_matches for every read (host buffers)."""
+        bases = _seq(bases)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        out = np.zeros(max(n, 0), dtype=hit_dtype)
+        if n > 0 and self._L.mq_map_batch(self._h, _p(bases), _p(offsets), n, _p(out)) != 0:
+            raise _err(self._L, "mq_map_batch")
+        return out
+
+    def map_batch_device(self, d_bases, d_offsets, n, max_len, d_out, stream=0):
+        rc = self._L.mq_map_batch_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n, max_len, C.c_void_p(d_out),
+                                         C.c_void_p(stream))
+        if rc != 0:
+            raise _err(self._L, "mq_map_batch_device")
+
+    def reserve(self, max_len):
+        if self._L.mq_map_reserve(self._h, max_len) != 0:
+            raise _err(self._L, "mq_map_reserve")
+
+    def last_map_ms(self):
+        ms = C.c_float()
+        if self._L.mq_last_map_ms(self._h, C.byref(ms)) != 0:
+            raise _err(self._L, "mq_last_map_ms")
+        return ms.value
+
+    def kminmers_batch(self, bases, offsets, caps=None):
+        """KminmersIterator output per sequence (src/mers.rs:41-54): list of structured arrays."""
+        bases = _seq(bases)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        if caps is None:  # one k-min-mer per base is an upper bound
+            caps = (offsets[1:] - offsets[:-1]).astype(np.uint64)
+        koff = np.zeros(n + 1, dtype=np.uint64)
+        koff[1:] = np.cumsum(np.asarray(caps, dtype=np.uint64))
+        out = np.zeros(int(koff[-1]), dtype=kminmer_dtype)
+        counts = np.zeros(n, dtype=np.uint32)
+        if n > 0 and self._L.mq_kminmers_batch(self._h, _p(bases), _p(offsets), n, _p(koff), _p(out), _p(counts)) != 0:
+            raise _err(self._L, "mq_kminmers_batch")
+        res = []
+        for i in range(n):
+            c = int(counts[i])
+            if c > int(koff[i + 1] - koff[i]):
+                raise MapquikError("k-min-mer window too small for sequence %d: %d > %d" % (i, c, int(koff[i + 1] - koff[i])))
+            res.append(out[int(koff[i]):int(koff[i]) + c].copy())
+        return res
+
+    def lookup(self, hashes):
+        """ReadOnlyIndex::get (src/index.rs:118-126) for many hashes."""
+        h = np.ascontiguousarray(hashes, dtype=np.uint64)
+        n = h.size
+        found = np.zeros(n, dtype=np.uint8)
+        ent = np.zeros(n, dtype=kminmer_dtype)
+        ids = np.zeros(n, dtype=np.uint32)
+        if n > 0 and self._L.mq_index_lookup(self._h, _p(h), n, _p(found), _p(ent), _p(ids)) != 0:
+            raise _err(self._L, "mq_index_lookup")
+        return found, ent, ids
+
+    def format_paf(self, q_id, q_len, hit):
+        rec = np.zeros(1, dtype=hit_dtype)
+        rec[0] = hit
+        buf = C.create_string_buffer(4096)
+        w = self._L.mq_format_paf(self._h, q_id.encode(), int(q_len), _p(rec), buf, 4096)
+        if w < 0:
+            raise _err(self._L, "mq_format_paf")
+        return buf.value.decode()
+
+    def paf_lines(self, names, offsets, hits):
+        """PAF text in input order; unmapped reads produce no line (src/closures.rs:117-123)."""
+        out = []
+        for i, name in enumerate(names):
+            st = int(hits[i]["status"])
+            if st == MQ_HIT_OVERFLOW:
+                raise MapquikError("read %s: Match-run scratch overflow (raise MQ_MATCH_CAP)" % name)
+            if st == MQ_HIT_MAPPED:
+                out.append(self.format_paf(name, int(offsets[i + 1] - offsets[i]), hits[i]))
+        return out
+
+
+def ref_extract(ref_idx, inp_seq_raw, params, mers_index, name=None):
+    """mers::ref_extract (src/mers.rs:15-38) + ref_map.insert (src/closures.rs:49)."""
+    assert params is mers_index.params or bytes(params) == bytes(mers_index.params)
+    return mers_index.add_ref(ref_idx, name if name is not None else str(ref_idx), inp_seq_raw)
+
+
+def find_matches(q_id, q_len, q_str, ref_map, mers_index, params):
+    """mers::find_matches (src/mers.rs:77-102): the PAF line or None.  ref_map is carried by the index."""
+    s = _seq(q_str)
+    assert q_len == s.size
+    hits = mers_index.map_batch(s, np.array([0, s.size], dtype=np.uint64))
+    lines = mers_index.paf_lines([q_id], [0, s.size], hits)
+    return lines[0] if lines else None

@@ -1,0 +1,604 @@
+// mq_device.hpp -- gfx950 device code for mapquik's hot path (seeding, index probe, Match runs, pseudo-chain).
+//
+// One wavefront (64 lanes) owns one sequence (or one segment of a long reference).  Everything is
+// integer / byte work: no MFMA.  Structure of the streaming seeder (lanes = consecutive positions):
+//   raw bytes --(head flags, ballot/mbcnt compaction)--> HPC ring in LDS --(64-wide XOR prefix scan of
+//   rotated ntHash seeds)--> canonical l-mer hashes --(density predicate, ballot compaction)--> ordered
+//   minimizer list in LDS --> sink (k-min-mers -> probe -> runs, or a global minimizer list).
+//
+// ntHash without a serial roll: with X(t) = XOR_{u<=t} ror(h(c_u), u) and Y(t) = XOR_{u<=t} rol(hc(c_u), u),
+//   fh(window ending at e) = rol(X(e) ^ X(e-l), e)        rh = ror(Y(e) ^ Y(e-l), e-l+1)
+// (all rotation amounts mod 64; blocks of 64 HPC positions are 64-aligned so amounts are lane constants).
+//
+// Reference semantics restated here (citations relative to the reference tree):
+//   KminmersIterator (rust-seq2kminmers, call sites src/mers.rs:27,53)   -> seed_segment + MapSink::consume
+//   ReadOnlyIndex::get (src/index.rs:118-126)                           -> probe_table
+//   Match::new/update/check/extend (src/match.rs:20-58), chain_matches (src/mers.rs:57-73) -> MapSink::runs
+//   Chain::get_match (src/chain.rs:147-169) and helpers                  -> chain_stage
+//   find_largest_two_chains/determine_best_match/find_coords (src/mers.rs:104-183) -> chain_stage
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mapquik_hip.h"
+
+namespace mq {
+
+constexpr int WAVE = 64;
+constexpr int RING = 256;    // HPC ring entries kept per wave (>= 64 + 64 + l)
+constexpr int MZ_CAP = 160;  // < (64 + k - 1) carried + 64 appended, k <= 32
+constexpr int MAX_K = 32;
+constexpr int MAX_L = 64;
+
+struct DevParams {
+    uint64_t bound;  // density bound: keep l-mer iff min(fh,rh) <= bound
+    uint32_t k, l, use_hpc, c, s, g;
+    uint32_t pad;
+};
+
+// 32-byte table slot: one aligned 32-B sector per probe.  key==0 <=> empty (a real key 0 lives in the extra slot).
+struct alignas(32) Slot {
+    unsigned long long key;
+    uint32_t start, end, offset, id_rc;
+    uint32_t count;  // times this key was inserted; live iff count == 1 && end != 0 (src/index.rs:67-69,94-104)
+    uint32_t pad;
+};
+static_assert(sizeof(Slot) == 32, "slot size");
+
+// reference k-min-mer waiting for insertion (same layout as mq_kminmer, rev field = id<<1|rc)
+struct alignas(8) RefKmm {
+    unsigned long long hash;
+    uint32_t start, end, offset, id_rc;
+};
+static_assert(sizeof(RefKmm) == 24, "RefKmm size");
+
+struct alignas(16) Minimizer {
+    unsigned long long hash;
+    uint32_t pos;
+    uint32_t pad;
+};
+
+// src/match.rs:10-18 plus the ref id of the run's first entry (src/mers.rs:68) and a "grouped" flag
+struct alignas(16) MatchRec {
+    uint32_t q_start, q_end, r_start, r_end, count, ref, rc, done;
+};
+
+struct WaveLds {
+    unsigned long long mz_hash[MZ_CAP];
+    uint32_t mz_pos[MZ_CAP];
+    uint32_t ring_pos[RING];
+    uint8_t ring_code[RING];
+};
+
+// ------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ uint64_t rdlane64(uint64_t v, int l) {
+    return ((uint64_t)rdlane((uint32_t)(v >> 32), l) << 32) | rdlane((uint32_t)v, l);
+}
+__device__ __forceinline__ uint32_t rdfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
+    uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64);
+    uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int d) {
+    uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64);
+    uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, uint32_t r) { return __builtin_rotateleft64(x, (uint64_t)(r & 63u)); }
+__device__ __forceinline__ uint64_t rotr64(uint64_t x, uint32_t r) { return __builtin_rotateright64(x, (uint64_t)(r & 63u)); }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------ ntHash-1 seeds (64-bit), non-ACGT -> 0
+__device__ __forceinline__ uint32_t base_code(uint32_t b) {
+    return b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 4u;
+}
+__device__ __forceinline__ uint64_t nt_seed(uint32_t code) {
+    return code == 0 ? 0x3c8bfbb395c60474ULL
+         : code == 1 ? 0x3193c18562a02b4cULL
+         : code == 2 ? 0x20323ed082572324ULL
+         : code == 3 ? 0x295549f54be24456ULL
+                     : 0ULL;
+}
+__device__ __forceinline__ uint32_t comp_code(uint32_t code) { return code < 4 ? 3u - code : 4u; }
+
+// ------------------------------------------------------------------ SipHash-1-3, key 0 (Rust DefaultHasher) over [len, m_0..m_{k-1}]
+#define MQ_SIPROUND(v0, v1, v2, v3) \
+    do {                            \
+        v0 += v1;                   \
+        v1 = rotl64(v1, 13);        \
+        v1 ^= v0;                   \
+        v0 = rotl64(v0, 32);        \
+        v2 += v3;                   \
+        v3 = rotl64(v3, 16);        \
+        v3 ^= v2;                   \
+        v0 += v3;                   \
+        v3 = rotl64(v3, 21);        \
+        v3 ^= v0;                   \
+        v2 += v1;                   \
+        v1 = rotl64(v1, 17);        \
+        v1 ^= v2;                   \
+        v2 = rotl64(v2, 32);        \
+    } while (0)
+
+struct Sip13 {
+    uint64_t v0, v1, v2, v3;
+    __device__ __forceinline__ void init() {
+        v0 = 0x736f6d6570736575ULL;
+        v1 = 0x646f72616e646f6dULL;
+        v2 = 0x6c7967656e657261ULL;
+        v3 = 0x7465646279746573ULL;
+    }
+    __device__ __forceinline__ void word(uint64_t m) {
+        v3 ^= m;
+        MQ_SIPROUND(v0, v1, v2, v3);
+        v0 ^= m;
+    }
+    __device__ __forceinline__ uint64_t finish(uint32_t nbytes) {
+        uint64_t b = (uint64_t)(nbytes & 0xffu) << 56;
+        v3 ^= b;
+        MQ_SIPROUND(v0, v1, v2, v3);
+        v0 ^= b;
+        v2 ^= 0xff;
+        MQ_SIPROUND(v0, v1, v2, v3);
+        MQ_SIPROUND(v0, v1, v2, v3);
+        MQ_SIPROUND(v0, v1, v2, v3);
+        return v0 ^ v1 ^ v2 ^ v3;
+    }
+};
+
+// canonical orientation + tuple hash of k minimizer hashes read through `get(i)`, i = 0..k-1 (forward order)
+template <class Get>
+__device__ __forceinline__ uint64_t kminmer_hash(uint32_t k, Get get, bool &rev) {
+    rev = false;
+    for (uint32_t i = 0; i < k; ++i) {
+        uint64_t a = get(i), b = get(k - 1 - i);
+        if (b < a) { rev = true; break; }
+        if (b > a) break;
+    }
+    Sip13 h;
+    h.init();
+    h.word((uint64_t)k);
+    for (uint32_t i = 0; i < k; ++i) h.word(rev ? get(k - 1 - i) : get(i));
+    return h.finish(8u * (k + 1u));
+}
+
+// ------------------------------------------------------------------ index probe (ReadOnlyIndex::get, src/index.rs:118-126)
+// table has nslots = mask+1 slots plus one extra slot [nslots] for the key 0.
+__device__ __forceinline__ bool probe_table(const Slot *__restrict__ table, uint64_t mask, uint64_t key, Slot &out) {
+    if (key == 0) {
+        out = table[mask + 1];
+        return out.count == 1 && out.end != 0;
+    }
+    uint64_t s = key & mask;  // identity hasher (src/index.rs:11-39): the key is the table hash
+    for (;;) {
+        Slot v = table[s];
+        if (v.key == key) {
+            out = v;
+            return v.count == 1 && v.end != 0;
+        }
+        if (v.key == 0) return false;
+        s = (s + 1) & mask;
+    }
+}
+
+// ------------------------------------------------------------------ streaming seeder
+// Emits, in order, every minimizer whose l-mer starts at a homopolymer-run head with raw index in [a, b).
+// Sink interface: void on_minimizers(WaveLds&, uint32_t &mz_count)  (called after each block, wave-uniform)
+template <class Sink>
+__device__ __forceinline__ void seed_segment(const uint8_t *__restrict__ seq, uint64_t len, uint64_t a, uint64_t b,
+                                             const DevParams &P, WaveLds &S, Sink &sink, uint32_t &mz_count) {
+    const uint32_t lane = lane_id();
+    const uint32_t l = P.l;
+    if (a >= len || a >= b) return;
+    uint32_t hbase = 0, hproc = 0;  // HPC positions seen / folded into the scan (segment-local, wave-uniform)
+    uint32_t s_elig = 0;            // heads with raw index < b
+    uint64_t prevF = 0, prevR = 0;  // per-lane inclusive prefixes of the previous block
+    uint64_t carryF = 0, carryR = 0;
+    uint32_t prev_byte = a > 0 ? (uint32_t)seq[a - 1] : 0x100u;
+    // lane constants
+    const uint32_t from = (lane - l) & 63u;
+    const bool src_cur = lane + l <= 63u;
+    const uint32_t rot_r = (lane - l + 1u) & 63u;
+
+    auto process_block = [&](uint32_t nvalid) {
+        const uint32_t idx = hproc + lane;
+        const bool valid = lane < nvalid;
+        const uint32_t code = valid ? (uint32_t)S.ring_code[idx & (RING - 1)] : 4u;
+        uint64_t tf = rotr64(nt_seed(code), lane);
+        uint64_t tr = rotl64(nt_seed(comp_code(code)), lane);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint64_t of = shfl_up64(tf, d), orr = shfl_up64(tr, d);
+            if (lane >= (uint32_t)d) {
+                tf ^= of;
+                tr ^= orr;
+            }
+        }
+        tf ^= carryF;
+        tr ^= carryR;
+        const uint64_t of = shfl64(src_cur ? tf : prevF, (int)from);
+        const uint64_t orr = shfl64(src_cur ? tr : prevR, (int)from);
+        const uint64_t fh = rotl64(tf ^ of, lane);
+        const uint64_t rh = rotr64(tr ^ orr, rot_r);
+        const uint64_t h = fh < rh ? fh : rh;
+        const uint32_t j = idx - (l - 1u);  // HPC index of the window's first base
+        const bool sel = valid && idx >= l - 1u && j < s_elig && h <= P.bound;
+        const uint64_t sm = __ballot(sel);
+        if (sel) {
+            const uint32_t o = mz_count + mbcnt64(sm);
+            S.mz_hash[o] = h;
+            S.mz_pos[o] = S.ring_pos[j & (RING - 1)];
+        }
+        mz_count += (uint32_t)__popcll(sm);
+        prevF = tf;
+        prevR = tr;
+        carryF = rdlane64(tf, 63);
+        carryR = rdlane64(tr, 63);
+        __syncthreads();
+        sink.on_minimizers(S, mz_count);
+    };
+
+    for (uint64_t pos = a;; pos += 64) {
+        const uint64_t i = pos + lane;
+        const bool inr = i < len;
+        const uint32_t bt = inr ? (uint32_t)seq[i] : 0u;
+        uint32_t pb = (uint32_t)__shfl_up((int)bt, 1, 64);
+        if (lane == 0) pb = prev_byte;
+        const bool head = inr && (!P.use_hpc || bt != pb);
+        const uint64_t hm = __ballot(head);
+        if (head) {
+            const uint32_t hi = (hbase + mbcnt64(hm)) & (RING - 1);
+            S.ring_code[hi] = (uint8_t)base_code(bt);
+            S.ring_pos[hi] = (uint32_t)i;
+        }
+        s_elig += (uint32_t)__popcll(hm & __ballot(i < b));
+        hbase += (uint32_t)__popcll(hm);
+        const uint64_t inm = __ballot(inr);
+        prev_byte = rdlane(bt, 63 - __clzll((long long)inm));
+        __syncthreads();
+        if (hbase - hproc >= 64u) {
+            process_block(64u);
+            hproc += 64u;
+        }
+        const bool end_of_seq = pos + 64 >= len;
+        const bool past = (pos + 64 >= b) && (hbase >= s_elig + l - 1u);
+        if (end_of_seq || past) break;
+    }
+    if (hbase > hproc) process_block(hbase - hproc);
+}
+
+// ------------------------------------------------------------------ chain helpers (src/chain.rs)
+__device__ __forceinline__ uint64_t abs_as_usize(int32_t x) {
+    int32_t a = x < 0 ? (int32_t)(0u - (uint32_t)x) : x;  // i32::MIN.abs() wraps in release
+    return (uint64_t)(int64_t)a;
+}
+// fwd_gap_too_long / rc_gap_too_long (src/chain.rs:132-142): `as i32` casts, wrapping subtraction
+__device__ __forceinline__ bool gap_too_long(uint32_t v_q_s, uint32_t u_q_e, uint32_t x, uint32_t y, uint32_t g) {
+    int32_t g1 = (int32_t)(v_q_s - u_q_e);
+    int32_t g2 = (int32_t)(x - y);
+    return abs_as_usize((int32_t)((uint32_t)g1 - (uint32_t)g2)) > (uint64_t)g;
+}
+// check_match_compatible (src/chain.rs:43-63), h1 = anchor
+__device__ __forceinline__ bool match_compatible(const MatchRec &h1, const MatchRec &h2, uint32_t g) {
+    if (h1.q_start == h2.q_start && h1.q_end == h2.q_end && h1.r_start == h2.r_start && h1.r_end == h2.r_end &&
+        h1.count == h2.count && h1.rc == h2.rc)
+        return true;
+    if (h1.rc != h2.rc) return false;
+    const bool h1_first = h1.q_start < h2.q_start;
+    const MatchRec &u = h1_first ? h1 : h2;
+    const MatchRec &v = h1_first ? h2 : h1;
+    if (u.rc) {
+        if (u.r_start <= v.r_start || gap_too_long(v.q_start, u.q_end, u.r_start, v.r_end, g)) return false;
+    } else if (v.r_start <= u.r_start || gap_too_long(v.q_start, u.q_end, v.r_start, u.r_end, g)) {
+        return false;
+    }
+    return true;
+}
+
+__device__ __forceinline__ MatchRec rd_match(const MatchRec &m, int l) {
+    MatchRec r;
+    r.q_start = rdlane(m.q_start, l);
+    r.q_end = rdlane(m.q_end, l);
+    r.r_start = rdlane(m.r_start, l);
+    r.r_end = rdlane(m.r_end, l);
+    r.count = rdlane(m.count, l);
+    r.ref = rdlane(m.ref, l);
+    r.rc = rdlane(m.rc, l);
+    r.done = 0;
+    return r;
+}
+
+// Per-reference Chain::get_match + best-of + find_coords.  CH = lanes used per chunk (64; smaller only in tests
+// so that ordinary inputs exercise the multi-chunk path).
+template <int CH>
+__device__ __forceinline__ void chain_stage(MatchRec *__restrict__ scratch, uint32_t nm, const DevParams &P, uint64_t q_len,
+                                            const uint64_t *__restrict__ ref_lens, mq_hit &out) {
+    const uint32_t lane = lane_id();
+    // find_largest_two_chains state (src/mers.rs:110-129)
+    uint32_t max_count = 0, second_count = 0, n_cand = 0;
+    MatchRec bfirst = {}, blast = {};
+    uint32_t b_ref = 0, b_score = 0, b_mapq = 0, b_len = 0;
+    for (uint32_t c0 = 0; c0 < nm; c0 += CH) {
+        const bool v0 = lane < (uint32_t)CH && c0 + lane < nm;
+        MatchRec m = {};
+        if (v0) m = scratch[c0 + lane];
+        uint64_t pending = __ballot(v0 && !m.done);
+        while (pending) {
+            const int lead = __ffsll((long long)pending) - 1;
+            const uint32_t r = rdlane(m.ref, lead);
+            // pass A: Chain::len and find_largest_match (src/chain.rs:93-104): first index with the largest count
+            uint32_t n_in = 0, best_cnt = 0;
+            MatchRec anchor = {};
+            for (uint32_t c = c0; c < nm; c += CH) {
+                const bool v = lane < (uint32_t)CH && c + lane < nm;
+                MatchRec x = {};
+                if (c == c0) x = m;
+                else if (v) x = scratch[c + lane];
+                const bool in = v && x.ref == r && !x.done;
+                const uint64_t im = __ballot(in);
+                if (!im) continue;
+                n_in += (uint32_t)__popcll(im);
+                const uint32_t cnt = in ? x.count : 0u;
+                const uint32_t mx = wave_max_u32(cnt);
+                if (mx > best_cnt) {
+                    const int fl = __ffsll((long long)__ballot(in && cnt == mx)) - 1;
+                    best_cnt = mx;
+                    anchor = rd_match(x, fl);
+                }
+            }
+            // pass B: filter_matches_max (src/chain.rs:123-129) when len > 1; first/last kept, score
+            uint32_t nkept = 0, score = 0;
+            MatchRec first = {}, last = {};
+            for (uint32_t c = c0; c < nm; c += CH) {
+                const bool v = lane < (uint32_t)CH && c + lane < nm;
+                MatchRec x = {};
+                if (c == c0) x = m;
+                else if (v) x = scratch[c + lane];
+                const bool in = v && x.ref == r && !x.done;
+                const uint64_t im = __ballot(in);
+                if (!im) continue;
+                if (c != c0 && in) scratch[c + lane].done = 1u;
+                const bool keep = in && (n_in <= 1u || match_compatible(anchor, x, P.g));
+                const uint64_t km = __ballot(keep);
+                if (!km) continue;
+                if (nkept == 0) first = rd_match(x, __ffsll((long long)km) - 1);
+                last = rd_match(x, 63 - __clzll((long long)km));
+                nkept += (uint32_t)__popcll(km);
+                score += wave_sum_u32(keep ? x.count : 0u);
+            }
+            pending &= ~__ballot(v0 && m.ref == r);
+            if (nkept == 0) continue;  // len_f == 0 => None (cannot happen: the anchor is compatible with itself)
+            // find_largest_two_chains update (strict >)
+            n_cand++;
+            if (score > max_count) {
+                second_count = max_count;
+                max_count = score;
+                bfirst = first;
+                blast = last;
+                b_ref = r;
+                b_score = score;
+                b_len = nkept;
+                b_mapq = ((P.s != 0 && P.c != 0) && (nkept >= P.c || score >= P.s)) ? 60u : 0u;
+            } else if (score > second_count) {
+                second_count = score;
+            }
+        }
+    }
+    out.status = MQ_HIT_UNMAPPED;
+    out.ref_id = 0;
+    out.rc = 0;
+    out.mapq = 0;
+    out.q_start = out.q_end = out.r_start = out.r_end = out.score = 0;
+    if (n_cand == 0) return;
+    if (n_cand > 1 && max_count == second_count) return;  // determine_best_match: tie => None (src/mers.rs:106)
+    // get_match coordinates (src/chain.rs:162-168), usize arithmetic
+    const bool rc = bfirst.rc != 0;
+    const uint64_t q_start = bfirst.q_start;
+    const uint64_t q_end = (uint64_t)blast.q_end - 1;
+    uint64_t r_start, r_end;
+    if (rc && b_len > 1) {
+        r_start = blast.r_start;
+        r_end = (uint64_t)bfirst.r_end - 1;
+    } else {
+        r_start = bfirst.r_start;
+        r_end = (uint64_t)blast.r_end - 1;
+    }
+    // find_coords (src/mers.rs:131-183)
+    const uint64_t r_len = ref_lens[b_ref];
+    const uint64_t tail = q_len - q_end - 1;
+    uint64_t frs, fre, exc_s, exc_e;
+    if (!rc) {
+        if (r_start >= q_start) { frs = r_start - q_start; exc_s = q_start; }
+        else { frs = 0; exc_s = r_start; }
+        if (r_end + tail <= r_len - 1) { fre = r_end + tail; exc_e = tail; }
+        else { fre = r_len - 1; exc_e = r_len - r_end - 1; }
+    } else {
+        if (r_end + q_start <= r_len - 1) { fre = r_end + q_start; exc_s = q_start; }
+        else { fre = r_len - 1; exc_s = r_len - r_end - 1; }
+        if (r_start >= tail) { frs = r_start - tail; exc_e = tail; }
+        else { frs = 0; exc_e = r_start; }
+    }
+    out.status = MQ_HIT_MAPPED;
+    out.ref_id = b_ref;
+    out.rc = rc ? 1u : 0u;
+    out.mapq = b_mapq;
+    out.q_start = (uint32_t)(q_start - exc_s);
+    out.q_end = (uint32_t)(q_end + exc_e);
+    out.r_start = (uint32_t)frs;
+    out.r_end = (uint32_t)fre;
+    out.score = b_score;
+}
+
+// ------------------------------------------------------------------ sink of the fused map path
+struct MapSink {
+    const Slot *__restrict__ table;
+    uint64_t mask;
+    const DevParams &P;
+    MatchRec *__restrict__ scratch;
+    uint32_t cap_matches;
+    mq_kminmer *__restrict__ dump;  // optional k-min-mer dump window for this read
+    uint32_t dump_cap;
+    // wave-uniform state
+    uint32_t kmm_count = 0;
+    uint32_t n_matches = 0;
+    bool open = false;
+    MatchRec M = {};
+    uint32_t p_id = 0, p_off = 0;
+
+    __device__ MapSink(const Slot *t, uint64_t m, const DevParams &p, MatchRec *s, uint32_t cap, mq_kminmer *d, uint32_t dc)
+        : table(t), mask(m), P(p), scratch(s), cap_matches(cap), dump(d), dump_cap(dc) {}
+
+    __device__ __forceinline__ void emit() {
+        if (n_matches < cap_matches && lane_id() == 0) scratch[n_matches] = M;
+        n_matches++;
+        open = false;
+    }
+
+    // k-min-mers [0, n) of the LDS minimizer list: hash, probe, extend runs
+    __device__ __forceinline__ void consume(WaveLds &S, uint32_t n) {
+        const uint32_t lane = lane_id();
+        const uint32_t k = P.k;
+        const bool act = lane < n;
+        bool rev = false, hit = false;
+        uint64_t key = 0;
+        uint32_t q_start = 0, q_end = 0;
+        Slot e = {};
+        if (act) {
+            key = kminmer_hash(k, [&](uint32_t i) { return (uint64_t)S.mz_hash[lane + i]; }, rev);
+            q_start = S.mz_pos[lane];
+            q_end = S.mz_pos[lane + k - 1] + P.l - 1u;
+            hit = probe_table(table, mask, key, e);
+            if (dump && kmm_count + lane < dump_cap) {
+                mq_kminmer d;
+                d.hash = key;
+                d.start = q_start;
+                d.end = q_end;
+                d.offset = kmm_count + lane;
+                d.rev = rev ? 1u : 0u;
+                dump[kmm_count + lane] = d;
+            }
+        }
+        kmm_count += n;
+        // chain_matches + Match::extend (src/mers.rs:57-73, src/match.rs:45-58) over the batch, wave-uniform
+        const uint64_t hitmask = __ballot(hit);
+        const uint32_t srel_v = (rev != ((e.id_rc & 1u) != 0)) ? 1u : 0u;  // q.rev != r.rc
+        uint64_t hm = hitmask;
+        while (hm) {
+            const int i = __ffsll((long long)hm) - 1;
+            hm &= hm - 1;
+            const bool adjacent = (i == 0) ? true : ((hitmask >> (i - 1)) & 1ull) != 0;
+            if (!adjacent && open) emit();  // a miss in between was consumed and ended the run
+            const uint32_t r_id = rdlane(e.id_rc, i) >> 1;
+            const uint32_t r_start = rdlane(e.start, i), r_end = rdlane(e.end, i), r_off = rdlane(e.offset, i);
+            const uint32_t qs = rdlane(q_start, i), qe = rdlane(q_end, i);
+            const uint32_t srel = rdlane(srel_v, i);
+            if (open) {
+                // Match::check (src/match.rs:39-43): (A && B && C) || D
+                bool ok;
+                if (M.rc) ok = (r_id == p_id) && (srel == 1u) && ((int32_t)(p_off - r_off) == 1);
+                else ok = ((int32_t)(r_off - p_off) == 1);
+                if (ok) {  // Match::update (src/match.rs:31-37)
+                    if (M.rc) M.r_start = r_start;
+                    else M.r_end = r_end;
+                    M.q_end = qe;
+                    M.count += 1;
+                    p_id = r_id;
+                    p_off = r_off;
+                    continue;
+                }
+                emit();  // a hit that fails check is not consumed: it starts the next Match
+            }
+            // Match::new (src/match.rs:20-29)
+            M.q_start = qs;
+            M.q_end = qe;
+            M.r_start = r_start;
+            M.r_end = r_end;
+            M.count = 1;
+            M.ref = r_id;
+            M.rc = srel;
+            M.done = 0;
+            p_id = r_id;
+            p_off = r_off;
+            open = true;
+        }
+        if (n > 0 && !((hitmask >> (n - 1)) & 1ull) && open) emit();
+    }
+
+    __device__ __forceinline__ void shift(WaveLds &S, uint32_t &mz_count) {
+        const uint32_t lane = lane_id();
+        const uint32_t rem = mz_count - 64u;
+        for (uint32_t base = 0; base < rem; base += 64u) {
+            const bool mv = base + lane < rem;
+            uint64_t h = 0;
+            uint32_t p = 0;
+            if (mv) {
+                h = S.mz_hash[64u + base + lane];
+                p = S.mz_pos[64u + base + lane];
+            }
+            __syncthreads();
+            if (mv) {
+                S.mz_hash[base + lane] = h;
+                S.mz_pos[base + lane] = p;
+            }
+            __syncthreads();
+        }
+        mz_count = rem;
+    }
+
+    __device__ __forceinline__ void on_minimizers(WaveLds &S, uint32_t &mz_count) {
+        if (mz_count >= 64u + P.k - 1u) {
+            consume(S, 64u);
+            shift(S, mz_count);
+        }
+    }
+
+    __device__ __forceinline__ void finish(WaveLds &S, uint32_t &mz_count) {
+        if (mz_count >= P.k) consume(S, mz_count - P.k + 1u);
+        if (open) emit();
+        mz_count = 0;
+    }
+};
+
+// ------------------------------------------------------------------ sink of the reference path: ordered minimizers to HBM
+struct ListSink {
+    Minimizer *__restrict__ out;
+    uint32_t cap;
+    uint32_t written = 0;  // may exceed cap (overflow detected by the host)
+    __device__ ListSink(Minimizer *o, uint32_t c) : out(o), cap(c) {}
+    __device__ __forceinline__ void on_minimizers(WaveLds &S, uint32_t &mz_count) {
+        const uint32_t lane = lane_id();
+        for (uint32_t base = 0; base < mz_count; base += 64u) {
+            const uint32_t i = base + lane;
+            if (i < mz_count && written + i < cap) {
+                Minimizer m;
+                m.hash = S.mz_hash[i];
+                m.pos = S.mz_pos[i];
+                m.pad = 0;
+                out[written + i] = m;
+            }
+        }
+        written += mz_count;
+        mz_count = 0;
+        __syncthreads();
+    }
+};
+
+}  // namespace mq

@@ -1,0 +1,152 @@
+"""GPU parity: the HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.  Bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mq():
+    import mapquik_amd
+    if mapquik_amd.device_count() <= 0:
+        pytest.fail("no HIP device visible: GPU tests must run on the GPU box")
+    return mapquik_amd
+
+
+@pytest.fixture(scope="module")
+def ecoli(simlib):
+    g, off, names = simlib.make_genome(simlib.ECOLI_LEN, seed=913)
+    return g, off, names
+
+
+def _cmp_kmm(got, want, tag):
+    assert len(got) == len(want), (tag, len(got), len(want))
+    for f in ("hash", "start", "end", "offset", "rev"):
+        assert np.array_equal(got[f].astype(np.uint64), want[f].astype(np.uint64)), (tag, f)
+
+
+PARAM_SETS = [dict(), dict(k=8, l=16, g=100), dict(use_hpc=False), dict(k=3, l=12, density=0.05), dict(k=1, l=31),
+              dict(k=7, l=64, density=0.02), dict(k=32, l=5, density=0.2), dict(k=5, l=1, density=0.3)]
+
+
+@pytest.mark.parametrize("ps", PARAM_SETS)
+def test_kminmers_match_oracle(mq, oracle, simlib, ecoli, ps):
+    g, off, names = ecoli
+    reads = simlib.make_reads(g, off, 24, seed=3, len_mean=6000, len_sd=4000, len_min=1, len_max=20000)
+    bases, offs = reads["bases"], reads["offsets"]
+    P = mq.Params(**ps)
+    po = oracle.params(**ps)
+    ix = mq.Index(P)
+    got = ix.kminmers_batch(bases, offs)
+    for i in range(offs.size - 1):
+        s = bases[int(offs[i]):int(offs[i + 1])]
+        want = oracle.kminmers(s, po) if s.size >= po.l + po.k - 1 else np.zeros(0, dtype=oracle.kminmer_dtype)
+        _cmp_kmm(got[i], want, (ps, i))
+
+
+def test_kminmers_edge_sequences(mq, oracle):
+    rng = np.random.default_rng(5)
+    seqs = [b"", b"A", b"ACGT" * 8, b"A" * 5000, b"AC" * 3000, b"ACGTN" * 700, b"N" * 4000,
+            bytes(rng.choice(list(b"ACGT"), size=35)), bytes(rng.choice(list(b"ACGT"), size=34)),
+            bytes(rng.choice(list(b"ACGTN"), size=9000)), bytes(rng.choice(list(b"ACGTacgtRYKM"), size=7000)),
+            b"A" * 3000 + bytes(rng.choice(list(b"ACGT"), size=3000)) + b"T" * 3000,
+            bytes(rng.choice(list(b"AACCGGTTTT"), size=64 * 67 + 1))]
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+    offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in seqs])
+    for ps in (dict(density=0.1), dict(density=1.0, k=2, l=4), dict(density=0.1, use_hpc=False)):
+        P, po = mq.Params(**ps), oracle.params(**ps)
+        got = mq.Index(P).kminmers_batch(bases, offs)
+        for i, s in enumerate(seqs):
+            want = oracle.kminmers(s, po) if len(s) >= po.l + po.k - 1 else np.zeros(0, dtype=oracle.kminmer_dtype)
+            _cmp_kmm(got[i], want, (ps, i))
+
+
+@pytest.mark.parametrize("ps", [dict(), dict(k=8, l=16, g=100), dict(use_hpc=False, density=0.02)])
+def test_index_matches_oracle(mq, oracle, simlib, ps):
+    g, off, names = simlib.make_genome([300000, 200001, 40, 70000], seed=11, repeat_frac=0.15, tandem_frac=0.03)
+    P, po = mq.Params(**ps), oracle.params(**ps)
+    ix, ox = mq.Index(P), oracle.Index()
+    all_h = []
+    for r in range(off.size - 1):
+        s = g[int(off[r]):int(off[r + 1])]
+        n_gpu = ix.add_ref(r, names[r], s)
+        n_cpu = ox.add_ref(r, names[r], s, po)
+        assert n_gpu == n_cpu
+        all_h.append(oracle.kminmers(s, po)["hash"] if s.size >= po.l + po.k - 1 else np.zeros(0, np.uint64))
+    assert ix.finalize() == ox.count()
+    st = ix.stats()
+    assert st["n_keys"] == ox.keys() and st["n_unique"] == ox.count()
+    hs = np.unique(np.concatenate(all_h))
+    rng = np.random.default_rng(1)
+    q = np.concatenate([hs, rng.integers(0, 2**63, size=1000, dtype=np.uint64)])
+    found, ent, ids = ix.lookup(q)
+    for i, h in enumerate(q):
+        e = ox.get(int(h))
+        assert bool(found[i]) == (e is not None)
+        if e is not None:
+            assert (int(ids[i]), int(ent[i]["start"]), int(ent[i]["end"]), int(ent[i]["offset"]), int(ent[i]["rev"])) == \
+                   (int(e["id"]), int(e["start"]), int(e["end"]), int(e["offset"]), int(e["rc"]))
+
+
+def _map_both(mq, oracle, g, off, names, reads, ps):
+    P, po = mq.Params(**ps), oracle.params(**ps)
+    ix, ox = mq.Index(P), oracle.Index()
+    for r in range(off.size - 1):
+        s = g[int(off[r]):int(off[r + 1])]
+        assert ix.add_ref(r, names[r], s) == ox.add_ref(r, names[r], s, po)
+    assert ix.finalize() == ox.count()
+    hits = ix.map_batch(reads["bases"], reads["offsets"])
+    want = ox.map_batch(reads["bases"], reads["offsets"], po, threads=4)
+    return ix, ox, hits, want
+
+
+def _cmp_hits(hits, want):
+    assert np.array_equal(hits["status"] == 1, want["mapped"] != 0)
+    m = want["mapped"] != 0
+    for a, b in (("ref_id", "ref_id"), ("rc", "rc"), ("mapq", "mapq"), ("q_start", "q_start"), ("q_end", "q_end"),
+                 ("r_start", "r_start"), ("r_end", "r_end"), ("score", "score")):
+        assert np.array_equal(hits[a][m].astype(np.uint64), want[b][m].astype(np.uint64)), a
+
+
+@pytest.mark.parametrize("ps", [dict(), dict(k=8, l=16, g=100)])
+def test_map_ecoli_paf_identical(mq, oracle, simlib, ecoli, ps):
+    """BASELINE config 1 stand-in: 100 HiFi-like reads vs the 4,641,652-bp genome; PAF bytes identical."""
+    g, off, names = ecoli
+    reads = simlib.make_reads(g, off, 100, seed=1)
+    ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads, ps)
+    _cmp_hits(hits, want)
+    rn = simlib.read_names(reads, names)
+    assert ix.paf_lines(rn, reads["offsets"], hits) == oracle.paf_lines(ox, rn, want)
+    n_m, n_q60, n_wrong = simlib.mapeval(reads, want)
+    assert n_q60 >= 95 and n_wrong == 0
+
+
+def test_map_repetitive_multi_contig(mq, oracle, simlib):
+    """Repeats => tombstones, misses, many short Matches, several candidate references, ties."""
+    g, off, names = simlib.make_genome([400000, 350000, 250000, 1000, 20], seed=21, repeat_frac=0.6, tandem_frac=0.1, div=0.005)
+    reads = simlib.make_reads(g, off, 600, seed=9, len_mean=9000, len_sd=5000, len_min=10, len_max=25000, err=0.02)
+    for ps in (dict(), dict(k=3, l=15, density=0.03, c=2, s=5, g=500), dict(k=2, l=10, density=0.05, g=50)):
+        ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads, ps)
+        _cmp_hits(hits, want)
+
+
+def test_map_chain_multichunk_path(mq, oracle, simlib, monkeypatch):
+    """MQ_CHAIN_CHUNK=4 builds the chain stage with 4-lane chunks so ordinary reads take the multi-chunk path."""
+    monkeypatch.setenv("MQ_CHAIN_CHUNK", "4")
+    g, off, names = simlib.make_genome([300000, 300000], seed=33, repeat_frac=0.5, tandem_frac=0.1, div=0.01)
+    reads = simlib.make_reads(g, off, 300, seed=2, len_mean=12000, len_sd=4000, err=0.03)
+    ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads, dict(k=3, l=15, density=0.03))
+    _cmp_hits(hits, want)
+
+
+def test_match_overflow_is_loud(mq, oracle, simlib, monkeypatch):
+    monkeypatch.setenv("MQ_MATCH_CAP", "1")
+    g, off, names = simlib.make_genome([200000], seed=5, repeat_frac=0.3)
+    reads = simlib.make_reads(g, off, 50, seed=2, len_mean=12000, err=0.03)
+    ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads, dict(k=3, l=15, density=0.03))
+    assert (hits["status"] == 2).any()
+    ok = hits["status"] != 2
+    assert np.array_equal(hits["status"][ok] == 1, want["mapped"][ok] != 0)
