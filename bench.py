@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- Gbases/s mapped by the HIP hot path on simulated CHM13-like HiFi reads (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the fused hot path (seeding -> index probe -> Match runs -> pseudo-chain) over one batch of
+synthetic reads that is already resident in HBM (ASCII bases + offsets); the index is resident too.  Reads are sharded
+across ranks with the index replicated per GPU, no data-path collective (weak scaling: every rank maps its own batch).
+Rank 0 prints ONE JSON line.  The only collectives are the barrier and the MAX of the elapsed time.
+
+Workload: CHM13v2.0 itself is not in this image, so the genome is a seeded synthetic stand-in with the same contig
+lengths (tools/sim.py CHM13_LIKE, ~3.117 Gbp, 25 contigs) with planted repeats; reads follow the reference's pbsim
+recipe shape (example/simulate_pbsim.sh:7-14: mean 24 kb, 1 % error).  --genome-scale shrinks the contigs for quick runs
+(the JSON names the scale; only scale 1.0 is the BASELINE configuration).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=49152, help="reads per step per GPU")
+    ap.add_argument("--genome-scale", type=float, default=1.0, help="1.0 = CHM13-like 3.117 Gbp")
+    ap.add_argument("--seed", type=int, default=2013)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the mapquik HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import mapquik_amd as mq
+    from tools import sim
+
+    ncpu = os.cpu_count() or 8
+    threads = max(1, ncpu // world)
+    P = mq.Params()  # k=5 l=31 d=0.01 HPC on, c=4 s=11 g=2000 (src/main.rs:174-188)
+
+    # ---- genome (same on every rank: the index is replicated)
+    t0 = time.time()
+    lens = [max(40, int(x * args.genome_scale)) for x in sim.CHM13_LIKE]
+    genome, ctg_off, ctg_names = sim.make_genome(lens, seed=args.seed, threads=threads, repeat_frac=0.05, tandem_frac=0.01, div=0.01)
+    t_genome = time.time() - t0
+
+    # ---- index on this rank's GPU (Index::add_with_mer + into_read_only on device)
+    t0 = time.time()
+    ix = mq.Index(P, device=local_rank)
+    per_ref = []
+    for r in range(len(lens)):
+        seg = genome[int(ctg_off[r]):int(ctg_off[r + 1])]
+        d_seg = torch.from_numpy(seg).to(dev)
+        per_ref.append(ix.add_ref_device(r, ctg_names[r], d_seg.data_ptr(), seg.size))
+        del d_seg
+    n_unique = ix.finalize()
+    torch.cuda.synchronize()
+    t_index = time.time() - t0
+    st = ix.stats()
+
+    # ---- this rank's batch of reads, resident in HBM
+    t0 = time.time()
+    reads = sim.make_reads(genome, ctg_off, args.reads, seed=args.seed + 1000 + rank, threads=threads)
+    n = args.reads
+    offs = reads["offsets"]
+    total_bases = int(offs[-1])
+    max_len = int((offs[1:] - offs[:-1]).max())
+    d_bases = torch.from_numpy(reads["bases"]).to(dev)
+    d_offs = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_out = torch.zeros(n * mq.hit_dtype.itemsize, dtype=torch.uint8, device=dev)
+    t_reads = time.time() - t0
+    ix.reserve(max_len)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        ix.map_batch_device(d_bases.data_ptr(), d_offs.data_ptr(), n, max_len, d_out.data_ptr(), stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(stream)
+        step()
+        ev[i][1].record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tb = torch.tensor([float(total_bases), float(n)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        all_bases, all_reads = float(tb[0].item()), float(tb[1].item())
+    else:
+        all_bases, all_reads = float(total_bases), float(n)
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    avg_kern_s = float(np.mean(kern_ms)) / 1e3
+
+    hits = np.frombuffer(d_out.cpu().numpy().tobytes(), dtype=mq.hit_dtype)
+    n_kmm = int(hits["n_kminmers"].astype(np.int64).sum())
+    n_mapped = int((hits["status"] == 1).sum())
+    n_over = int((hits["status"] == 2).sum())
+
+    # ---- roofline of the dominant (only) kernel of a step: map_kernel
+    # algorithmic bytes per launch (DESIGN.md "Measurement"): 1 B per base (ASCII in HBM) + one 32-B slot per k-min-mer
+    # lookup (extra linear-probe steps are NOT counted as algorithmic) + 8 B offset + 40 B result per read
+    alg_bytes = total_bases * 1 + n_kmm * st["slot_bytes"] + n * (8 + 40)
+    achieved = alg_bytes / avg_kern_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("reads") == n and abs(tj.get("genome_scale", -1) - args.genome_scale) < 1e-9:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=8000.0, unit="GB/s", frac=round(achieved / 8000.0, 4),
+                    traffic=traffic, kernel="map_kernel", avg_launch_ms=round(avg_kern_s * 1e3, 4),
+                    algorithmic_bytes_per_launch=int(alg_bytes))
+
+    # ---- CPU baseline: the C oracle ("port") on a bounded sample of the same reads, rank 0 at N=1 only
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        po = O.params()
+        t0 = time.time()
+        ox = O.Index()
+        ox.build_mt(genome, ctg_off, ctg_names, po, ncpu)
+        t_cpu_index = time.time() - t0
+        ns = args.cpu_sample_reads or min(n, max(256, ncpu * 256))
+        sb = reads["bases"][:int(offs[ns])]
+        so = offs[:ns + 1]
+        t0 = time.time()
+        want = ox.map_batch(sb, so, po, threads=ncpu)
+        t_cpu = time.time() - t0
+        if t_cpu < 5.0 and ns < n:  # too short to time well: take a larger sample
+            ns = min(n, int(ns * 10.0 / max(t_cpu, 0.05)))
+            sb = reads["bases"][:int(offs[ns])]
+            so = offs[:ns + 1]
+            t0 = time.time()
+            want = ox.map_batch(sb, so, po, threads=ncpu)
+            t_cpu = time.time() - t0
+        m = want["mapped"] != 0
+        same = bool(np.array_equal(hits["status"][:ns] == 1, m)) and all(
+            np.array_equal(hits[a][:ns][m].astype(np.uint64), want[a][m].astype(np.uint64))
+            for a in ("ref_id", "rc", "mapq", "q_start", "q_end", "r_start", "r_end", "score"))
+        cpu = dict(value=round(int(so[-1]) / t_cpu / 1e9, 4), unit="Gbases/s", cores=ncpu, kind="port",
+                   sample="first %d reads (%d bases) of the step batch, C oracle with %d pthreads, index build (%.1f s) excluded"
+                          % (ns, int(so[-1]), ncpu, t_cpu_index),
+                   seconds=round(t_cpu, 2), paf_columns_identical_to_gpu=same, unique_kminmers_equal=bool(ox.count() == n_unique))
+
+    if rank == 0:
+        value = all_bases * args.steps / elapsed / 1e9
+        line = {
+            "metric": "Gbases/s mapped (sim CHM13v2-like HiFi, k=5 l=31 d=0.01)",
+            "value": round(value, 3),
+            "unit": "Gbases/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": "CHM13v2.0-like synthetic genome (25 contigs, %.3f Gbp, scale %.3g, 5%% planted repeats) "
+                            "x pbsim-like HiFi reads (mean 24 kb, 1%% error); k=5 l=31 d=0.01 HPC" % (st and sum(lens) / 1e9, args.genome_scale),
+                "reads_per_step_per_gpu": n,
+                "bases_per_step_per_gpu": total_bases,
+                "index_unique_kminmers": int(n_unique),
+                "index_table_bytes": int(st["table_bytes"]),
+                "parallelism": "reads sharded over %d GPU(s), index replicated, no data-path collective" % world,
+            },
+            "mreads_per_s": round(all_reads * args.steps / elapsed / 1e6, 4),
+            "mapped_frac": round(n_mapped / max(n, 1), 4),
+            "overflow_reads": n_over,
+            "kminmers_per_step": n_kmm,
+            "setup_s": {"genome": round(t_genome, 1), "gpu_index": round(t_index, 2), "reads": round(t_reads, 1)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -350,13 +350,13 @@ static void index_grow(mqo_index *ix, uint64_t newcap) {
 
 static void index_reserve(mqo_index *ix, uint64_t n_keys) {
     uint64_t need = 1024;
-    while (need < n_keys * 2) need <<= 1;
+    while (need * 7 < n_keys * 10) need <<= 1; /* load <= 0.7 */
     if (need > ix->cap) index_grow(ix, need);
 }
 
 /* Index::add (src/index.rs:94-97) / add_with_mer (100-104) */
 void mqo_index_add(mqo_index *ix, uint64_t h, uint64_t id, uint64_t start, uint64_t end, uint64_t offset, int rc) {
-    if ((ix->n + 1) * 2 > ix->cap) index_grow(ix, ix->cap * 2);
+    if ((ix->n + 1) * 10 > ix->cap * 7) index_grow(ix, ix->cap * 2);
     uint64_t s = slot_of(h, ix->cap);
     while (ix->used[s]) {
         if (ix->keys[s] == h) {
