@@ -136,6 +136,10 @@ int mq_index_lookup(mq_index *idx, const uint64_t *hashes, uint32_t n, uint8_t *
 /* The format! of src/mers.rs:181 (no newline).  Returns the length or <0. */
 int mq_format_paf(const mq_index *idx, const char *q_id, uint64_t q_len, const mq_hit *hit, char *buf, size_t cap);
 
+/* Diagnostic: how many reads of the last map launch took the fast seeding path (ACGT-only, one LDS tile) and how many
+ * the general streaming path.  Both produce identical results.  Synchronises on the launch. */
+int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general);
+
 /* Timing of the last mq_map_batch_device launch sequence on its stream, from HIP events recorded around the
  * kernels (milliseconds).  Synchronises on the end event. */
 int mq_last_map_ms(mq_index *idx, float *ms);

@@ -11,29 +11,57 @@
 #include <vector>
 
 #include "mq_device.hpp"
+#include "mq_fast.hpp"
 
 using namespace mq;
 
 // =================================================================== kernels
 
-// Fused hot path: one wave per read, persistent waves pull read indices from an atomic counter.
-// CH: lanes per chunk in the chain stage (64 in production).
-template <int CH>
-__global__ __launch_bounds__(64) void map_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets,
-                                                 uint32_t n, DevParams P, const Slot *__restrict__ table, uint64_t mask,
-                                                 const uint64_t *__restrict__ ref_lens, MatchRec *__restrict__ scratch_all,
-                                                 uint32_t cap_matches, uint32_t *__restrict__ work_counter,
-                                                 mq_hit *__restrict__ out, mq_kminmer *__restrict__ dump,
-                                                 const uint64_t *__restrict__ dump_off, uint32_t *__restrict__ dump_counts) {
-    __shared__ WaveLds S;
+// Fused hot path: one wave per read; 4 waves per workgroup share the look-up tables; persistent waves pull read indices
+// from an atomic counter.  CH: lanes per chunk in the chain stage (64 in production).  FAST=false forces the general path.
+struct MapArgs {
+    const uint8_t *bases;
+    const uint64_t *offsets;
+    uint32_t n;
+    DevParams P;
+    const Slot *table;
+    uint64_t mask;
+    const uint64_t *ref_lens;
+    MatchRec *scratch_all;   // per wave: cap_matches records
+    uint32_t cap_matches;
+    uint8_t *fast_scratch;   // per wave: FAST_EM_BYTES + FAST_HM_WORDS*4
+    uint32_t *work_counter;
+    mq_hit *out;
+    mq_kminmer *dump;
+    const uint64_t *dump_off;
+    uint32_t *dump_counts;
+    uint32_t *stats;         // [0] reads through the fast path, [1] through the general path
+};
+
+constexpr int MAP_WAVES = 4;
+
+template <int CH, bool FAST>
+__global__ __launch_bounds__(64 * MAP_WAVES) void map_kernel(const MapArgs A) {
+    __shared__ WgTables T;
+    __shared__ WaveLds SS[MAP_WAVES];
+    build_tables(T, A.P.l);
+    __syncthreads();  // the only workgroup-wide rendezvous; waves are independent from here on
     const uint32_t lane = lane_id();
-    MatchRec *scratch = scratch_all + (size_t)blockIdx.x * cap_matches;
+    const uint32_t wv = threadIdx.x >> 6;
+    WaveLds &S = SS[wv];
+    const size_t wave_gid = (size_t)blockIdx.x * MAP_WAVES + wv;
+    MatchRec *scratch = A.scratch_all + wave_gid * A.cap_matches;
+    uint8_t *fs = A.fast_scratch + wave_gid * (size_t)(FAST_EM_BYTES + FAST_HM_WORDS * 4u);
+    uint4 *em = reinterpret_cast<uint4 *>(fs);
+    uint32_t *hm = reinterpret_cast<uint32_t *>(fs + FAST_EM_BYTES);
+    const DevParams &P = A.P;
+    uint32_t n_fast = 0, n_general = 0;
     for (;;) {
         uint32_t r = 0;
-        if (lane == 0) r = atomicAdd(work_counter, 1u);
+        if (lane == 0) r = atomicAdd(A.work_counter, 1u);
         r = rdfirst(r);
-        if (r >= n) break;
-        const uint64_t o0 = offsets[r], o1 = offsets[r + 1];
+        if (r >= A.n) break;
+        const uint64_t o0 = A.offsets[r], o1 = A.offsets[r + 1];
         const uint64_t len = o1 - o0;
         mq_hit h;
         h.status = MQ_HIT_UNMAPPED;
@@ -43,29 +71,39 @@ __global__ __launch_bounds__(64) void map_kernel(const uint8_t *__restrict__ bas
         if (len >= (uint64_t)P.l + P.k - 1u) {
             mq_kminmer *d = nullptr;
             uint32_t dcap = 0;
-            if (dump) {
-                d = dump + dump_off[r];
-                dcap = (uint32_t)(dump_off[r + 1] - dump_off[r]);
+            if (A.dump) {
+                d = A.dump + A.dump_off[r];
+                dcap = (uint32_t)(A.dump_off[r + 1] - A.dump_off[r]);
             }
-            MapSink sink(table, mask, P, scratch, cap_matches, d, dcap);
+            MapSink sink(A.table, A.mask, P, scratch, A.cap_matches, d, dcap);
             uint32_t mz_count = 0;
-            seed_segment(bases + o0, len, 0, len, P, S, sink, mz_count);
+            bool done = false;
+            if (FAST) done = fast_seed_sequence(A.bases + o0, (uint32_t)len, P, T, S, sink, mz_count, em, hm);
+            if (done) n_fast++;
+            else {
+                n_general++;
+                seed_segment(A.bases + o0, len, 0, len, P, S, sink, mz_count);
+            }
             sink.finish(S, mz_count);
             n_kmm = sink.kmm_count;
-            if (sink.n_matches > cap_matches) {
+            if (sink.n_matches > A.cap_matches) {
                 h.status = MQ_HIT_OVERFLOW;
             } else if (sink.n_matches > 0) {
-                __threadfence_block();
-                __syncthreads();
-                chain_stage<CH>(scratch, sink.n_matches, P, len, ref_lens, h);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Match records written by this wave are in L2
+                wave_sync();
+                chain_stage<CH>(scratch, sink.n_matches, P, len, A.ref_lens, h);
             }
         }
         h.n_kminmers = n_kmm;
         if (lane == 0) {
-            out[r] = h;
-            if (dump_counts) dump_counts[r] = n_kmm;
+            A.out[r] = h;
+            if (A.dump_counts) A.dump_counts[r] = n_kmm;
         }
-        __syncthreads();
+        wave_sync();
+    }
+    if (A.stats && lane == 0) {
+        if (n_fast) atomicAdd(&A.stats[0], n_fast);
+        if (n_general) atomicAdd(&A.stats[1], n_general);
     }
 }
 
@@ -81,7 +119,7 @@ __global__ __launch_bounds__(64) void seed_segments_kernel(const uint8_t *__rest
         uint32_t mz_count = 0;
         seed_segment(seq, len, a, b, P, S, sink, mz_count);
         if (lane_id() == 0) counts[s] = sink.written;
-        __syncthreads();
+        wave_sync();
     }
 }
 
@@ -218,7 +256,9 @@ struct mq_index {
     MatchRec *scratch = nullptr;
     uint32_t cap_matches = 0;
     uint32_t grid = 0;
-    uint32_t *d_counter = nullptr;
+    uint32_t *d_counter = nullptr;  // [0] work counter, [1] fast-path reads, [2] general-path reads
+    uint8_t *fast_scratch = nullptr;
+    bool force_general = false;     // test hook MQ_FORCE_GENERAL=1: never take the fast seeding path
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
     // staging for the host-buffer entry points
@@ -292,18 +332,20 @@ static int ensure_scratch(mq_index *idx, uint32_t max_len) {
     }
     if (!idx->grid) {
         int occ = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, map_kernel<64>, 64, 0));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, map_kernel<64, true>, 64 * MAP_WAVES, 0));
         if (occ < 1) occ = 1;
-        if (occ > 32) occ = 32;
-        idx->grid = (uint32_t)(occ * idx->n_cu);
+        if (occ > 8) occ = 8;
+        idx->grid = (uint32_t)(occ * idx->n_cu);  // workgroups; MAP_WAVES persistent waves each
     }
+    const size_t n_waves = (size_t)idx->grid * MAP_WAVES;
     if (!idx->scratch) {
         // Match runs per read held in HBM scratch; a read with more runs is reported MQ_HIT_OVERFLOW (never silently wrong)
         const char *e = getenv("MQ_MATCH_CAP");
         idx->cap_matches = e ? (uint32_t)strtoul(e, nullptr, 10) : 2048u;
         if (idx->cap_matches < 1) idx->cap_matches = 1;
-        HIPCHK(hipMalloc((void **)&idx->scratch, (size_t)idx->grid * idx->cap_matches * sizeof(MatchRec)));
+        HIPCHK(hipMalloc((void **)&idx->scratch, n_waves * idx->cap_matches * sizeof(MatchRec)));
     }
+    if (!idx->fast_scratch) HIPCHK(hipMalloc((void **)&idx->fast_scratch, n_waves * (size_t)(FAST_EM_BYTES + FAST_HM_WORDS * 4u)));
     return MQ_OK;
 }
 
@@ -340,6 +382,8 @@ mq_index *mq_index_new(const mq_params *params, int device) {
     idx->dp.pad = 0;
     const char *cc = getenv("MQ_CHAIN_CHUNK");
     if (cc && atoi(cc) == 4) idx->chain_chunk = 4;
+    const char *fg = getenv("MQ_FORCE_GENERAL");
+    idx->force_general = fg && atoi(fg) != 0;
     hipDeviceProp_t prop;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
         set_err(MQ_EHIP, "hipSetDevice/hipGetDeviceProperties failed");
@@ -364,6 +408,7 @@ void mq_index_free(mq_index *idx) {
     if (idx->d_ref_lens) hipFree(idx->d_ref_lens);
     if (idx->scratch) hipFree(idx->scratch);
     if (idx->d_counter) hipFree(idx->d_counter);
+    if (idx->fast_scratch) hipFree(idx->fast_scratch);
     if (idx->st_bases) hipFree(idx->st_bases);
     if (idx->st_off) hipFree(idx->st_off);
     if (idx->st_out) hipFree(idx->st_out);
@@ -553,16 +598,31 @@ int mq_map_reserve(mq_index *idx, uint32_t max_len) {
 static int launch_map(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, mq_hit *d_out,
                       mq_kminmer *d_dump, const uint64_t *d_dump_off, uint32_t *d_dump_counts, hipStream_t st) {
     if (n == 0) return MQ_OK;
-    HIPCHK(hipMemsetAsync(idx->d_counter, 0, 4, st));
+    HIPCHK(hipMemsetAsync(idx->d_counter, 0, 16, st));
     HIPCHK(hipEventRecord(idx->ev0, st));
-    const uint32_t grid = std::min<uint32_t>(idx->grid, n);
-    const uint64_t *ref_lens = idx->d_ref_lens;
-    if (idx->chain_chunk == 4)
-        hipLaunchKernelGGL(map_kernel<4>, dim3(grid), dim3(64), 0, st, d_bases, d_offsets, n, idx->dp, idx->table, idx->nslots - 1,
-                           ref_lens, idx->scratch, idx->cap_matches, idx->d_counter, d_out, d_dump, d_dump_off, d_dump_counts);
-    else
-        hipLaunchKernelGGL(map_kernel<64>, dim3(grid), dim3(64), 0, st, d_bases, d_offsets, n, idx->dp, idx->table, idx->nslots - 1,
-                           ref_lens, idx->scratch, idx->cap_matches, idx->d_counter, d_out, d_dump, d_dump_off, d_dump_counts);
+    MapArgs A;
+    A.bases = d_bases;
+    A.offsets = d_offsets;
+    A.n = n;
+    A.P = idx->dp;
+    A.table = idx->table;
+    A.mask = idx->nslots - 1;
+    A.ref_lens = idx->d_ref_lens;
+    A.scratch_all = idx->scratch;
+    A.cap_matches = idx->cap_matches;
+    A.fast_scratch = idx->fast_scratch;
+    A.work_counter = idx->d_counter;
+    A.out = d_out;
+    A.dump = d_dump;
+    A.dump_off = d_dump_off;
+    A.dump_counts = d_dump_counts;
+    A.stats = idx->d_counter + 1;
+    const uint32_t grid = std::min<uint32_t>(idx->grid, (n + MAP_WAVES - 1) / MAP_WAVES);
+    const dim3 blk(64 * MAP_WAVES);
+    if (idx->chain_chunk == 4 && idx->force_general) hipLaunchKernelGGL((map_kernel<4, false>), dim3(grid), blk, 0, st, A);
+    else if (idx->chain_chunk == 4) hipLaunchKernelGGL((map_kernel<4, true>), dim3(grid), blk, 0, st, A);
+    else if (idx->force_general) hipLaunchKernelGGL((map_kernel<64, false>), dim3(grid), blk, 0, st, A);
+    else hipLaunchKernelGGL((map_kernel<64, true>), dim3(grid), blk, 0, st, A);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(idx->ev1, st));
     idx->ev_valid = true;
@@ -714,6 +774,19 @@ int mq_format_paf(const mq_index *idx, const char *q_id, uint64_t q_len, const m
                      hit->q_end, hit->rc ? "-" : "+", it->second.first.c_str(), r_len, hit->r_start, hit->r_end, hit->score, r_len,
                      hit->mapq);
     return w;
+}
+
+int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general) {
+    if (!idx || !n_fast || !n_general) return set_err(MQ_EINVAL, "bad arguments");
+    if (!idx->ev_valid) return set_err(MQ_ESTATE, "no map launch recorded");
+    int rc = use_device(idx);
+    if (rc) return rc;
+    HIPCHK(hipEventSynchronize(idx->ev1));
+    uint32_t v[2] = {0, 0};
+    HIPCHK(hipMemcpy(v, idx->d_counter + 1, 8, hipMemcpyDeviceToHost));
+    *n_fast = v[0];
+    *n_general = v[1];
+    return MQ_OK;
 }
 
 int mq_last_map_ms(mq_index *idx, float *ms) {

@@ -63,14 +63,34 @@ struct alignas(16) MatchRec {
     uint32_t q_start, q_end, r_start, r_end, count, ref, rc, done;
 };
 
+constexpr uint32_t FAST_CODES_DW = 1312;  // packed 2-bit HPC codes of one tile (+ read-ahead padding), see mq_fast.hpp
+constexpr uint32_t FAST_CNT_N = 516;      // HPC count at every 64-base block (+ sentinel)
+
+// Per-wave LDS.  The general streaming path uses the ring, the fast path the packed tile: never at the same time.
 struct WaveLds {
     unsigned long long mz_hash[MZ_CAP];
     uint32_t mz_pos[MZ_CAP];
-    uint32_t ring_pos[RING];
-    uint8_t ring_code[RING];
+    union {
+        struct {
+            uint32_t ring_pos[RING];
+            uint8_t ring_code[RING];
+        };
+        struct {
+            uint32_t codes[FAST_CODES_DW];
+            uint32_t lane_prefix[68];
+            uint16_t cnt64[FAST_CNT_N];
+        } f;
+    };
 };
 
 // ------------------------------------------------------------------ wave helpers
+// LDS hand-off between lanes of ONE wave (waves of a workgroup work on different reads and never rendezvous):
+// LDS operations of a wave execute in order; this only stops the compiler from moving them across the point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -252,7 +272,7 @@ __device__ __forceinline__ void seed_segment(const uint8_t *__restrict__ seq, ui
         prevR = tr;
         carryF = rdlane64(tf, 63);
         carryR = rdlane64(tr, 63);
-        __syncthreads();
+        wave_sync();
         sink.on_minimizers(S, mz_count);
     };
 
@@ -273,7 +293,7 @@ __device__ __forceinline__ void seed_segment(const uint8_t *__restrict__ seq, ui
         hbase += (uint32_t)__popcll(hm);
         const uint64_t inm = __ballot(inr);
         prev_byte = rdlane(bt, 63 - __clzll((long long)inm));
-        __syncthreads();
+        wave_sync();
         if (hbase - hproc >= 64u) {
             process_block(64u);
             hproc += 64u;
@@ -459,18 +479,12 @@ struct MapSink {
     // wave-uniform state
     uint32_t kmm_count = 0;
     uint32_t n_matches = 0;
-    bool open = false;
+    bool c_open = false;  // a run is open across the batch boundary; M holds it so far
     MatchRec M = {};
-    uint32_t p_id = 0, p_off = 0;
+    uint32_t c_hit = 0, c_id = 0, c_off = 0, c_sigma = 0;  // last element of the previous batch
 
     __device__ MapSink(const Slot *t, uint64_t m, const DevParams &p, MatchRec *s, uint32_t cap, mq_kminmer *d, uint32_t dc)
         : table(t), mask(m), P(p), scratch(s), cap_matches(cap), dump(d), dump_cap(dc) {}
-
-    __device__ __forceinline__ void emit() {
-        if (n_matches < cap_matches && lane_id() == 0) scratch[n_matches] = M;
-        n_matches++;
-        open = false;
-    }
 
     // k-min-mers [0, n) of the LDS minimizer list: hash, probe, extend runs
     __device__ __forceinline__ void consume(WaveLds &S, uint32_t n) {
@@ -497,49 +511,108 @@ struct MapSink {
             }
         }
         kmm_count += n;
-        // chain_matches + Match::extend (src/mers.rs:57-73, src/match.rs:45-58) over the batch, wave-uniform
-        const uint64_t hitmask = __ballot(hit);
-        const uint32_t srel_v = (rev != ((e.id_rc & 1u) != 0)) ? 1u : 0u;  // q.rev != r.rc
-        uint64_t hm = hitmask;
-        while (hm) {
-            const int i = __ffsll((long long)hm) - 1;
-            hm &= hm - 1;
-            const bool adjacent = (i == 0) ? true : ((hitmask >> (i - 1)) & 1ull) != 0;
-            if (!adjacent && open) emit();  // a miss in between was consumed and ended the run
-            const uint32_t r_id = rdlane(e.id_rc, i) >> 1;
-            const uint32_t r_start = rdlane(e.start, i), r_end = rdlane(e.end, i), r_off = rdlane(e.offset, i);
-            const uint32_t qs = rdlane(q_start, i), qe = rdlane(q_end, i);
-            const uint32_t srel = rdlane(srel_v, i);
-            if (open) {
-                // Match::check (src/match.rs:39-43): (A && B && C) || D
-                bool ok;
-                if (M.rc) ok = (r_id == p_id) && (srel == 1u) && ((int32_t)(p_off - r_off) == 1);
-                else ok = ((int32_t)(r_off - p_off) == 1);
-                if (ok) {  // Match::update (src/match.rs:31-37)
-                    if (M.rc) M.r_start = r_start;
-                    else M.r_end = r_end;
-                    M.q_end = qe;
-                    M.count += 1;
-                    p_id = r_id;
-                    p_off = r_off;
-                    continue;
-                }
-                emit();  // a hit that fails check is not consumed: it starts the next Match
-            }
-            // Match::new (src/match.rs:20-29)
-            M.q_start = qs;
-            M.q_end = qe;
-            M.r_start = r_start;
-            M.r_end = r_end;
-            M.count = 1;
-            M.ref = r_id;
-            M.rc = srel;
-            M.done = 0;
-            p_id = r_id;
-            p_off = r_off;
-            open = true;
+        // chain_matches + Match::extend (src/mers.rs:57-73, src/match.rs:45-58), lane = k-min-mer.
+        // Run state after element i: 0 = no open run (miss), 1 = forward run, 2 = reverse run (Match.rc of the run's
+        // first element).  Element i maps the previous state to the next one; the maps compose associatively, so a wave
+        // scan resolves every state.  Match::check (src/match.rs:39-43) parses as (A && B && C) || D:
+        //   reverse run continues iff same ref id && (q.rev != r.rc) && p.offset - r.offset == 1   (cr)
+        //   forward run continues iff r.offset - p.offset == 1                                      (cf)
+        const uint32_t r_id = e.id_rc >> 1;
+        const uint32_t srel = (hit && (rev != ((e.id_rc & 1u) != 0))) ? 1u : 0u;  // q.rev != r.rc
+        uint32_t hit_p = (uint32_t)__shfl_up((int)(hit ? 1u : 0u), 1, 64);
+        uint32_t id_p = (uint32_t)__shfl_up((int)r_id, 1, 64);
+        uint32_t off_p = (uint32_t)__shfl_up((int)e.offset, 1, 64);
+        if (lane == 0) {
+            hit_p = c_hit;
+            id_p = c_id;
+            off_p = c_off;
         }
-        if (n > 0 && !((hitmask >> (n - 1)) & 1ull) && open) emit();
+        const bool both = hit && hit_p;
+        const bool cf = both && ((int32_t)(e.offset - off_p) == 1);
+        const bool cr = both && r_id == id_p && srel == 1u && ((int32_t)(off_p - e.offset) == 1);
+        const uint32_t sv = srel ? 2u : 1u;
+        // f(N) | f(F) << 2 | f(R) << 4
+        uint32_t G = hit ? (sv | ((cf ? 1u : sv) << 2) | ((cr ? 2u : sv) << 4)) : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)G, d, 64);  // earlier elements
+            if (lane >= (uint32_t)d) {
+                const uint32_t hN = (G >> (2u * (o & 3u))) & 3u;
+                const uint32_t hF = (G >> (2u * ((o >> 2) & 3u))) & 3u;
+                const uint32_t hR = (G >> (2u * ((o >> 4) & 3u))) & 3u;
+                G = hN | (hF << 2) | (hR << 4);
+            }
+        }
+        const uint32_t sigma = (G >> (2u * c_sigma)) & 3u;
+        uint32_t sigma_p = (uint32_t)__shfl_up((int)sigma, 1, 64);
+        if (lane == 0) sigma_p = c_sigma;
+        const bool isnew = hit && !((sigma_p == 1u && cf) || (sigma_p == 2u && cr));
+        const uint64_t hitmask = __ballot(hit);
+        const uint64_t newmask = __ballot(isnew);
+        // the run carried in from the previous batch ends unless element 0 continues it
+        const bool cont0 = (hitmask & 1ull) && !(newmask & 1ull);
+        if (c_open && n > 0 && !cont0) {
+            if (n_matches < cap_matches && lane == 0) scratch[n_matches] = M;
+            n_matches++;
+            c_open = false;
+        }
+        if (n > 0) {
+            // element i ends a run iff it is a hit and the next element is a miss or starts a new run;
+            // the last element of the batch never ends one here (its run stays open for the next batch / finish()).
+            const uint64_t next_breaks = ((~hitmask | newmask) >> 1);
+            const bool is_end = hit && lane + 1u < n && ((next_breaks >> lane) & 1ull);
+            const uint64_t endmask = __ballot(is_end);
+            const uint64_t below = newmask & ((lane >= 63u) ? ~0ull : ((2ull << lane) - 1ull));
+            const int fl = below ? 63 - __clzll((long long)below) : -1;  // first element of this lane's run
+            const int src = fl < 0 ? 0 : fl;
+            const uint32_t f_qs = (uint32_t)__shfl((int)q_start, src, 64);
+            const uint32_t f_rs = (uint32_t)__shfl((int)e.start, src, 64);
+            const uint32_t f_re = (uint32_t)__shfl((int)e.end, src, 64);
+            const uint32_t f_id = (uint32_t)__shfl((int)r_id, src, 64);
+            const uint32_t f_rc = (uint32_t)__shfl((int)srel, src, 64);
+            MatchRec m;
+            if (fl >= 0) {
+                m.q_start = f_qs;
+                m.rc = f_rc;
+                m.ref = f_id;
+                m.count = lane - (uint32_t)fl + 1u;
+                m.r_start = f_rc ? e.start : f_rs;  // Match::update: rc moves r_start, forward moves r_end
+                m.r_end = f_rc ? f_re : e.end;
+            } else {  // the run began in an earlier batch: extend the carried Match
+                m.q_start = M.q_start;
+                m.rc = M.rc;
+                m.ref = M.ref;
+                m.count = M.count + lane + 1u;
+                m.r_start = M.rc ? e.start : M.r_start;
+                m.r_end = M.rc ? M.r_end : e.end;
+            }
+            m.q_end = q_end;
+            m.done = 0;
+            if (is_end) {
+                const uint32_t mi = n_matches + mbcnt64(endmask);
+                if (mi < cap_matches) scratch[mi] = m;
+            }
+            n_matches += (uint32_t)__popcll(endmask);
+            // carry out: state of the last element
+            const int last = (int)n - 1;
+            c_hit = (uint32_t)((hitmask >> last) & 1ull);
+            c_id = rdlane(r_id, last);
+            c_off = rdlane(e.offset, last);
+            c_sigma = rdlane(sigma, last);
+            if (c_hit) {
+                M.q_start = rdlane(m.q_start, last);
+                M.q_end = rdlane(m.q_end, last);
+                M.r_start = rdlane(m.r_start, last);
+                M.r_end = rdlane(m.r_end, last);
+                M.count = rdlane(m.count, last);
+                M.ref = rdlane(m.ref, last);
+                M.rc = rdlane(m.rc, last);
+                M.done = 0;
+                c_open = true;
+            } else {
+                c_open = false;
+            }
+        }
     }
 
     __device__ __forceinline__ void shift(WaveLds &S, uint32_t &mz_count) {
@@ -553,12 +626,12 @@ struct MapSink {
                 h = S.mz_hash[64u + base + lane];
                 p = S.mz_pos[64u + base + lane];
             }
-            __syncthreads();
+            wave_sync();
             if (mv) {
                 S.mz_hash[base + lane] = h;
                 S.mz_pos[base + lane] = p;
             }
-            __syncthreads();
+            wave_sync();
         }
         mz_count = rem;
     }
@@ -572,7 +645,11 @@ struct MapSink {
 
     __device__ __forceinline__ void finish(WaveLds &S, uint32_t &mz_count) {
         if (mz_count >= P.k) consume(S, mz_count - P.k + 1u);
-        if (open) emit();
+        if (c_open) {
+            if (n_matches < cap_matches && lane_id() == 0) scratch[n_matches] = M;
+            n_matches++;
+            c_open = false;
+        }
         mz_count = 0;
     }
 };
@@ -597,7 +674,7 @@ struct ListSink {
         }
         written += mz_count;
         mz_count = 0;
-        __syncthreads();
+        wave_sync();
     }
 };
 

@@ -150,3 +150,37 @@ def test_match_overflow_is_loud(mq, oracle, simlib, monkeypatch):
     assert (hits["status"] == 2).any()
     ok = hits["status"] != 2
     assert np.array_equal(hits["status"][ok] == 1, want["mapped"][ok] != 0)
+
+
+def test_fast_path_taken_and_general_path_agrees(mq, oracle, simlib, ecoli, monkeypatch):
+    """ACGT-only reads that fit one LDS tile go through the fast seeding path; MQ_FORCE_GENERAL=1 sends the same reads
+    through the general streaming path.  Both must equal the oracle."""
+    g, off, names = ecoli
+    reads = simlib.make_reads(g, off, 300, seed=4)
+    ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads, dict())
+    _cmp_hits(hits, want)
+    n_fast, n_gen = ix.last_map_path_counts()
+    assert n_fast == 300 and n_gen == 0
+    monkeypatch.setenv("MQ_FORCE_GENERAL", "1")
+    ix2, ox2, hits2, want2 = _map_both(mq, oracle, g, off, names, reads, dict())
+    _cmp_hits(hits2, want2)
+    n_fast, n_gen = ix2.last_map_path_counts()
+    assert n_fast == 0 and n_gen == 300
+    assert np.array_equal(hits.view(np.uint8), hits2.view(np.uint8))
+
+
+def test_long_and_mixed_reads_take_the_right_path(mq, oracle, simlib, ecoli):
+    g, off, names = ecoli
+    reads = simlib.make_reads(g, off, 40, seed=8, len_mean=30000, len_sd=15000, len_min=20, len_max=90000)
+    bases = reads["bases"].copy()
+    offs = reads["offsets"]
+    for i in range(0, 40, 5):  # sprinkle N into every 5th read
+        lo, hi = int(offs[i]), int(offs[i + 1])
+        if hi - lo > 100:
+            bases[lo + (hi - lo) // 2] = ord("N")
+    reads2 = dict(reads)
+    reads2["bases"] = bases
+    ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads2, dict())
+    _cmp_hits(hits, want)
+    n_fast, n_gen = ix.last_map_path_counts()
+    assert n_fast > 0 and n_gen > 0 and n_fast + n_gen == int(((offs[1:] - offs[:-1]) >= 35).sum())
