@@ -140,6 +140,10 @@ int mq_format_paf(const mq_index *idx, const char *q_id, uint64_t q_len, const m
  * the general streaming path.  Both produce identical results.  Synchronises on the launch. */
 int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general);
 
+/* Diagnostic builds only (env MQ_STAGE_TIMING=1 selects an instrumented kernel; its run time is never a reported number):
+ * shader-clock cycles summed over all waves of the last launch in {stage A, stage B, stage C + consume, finish, chain, whole wave}. */
+int mq_last_stage_cycles(mq_index *idx, uint64_t *cycles6);
+
 /* Timing of the last mq_map_batch_device launch sequence on its stream, from HIP events recorded around the
  * kernels (milliseconds).  Synchronises on the end event. */
 int mq_last_map_ms(mq_index *idx, float *ms);

@@ -22,7 +22,7 @@ assert hit_dtype.itemsize == 40 and kminmer_dtype.itemsize == 24
 EXPORTS = ["mq_last_error", "mq_abi_version", "mq_device_count", "mq_params_default", "mq_index_new", "mq_index_free",
            "mq_index_add_ref", "mq_index_add_ref_device", "mq_index_finalize", "mq_index_get_stats", "mq_index_ref_info",
            "mq_map_batch", "mq_map_batch_device", "mq_map_reserve", "mq_kminmers_batch", "mq_index_lookup", "mq_format_paf",
-           "mq_last_map_ms", "mq_last_map_path_counts"]
+           "mq_last_map_ms", "mq_last_map_path_counts", "mq_last_stage_cycles"]
 
 
 class MapquikError(RuntimeError):
@@ -84,6 +84,7 @@ def load_library(path=None):
     L.mq_index_lookup.argtypes = [vp, vp, u32, vp, vp, vp]
     L.mq_format_paf.argtypes = [vp, C.c_char_p, u64, vp, C.c_char_p, C.c_size_t]
     L.mq_last_map_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.mq_last_stage_cycles.argtypes = [vp, vp]
     L.mq_last_map_path_counts.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     if path is None:
         _lib = L
@@ -188,6 +189,13 @@ class Index:
         if self._L.mq_last_map_ms(self._h, C.byref(ms)) != 0:
             raise _err(self._L, "mq_last_map_ms")
         return ms.value
+
+    def last_stage_cycles(self):
+        """Diagnostic (MQ_STAGE_TIMING=1): cycles summed over waves in [A, B, C+consume, finish, chain, total]."""
+        v = np.zeros(6, dtype=np.uint64)
+        if self._L.mq_last_stage_cycles(self._h, _p(v)) != 0:
+            raise _err(self._L, "mq_last_stage_cycles")
+        return v
 
     def last_map_path_counts(self):
         """(reads through the fast seeding path, reads through the general path) of the last launch."""

@@ -29,7 +29,7 @@ def build(force=False, verbose=False):
     if not force and is_fresh():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", LIB] + SOURCES
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Wno-align-mismatch", "-o", LIB] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

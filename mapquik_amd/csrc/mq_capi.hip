@@ -36,12 +36,13 @@ struct MapArgs {
     const uint64_t *dump_off;
     uint32_t *dump_counts;
     uint32_t *stats;         // [0] reads through the fast path, [1] through the general path
+    uint32_t stop_after;     // diagnostic (MQ_STOP_AFTER): 0 = run everything; 1/2/3 = stop a read after stage A / B / gather
 };
 
 constexpr int MAP_WAVES = 4;
 
-template <int CH, bool FAST>
-__global__ __launch_bounds__(64 * MAP_WAVES) void map_kernel(const MapArgs A) {
+template <int CH, bool FAST, bool TIMING = false>
+__global__ __launch_bounds__(64 * MAP_WAVES, 4) void map_kernel(const MapArgs A) {
     __shared__ WgTables T;
     __shared__ WaveLds SS[MAP_WAVES];
     build_tables(T, A.P.l);
@@ -56,6 +57,8 @@ __global__ __launch_bounds__(64 * MAP_WAVES) void map_kernel(const MapArgs A) {
     uint32_t *hm = reinterpret_cast<uint32_t *>(fs + FAST_EM_BYTES);
     const DevParams &P = A.P;
     uint32_t n_fast = 0, n_general = 0;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};  // diagnostic build only: cycles in A, B, C(+consume), finish, chain, total
+    const unsigned long long t_begin = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
     for (;;) {
         uint32_t r = 0;
         if (lane == 0) r = atomicAdd(A.work_counter, 1u);
@@ -78,14 +81,17 @@ __global__ __launch_bounds__(64 * MAP_WAVES) void map_kernel(const MapArgs A) {
             MapSink sink(A.table, A.mask, P, scratch, A.cap_matches, d, dcap);
             uint32_t mz_count = 0;
             bool done = false;
-            if (FAST) done = fast_seed_sequence(A.bases + o0, (uint32_t)len, P, T, S, sink, mz_count, em, hm);
+            if (FAST) done = fast_seed_sequence<MapSink, TIMING>(A.bases + o0, (uint32_t)len, P, T, S, sink, mz_count, em, hm, tacc, A.stop_after);
             if (done) n_fast++;
             else {
                 n_general++;
                 seed_segment(A.bases + o0, len, 0, len, P, S, sink, mz_count);
             }
+            const unsigned long long t_f0 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
             sink.finish(S, mz_count);
             n_kmm = sink.kmm_count;
+            const unsigned long long t_f1 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
+            tacc[3] += t_f1 - t_f0;
             if (sink.n_matches > A.cap_matches) {
                 h.status = MQ_HIT_OVERFLOW;
             } else if (sink.n_matches > 0) {
@@ -93,6 +99,7 @@ __global__ __launch_bounds__(64 * MAP_WAVES) void map_kernel(const MapArgs A) {
                 wave_sync();
                 chain_stage<CH>(scratch, sink.n_matches, P, len, A.ref_lens, h);
             }
+            if (TIMING) tacc[4] += __builtin_amdgcn_s_memtime() - t_f1;
         }
         h.n_kminmers = n_kmm;
         if (lane == 0) {
@@ -104,6 +111,11 @@ __global__ __launch_bounds__(64 * MAP_WAVES) void map_kernel(const MapArgs A) {
     if (A.stats && lane == 0) {
         if (n_fast) atomicAdd(&A.stats[0], n_fast);
         if (n_general) atomicAdd(&A.stats[1], n_general);
+        if (TIMING) {
+            tacc[5] = __builtin_amdgcn_s_memtime() - t_begin;
+            unsigned long long *ts = reinterpret_cast<unsigned long long *>(A.stats + 2);
+            for (int i = 0; i < 6; ++i) atomicAdd(&ts[i], tacc[i]);
+        }
     }
 }
 
@@ -259,6 +271,8 @@ struct mq_index {
     uint32_t *d_counter = nullptr;  // [0] work counter, [1] fast-path reads, [2] general-path reads
     uint8_t *fast_scratch = nullptr;
     bool force_general = false;     // test hook MQ_FORCE_GENERAL=1: never take the fast seeding path
+    uint32_t stop_after = 0;        // diagnostic MQ_STOP_AFTER (instruction-count attribution; results are NOT valid)
+    bool stage_timing = false;      // diagnostic MQ_STAGE_TIMING=1: s_memtime stamps per stage (never for reported numbers)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
     // staging for the host-buffer entry points
@@ -325,7 +339,7 @@ static int alloc_table(mq_index *idx, uint64_t nslots) {
 
 static int ensure_scratch(mq_index *idx, uint32_t max_len) {
     (void)max_len;
-    if (!idx->d_counter) HIPCHK(hipMalloc((void **)&idx->d_counter, 64));
+    if (!idx->d_counter) HIPCHK(hipMalloc((void **)&idx->d_counter, 128));
     if (!idx->ev0) {
         HIPCHK(hipEventCreate(&idx->ev0));
         HIPCHK(hipEventCreate(&idx->ev1));
@@ -384,6 +398,10 @@ mq_index *mq_index_new(const mq_params *params, int device) {
     if (cc && atoi(cc) == 4) idx->chain_chunk = 4;
     const char *fg = getenv("MQ_FORCE_GENERAL");
     idx->force_general = fg && atoi(fg) != 0;
+    const char *stt = getenv("MQ_STAGE_TIMING");
+    idx->stage_timing = stt && atoi(stt) != 0;
+    const char *sa = getenv("MQ_STOP_AFTER");
+    idx->stop_after = sa ? (uint32_t)atoi(sa) : 0u;
     hipDeviceProp_t prop;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
         set_err(MQ_EHIP, "hipSetDevice/hipGetDeviceProperties failed");
@@ -598,7 +616,7 @@ int mq_map_reserve(mq_index *idx, uint32_t max_len) {
 static int launch_map(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, mq_hit *d_out,
                       mq_kminmer *d_dump, const uint64_t *d_dump_off, uint32_t *d_dump_counts, hipStream_t st) {
     if (n == 0) return MQ_OK;
-    HIPCHK(hipMemsetAsync(idx->d_counter, 0, 16, st));
+    HIPCHK(hipMemsetAsync(idx->d_counter, 0, 64, st));
     HIPCHK(hipEventRecord(idx->ev0, st));
     MapArgs A;
     A.bases = d_bases;
@@ -616,10 +634,12 @@ static int launch_map(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_o
     A.dump = d_dump;
     A.dump_off = d_dump_off;
     A.dump_counts = d_dump_counts;
-    A.stats = idx->d_counter + 1;
+    A.stats = idx->d_counter + 2;
+    A.stop_after = idx->stop_after;  // [2] fast reads, [3] general reads, [4..15] six 64-bit stage cycle sums
     const uint32_t grid = std::min<uint32_t>(idx->grid, (n + MAP_WAVES - 1) / MAP_WAVES);
     const dim3 blk(64 * MAP_WAVES);
-    if (idx->chain_chunk == 4 && idx->force_general) hipLaunchKernelGGL((map_kernel<4, false>), dim3(grid), blk, 0, st, A);
+    if (idx->stage_timing) hipLaunchKernelGGL((map_kernel<64, true, true>), dim3(grid), blk, 0, st, A);
+    else if (idx->chain_chunk == 4 && idx->force_general) hipLaunchKernelGGL((map_kernel<4, false>), dim3(grid), blk, 0, st, A);
     else if (idx->chain_chunk == 4) hipLaunchKernelGGL((map_kernel<4, true>), dim3(grid), blk, 0, st, A);
     else if (idx->force_general) hipLaunchKernelGGL((map_kernel<64, false>), dim3(grid), blk, 0, st, A);
     else hipLaunchKernelGGL((map_kernel<64, true>), dim3(grid), blk, 0, st, A);
@@ -783,9 +803,19 @@ int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general
     if (rc) return rc;
     HIPCHK(hipEventSynchronize(idx->ev1));
     uint32_t v[2] = {0, 0};
-    HIPCHK(hipMemcpy(v, idx->d_counter + 1, 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(v, idx->d_counter + 2, 8, hipMemcpyDeviceToHost));
     *n_fast = v[0];
     *n_general = v[1];
+    return MQ_OK;
+}
+
+int mq_last_stage_cycles(mq_index *idx, uint64_t *cycles6) {
+    if (!idx || !cycles6) return set_err(MQ_EINVAL, "bad arguments");
+    if (!idx->ev_valid) return set_err(MQ_ESTATE, "no map launch recorded");
+    int rc = use_device(idx);
+    if (rc) return rc;
+    HIPCHK(hipEventSynchronize(idx->ev1));
+    HIPCHK(hipMemcpy(cycles6, idx->d_counter + 4, 48, hipMemcpyDeviceToHost));
     return MQ_OK;
 }
 

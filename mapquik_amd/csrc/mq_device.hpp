@@ -486,29 +486,65 @@ struct MapSink {
     __device__ MapSink(const Slot *t, uint64_t m, const DevParams &p, MatchRec *s, uint32_t cap, mq_kminmer *d, uint32_t dc)
         : table(t), mask(m), P(p), scratch(s), cap_matches(cap), dump(d), dump_cap(dc) {}
 
-    // k-min-mers [0, n) of the LDS minimizer list: hash, probe, extend runs
-    __device__ __forceinline__ void consume(WaveLds &S, uint32_t n) {
-        const uint32_t lane = lane_id();
-        const uint32_t k = P.k;
-        const bool act = lane < n;
-        bool rev = false, hit = false;
-        uint64_t key = 0;
-        uint32_t q_start = 0, q_end = 0;
-        Slot e = {};
+    // k-min-mer `base + lane` of a minimizer list: canonical orientation, tuple hash, query coordinates
+    __device__ __forceinline__ void batch_keys(const unsigned long long *mzh, const uint32_t *mzp, uint32_t base, bool act,
+                                               uint64_t &key, bool &rev, uint32_t &q_start, uint32_t &q_end) const {
+        const uint32_t i0 = base + lane_id();
+        key = 0;
+        rev = false;
+        q_start = q_end = 0;
         if (act) {
-            key = kminmer_hash(k, [&](uint32_t i) { return (uint64_t)S.mz_hash[lane + i]; }, rev);
-            q_start = S.mz_pos[lane];
-            q_end = S.mz_pos[lane + k - 1] + P.l - 1u;
-            hit = probe_table(table, mask, key, e);
-            if (dump && kmm_count + lane < dump_cap) {
-                mq_kminmer d;
-                d.hash = key;
-                d.start = q_start;
-                d.end = q_end;
-                d.offset = kmm_count + lane;
-                d.rev = rev ? 1u : 0u;
-                dump[kmm_count + lane] = d;
+            key = kminmer_hash(P.k, [&](uint32_t i) { return (uint64_t)mzh[i0 + i]; }, rev);
+            q_start = mzp[i0];
+            q_end = mzp[i0 + P.k - 1] + P.l - 1u;
+        }
+    }
+
+    // first-slot probe issued early (all batches of a read at once): returns the key stored in the home slot
+    __device__ __forceinline__ unsigned long long probe_issue(uint64_t key) const {
+        return table[key == 0 ? mask + 1 : (key & mask)].key;
+    }
+    // ReadOnlyIndex::get (src/index.rs:118-126) continuing from an already loaded home-slot key
+    __device__ __forceinline__ bool probe_resolve(uint64_t key, unsigned long long k0, Slot &out) const {
+        if (key == 0) {
+            out = table[mask + 1];
+            return out.count == 1 && out.end != 0;
+        }
+        uint64_t s = key & mask;
+        for (;;) {
+            if (k0 == key) {
+                out = table[s];
+                return out.count == 1 && out.end != 0;
             }
+            if (k0 == 0) return false;
+            s = (s + 1) & mask;
+            k0 = table[s].key;
+        }
+    }
+
+    // k-min-mers [0, n) of the small LDS minimizer list (general streaming path)
+    __device__ __forceinline__ void consume(WaveLds &S, uint32_t n) {
+        uint64_t key;
+        bool rev;
+        uint32_t q_start, q_end;
+        const bool act = lane_id() < n;
+        batch_keys(S.mz_hash, S.mz_pos, 0, act, key, rev, q_start, q_end);
+        Slot e = {};
+        const bool hit = act && probe_table(table, mask, key, e);
+        batch_runs(n, key, rev, q_start, q_end, hit, e);
+    }
+
+    // one batch of n <= 64 consecutive k-min-mers (lane = k-min-mer) with their index entries: dump + Match runs
+    __device__ __forceinline__ void batch_runs(uint32_t n, uint64_t key, bool rev, uint32_t q_start, uint32_t q_end, bool hit, const Slot &e) {
+        const uint32_t lane = lane_id();
+        if (dump && lane < n && kmm_count + lane < dump_cap) {
+            mq_kminmer d;
+            d.hash = key;
+            d.start = q_start;
+            d.end = q_end;
+            d.offset = kmm_count + lane;
+            d.rev = rev ? 1u : 0u;
+            dump[kmm_count + lane] = d;
         }
         kmm_count += n;
         // chain_matches + Match::extend (src/mers.rs:57-73, src/match.rs:45-58), lane = k-min-mer.
@@ -615,6 +651,47 @@ struct MapSink {
         }
     }
 
+    // All k-min-mers of an ordered minimizer list (have <= 64*NB entries) in one go: every tuple hash first, then all
+    // home-slot probes in flight together (one exposed HBM latency per read instead of one per batch), then the runs.
+    template <int NB>
+    __device__ __forceinline__ void consume_list(const unsigned long long *mzh, const uint32_t *mzp, uint32_t have) {
+        if (have < P.k) return;
+        const uint32_t lane = lane_id();
+        const uint32_t K = have - P.k + 1u;
+        uint64_t key[NB];
+        unsigned long long k0[NB];
+        uint32_t revbits = 0;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            key[c] = 0;
+            k0[c] = 0;
+            if ((uint32_t)c * 64u < K) {
+                const bool act = (uint32_t)c * 64u + lane < K;
+                bool rev;
+                uint32_t qs, qe;
+                batch_keys(mzh, mzp, (uint32_t)c * 64u, act, key[c], rev, qs, qe);
+                revbits |= (rev ? 1u : 0u) << c;
+                if (act) k0[c] = probe_issue(key[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            if ((uint32_t)c * 64u < K) {
+                const uint32_t n = K - (uint32_t)c * 64u < 64u ? K - (uint32_t)c * 64u : 64u;
+                const bool act = lane < n;
+                const uint32_t i0 = (uint32_t)c * 64u + lane;
+                uint32_t qs = 0, qe = 0;
+                if (act) {
+                    qs = mzp[i0];
+                    qe = mzp[i0 + P.k - 1] + P.l - 1u;
+                }
+                Slot e = {};
+                const bool hit = act && probe_resolve(key[c], k0[c], e);
+                batch_runs(n, key[c], ((revbits >> c) & 1u) != 0, qs, qe, hit, e);
+            }
+        }
+    }
+
     __device__ __forceinline__ void shift(WaveLds &S, uint32_t &mz_count) {
         const uint32_t lane = lane_id();
         const uint32_t rem = mz_count - 64u;
@@ -660,6 +737,10 @@ struct ListSink {
     uint32_t cap;
     uint32_t written = 0;  // may exceed cap (overflow detected by the host)
     __device__ ListSink(Minimizer *o, uint32_t c) : out(o), cap(c) {}
+    template <int NB>
+    __device__ __forceinline__ void consume_list(const unsigned long long *mzh, const uint32_t *mzp, uint32_t have) {
+        (void)mzh; (void)mzp; (void)have;  // the reference path streams through on_minimizers only
+    }
     __device__ __forceinline__ void on_minimizers(WaveLds &S, uint32_t &mz_count) {
         const uint32_t lane = lane_id();
         for (uint32_t base = 0; base < mz_count; base += 64u) {

@@ -73,90 +73,132 @@ __device__ __forceinline__ uint64_t ld_sc1_u64(const uint64_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// pack 4 ASCII bases (one dword) into 8 bits of 2-bit codes; t = w & 0x06060606
-__device__ __forceinline__ uint32_t pack4(uint32_t t) {
-    const uint32_t x = t | (t << 6);
-    const uint32_t y = x | (x << 12);
-    return (y >> 19) & 0xFFu;
+// 16 ASCII bases (four dwords masked with 0x06060606: code<<1 in every byte) -> 32 bits, code j at bits 2j..2j+1.
+// Merge the dwords so that byte b holds bases b, 4+b, 8+b, 12+b, then transpose the 4x4 matrix of 2-bit elements.
+__device__ __forceinline__ uint32_t pack16(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
+    uint32_t v = (t0 >> 1) | (t1 << 1) | (t2 << 3) | (t3 << 5);
+    uint32_t x = ((v >> 6) ^ v) & 0x00CC00CCu;
+    v ^= x ^ (x << 6);
+    x = ((v >> 12) ^ v) & 0x0000F0F0u;
+    v ^= x ^ (x << 12);
+    return v;
 }
 
 // ------------------------------------------------------------------ stage A
+// A super-row is 4096 raw bases: every lane owns 64 consecutive bases = one 64-base block (four 16-B loads in flight,
+// plus the next super-row's four: 8 KiB per wave outstanding), one wave prefix sum per super-row.
 // Returns false when the sequence needs the general path (non-ACGT byte, too long for the tile).
 __device__ __forceinline__ bool fast_stage_a(const uint8_t *__restrict__ seq, uint32_t len, bool use_hpc, const WgTables &T,
                                              WaveLds &S, uint32_t *__restrict__ hm_scratch, uint32_t &n_codes, uint32_t &n_blocks) {
     const uint32_t lane = lane_id();
-    const uint32_t n_rows = (len + 1023u) >> 10;
-    if (n_rows > FAST_MAX_ROWS) return false;
+    const uint32_t n_sr = (len + 4095u) >> 12;
+    if (n_sr * 4u > FAST_MAX_ROWS) return false;
+    const uint32_t fill = (uint32_t)seq[len - 1] * 0x01010101u;
+    // 16 bases at pos; bytes past the end repeat the last base (never a run head under HPC; masked without HPC)
+    auto load_piece = [&](uint32_t pos) -> uint4 {
+        if (pos + 16u <= len) return *reinterpret_cast<const uint4_unaligned *>(seq + pos);
+        unsigned long long lo = ((unsigned long long)fill << 32) | fill, hi = lo;
+        const uint32_t nv = pos < len ? len - pos : 0u;
+        for (uint32_t j = 0; j < nv; ++j) {
+            const unsigned long long b = seq[pos + j];
+            if (j < 8u) lo = (lo & ~(0xFFull << (8u * j))) | (b << (8u * j));
+            else hi = (hi & ~(0xFFull << (8u * (j - 8u)))) | (b << (8u * (j - 8u)));
+        }
+        return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+    };
+    uint4 nx0, nx1, nx2, nx3;
+    {
+        const uint32_t pos = lane * 64u;
+        nx0 = load_piece(pos);
+        nx1 = load_piece(pos + 16u);
+        nx2 = load_piece(pos + 32u);
+        nx3 = load_piece(pos + 48u);
+    }
     for (uint32_t i = lane * 4u; i < FAST_CODES_DW; i += 256u) *reinterpret_cast<uint4 *>(&S.f.codes[i]) = make_uint4(0, 0, 0, 0);
     wave_sync();
-    const uint32_t fill = (uint32_t)seq[len - 1] * 0x01010101u;
     uint32_t b2 = 0;  // bits written so far = 2 * codes
     uint32_t bad = 0;
     uint32_t carry_prev = 0;
-    for (uint32_t r = 0; r < n_rows; ++r) {
-        if (b2 > 2u * (FAST_CODES_CAP - 1024u)) return false;
-        const uint32_t pos = (r << 10) + lane * 16u;
-        uint32_t w0, w1, w2, w3;
-        if (pos + 16u <= len) {
-            const uint4 v = *reinterpret_cast<const uint4_unaligned *>(seq + pos);
-            w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w;
-        } else {
-            // tail: bytes past the end repeat the last base (never a run head under HPC; masked without HPC)
-            uint32_t ww[4] = {fill, fill, fill, fill};
-            const uint32_t nv = pos < len ? len - pos : 0u;
+    constexpr uint32_t S1 = 0x00430041u, S0 = 0x00470054u;  // v_perm pool: selector 0,2 -> 'A','C' ; 4,6 -> 'T','G'
+    for (uint32_t sr = 0; sr < n_sr; ++sr) {
+        const uint32_t pos = (sr << 12) + lane * 64u;
+        const uint4 c0 = nx0, c1 = nx1, c2 = nx2, c3 = nx3;
+        if (sr + 1u < n_sr) {
+            const uint32_t np = pos + 4096u;
+            nx0 = load_piece(np);
+            nx1 = load_piece(np + 16u);
+            nx2 = load_piece(np + 32u);
+            nx3 = load_piece(np + 48u);
+        }
+        uint32_t p[4];
+        {
+            const uint4 cc[4] = {c0, c1, c2, c3};
 #pragma unroll
-            for (uint32_t j = 0; j < 15; ++j)
-                if (j < nv) ww[j >> 2] = (ww[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | ((uint32_t)seq[pos + j] << (8 * (j & 3)));
-            w0 = ww[0]; w1 = ww[1]; w2 = ww[2]; w3 = ww[3];
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t t0 = cc[j].x & 0x06060606u, t1 = cc[j].y & 0x06060606u, t2 = cc[j].z & 0x06060606u, t3 = cc[j].w & 0x06060606u;
+                // reconstructs each byte iff it was A/C/G/T
+                bad |= (__builtin_amdgcn_perm(S0, S1, t0) ^ cc[j].x) | (__builtin_amdgcn_perm(S0, S1, t1) ^ cc[j].y) |
+                       (__builtin_amdgcn_perm(S0, S1, t2) ^ cc[j].z) | (__builtin_amdgcn_perm(S0, S1, t3) ^ cc[j].w);
+                p[j] = pack16(t0, t1, t2, t3);
+            }
         }
-        const uint32_t t0 = w0 & 0x06060606u, t1 = w1 & 0x06060606u, t2 = w2 & 0x06060606u, t3 = w3 & 0x06060606u;
-        // selector bytes 0,2 pick from S1 ('A','C'), 4,6 from S0 ('T','G'): reconstructs the byte iff it was A/C/G/T
-        constexpr uint32_t S1 = 0x00430041u, S0 = 0x00470054u;
-        bad |= (__builtin_amdgcn_perm(S0, S1, t0) ^ w0) | (__builtin_amdgcn_perm(S0, S1, t1) ^ w1) |
-               (__builtin_amdgcn_perm(S0, S1, t2) ^ w2) | (__builtin_amdgcn_perm(S0, S1, t3) ^ w3);
-        const uint32_t p = pack4(t0) | (pack4(t1) << 8) | (pack4(t2) << 16) | (pack4(t3) << 24);
-        uint32_t out, n2, hm;
+        uint32_t out[4], n2[4], hm[4];
         if (use_hpc) {
-            uint32_t pc = (uint32_t)__shfl_up((int)(p >> 30), 1, 64);
-            if (lane == 0) pc = r == 0 ? ((p & 3u) ^ 1u) : carry_prev;  // first base of the sequence is always a head
-            const uint32_t q = (p << 2) | pc;
-            const uint32_t e0 = T.lut[q & 0x3FFu], e1 = T.lut[(q >> 8) & 0x3FFu], e2 = T.lut[(q >> 16) & 0x3FFu], e3 = T.lut[p >> 22];
-            out = e0 & 0xFFu;
-            uint32_t sh = e0 >> 8;
-            out |= (e1 & 0xFFu) << sh;
-            sh += e1 >> 8;
-            out |= (e2 & 0xFFu) << sh;
-            sh += e2 >> 8;
-            out |= (e3 & 0xFFu) << sh;
-            n2 = sh + (e3 >> 8);
-            const uint32_t d = p ^ q;
-            hm = (d | (d >> 1)) & 0x55555555u;
+            uint32_t pc = (uint32_t)__shfl_up((int)(p[3] >> 30), 1, 64);
+            if (lane == 0) pc = sr == 0 ? ((p[0] & 3u) ^ 1u) : carry_prev;  // first base of the sequence is always a head
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t q = (p[j] << 2) | pc;
+                pc = p[j] >> 30;
+                const uint32_t e0 = T.lut[q & 0x3FFu], e1 = T.lut[(q >> 8) & 0x3FFu], e2 = T.lut[(q >> 16) & 0x3FFu], e3 = T.lut[p[j] >> 22];
+                uint32_t o = e0 & 0xFFu, sh = e0 >> 8;
+                o |= (e1 & 0xFFu) << sh;
+                sh += e1 >> 8;
+                o |= (e2 & 0xFFu) << sh;
+                sh += e2 >> 8;
+                o |= (e3 & 0xFFu) << sh;
+                out[j] = o;
+                n2[j] = sh + (e3 >> 8);
+                const uint32_t d = p[j] ^ q;
+                hm[j] = (d | (d >> 1)) & 0x55555555u;
+            }
         } else {
-            const uint32_t nv = pos < len ? (len - pos < 16u ? len - pos : 16u) : 0u;
-            const uint32_t m = nv >= 16u ? 0xFFFFFFFFu : ((1u << (2u * nv)) - 1u);
-            out = p & m;
-            n2 = 2u * nv;
-            hm = 0x55555555u & m;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t pp = pos + 16u * (uint32_t)j;
+                const uint32_t nv = pp < len ? (len - pp < 16u ? len - pp : 16u) : 0u;
+                const uint32_t m = nv >= 16u ? 0xFFFFFFFFu : ((1u << (2u * nv)) - 1u);
+                out[j] = p[j] & m;
+                n2[j] = 2u * nv;
+                hm[j] = 0x55555555u & m;
+            }
         }
-        uint32_t incl = n2;
+        const uint32_t mine = n2[0] + n2[1] + n2[2] + n2[3];
+        uint32_t incl = mine;
 #pragma unroll
         for (int dd = 1; dd < 64; dd <<= 1) {
             const uint32_t o = (uint32_t)__shfl_up((int)incl, dd, 64);
             if (lane >= (uint32_t)dd) incl += o;
         }
-        const uint32_t bo = b2 + incl - n2;
-        if (n2) {
-            const uint32_t sh = bo & 31u;
-            atomicOr(&S.f.codes[bo >> 5], out << sh);
-            const uint32_t hi = sh ? out >> (32u - sh) : 0u;
-            if (hi) atomicOr(&S.f.codes[(bo >> 5) + 1u], hi);
+        const uint32_t total = rdlane(incl, 63);
+        if (b2 + total > 2u * FAST_CODES_CAP) return false;
+        uint32_t bo = b2 + incl - mine;
+        S.f.cnt64[sr * 64u + lane] = (uint16_t)(bo >> 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (n2[j]) {
+                const uint32_t sh = bo & 31u;
+                atomicOr(&S.f.codes[bo >> 5], out[j] << sh);
+                const uint32_t hi = sh ? out[j] >> (32u - sh) : 0u;
+                if (hi) atomicOr(&S.f.codes[(bo >> 5) + 1u], hi);
+            }
+            bo += n2[j];
         }
-        if ((lane & 3u) == 0) S.f.cnt64[r * 16u + (lane >> 2)] = (uint16_t)(bo >> 1);
-        hm_scratch[r * 64u + lane] = hm;
-        b2 += rdlane(incl, 63);
-        carry_prev = rdlane(p, 63) >> 30;
+        *reinterpret_cast<uint4 *>(hm_scratch + (sr * 64u + lane) * 4u) = make_uint4(hm[0], hm[1], hm[2], hm[3]);
+        b2 += total;
+        carry_prev = rdlane(p[3], 63) >> 30;
     }
-    n_blocks = n_rows * 16u;
+    n_blocks = n_sr * 64u;
     n_codes = b2 >> 1;
     if (lane == 0) S.f.cnt64[n_blocks] = (uint16_t)n_codes;
     wave_sync();
@@ -198,15 +240,34 @@ __device__ __forceinline__ uint32_t fast_stage_b(const WgTables &T, const WaveLd
     }
     const uint32_t in_dw = l >> 4, in_sh = 2u * (l & 15u);
     uint32_t e = 0;
+    // nibble m of xe / xo = out | in<<2 for step 2m / 2m+1 of a 16-step block
+    auto mk_xe = [](uint32_t ow, uint32_t iw) { return (ow & 0x33333333u) | ((iw & 0x33333333u) << 2); };
+    auto mk_xo = [](uint32_t ow, uint32_t iw) { return ((ow >> 2) & 0x33333333u) | (iw & 0xCCCCCCCCu); };
+    auto nib = [](uint32_t xe, uint32_t xo, uint32_t s) { return (((s & 1u) ? xo : xe) >> (4u * (s >> 1))) & 0xFu; };
     uint32_t prev_in = S.f.codes[base_dw + in_dw];
-    for (uint32_t blk = 0; blk < d; ++blk) {
-        const uint32_t ow = S.f.codes[base_dw + blk];
-        const uint32_t nxt = S.f.codes[base_dw + blk + in_dw + 1u];
+    uint32_t xe, xo;
+    {
+        const uint32_t ow = S.f.codes[base_dw];
+        const uint32_t nxt = S.f.codes[base_dw + in_dw + 1u];
         const uint32_t iw = __builtin_amdgcn_alignbit(nxt, prev_in, in_sh);
         prev_in = nxt;
-        // nibble m of xe / xo = out | in<<2 for step 2m / 2m+1
-        const uint32_t xe = (ow & 0x33333333u) | ((iw & 0x33333333u) << 2);
-        const uint32_t xo = ((ow >> 2) & 0x33333333u) | (iw & 0xCCCCCCCCu);
+        xe = mk_xe(ow, iw);
+        xo = mk_xo(ow, iw);
+    }
+    // ring of table values for the next four steps: their LDS reads are in flight while a step tests / emits
+    uint4 tv[4];
+#pragma unroll
+    for (uint32_t s = 0; s < 4; ++s) tv[s] = T.roll[nib(xe, xo, s)];
+    for (uint32_t blk = 0; blk < d; ++blk) {
+        uint32_t xe_n, xo_n;
+        {
+            const uint32_t ow = S.f.codes[base_dw + blk + 1u];
+            const uint32_t nxt = S.f.codes[base_dw + blk + in_dw + 2u];
+            const uint32_t iw = __builtin_amdgcn_alignbit(nxt, prev_in, in_sh);
+            prev_in = nxt;
+            xe_n = mk_xe(ow, iw);
+            xo_n = mk_xo(ow, iw);
+        }
 #pragma unroll
         for (uint32_t t = 0; t < 16; ++t) {
             const bool cand = h.fhi <= bhi || h.rhi <= bhi;
@@ -219,26 +280,23 @@ __device__ __forceinline__ uint32_t fast_stage_b(const WgTables &T, const WaveLd
                     e++;
                 }
             }
-            const uint32_t x = (t & 1u) ? xo : xe;
-            const uint32_t nib = (x >> (4u * (t >> 1))) & 0xFu;
-            h.roll(T.roll[nib]);
+            h.roll(tv[t & 3u]);
+            tv[t & 3u] = (t + 4u < 16u) ? T.roll[nib(xe, xo, t + 4u)] : T.roll[nib(xe_n, xo_n, t + 4u - 16u)];
         }
+        xe = xe_n;
+        xo = xo_n;
     }
     return e;
 }
 
 // ------------------------------------------------------------------ stage C
-// raw position (tile-relative) of the run head with HPC index j
-__device__ __forceinline__ uint32_t fast_rawpos(const WaveLds &S, uint32_t n_blocks, const uint32_t *__restrict__ hm_scratch, uint32_t j) {
-    uint32_t lo = 0, hi = n_blocks;  // largest block b with cnt64[b] <= j
-    while (hi - lo > 1u) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if ((uint32_t)S.f.cnt64[mid] <= j) lo = mid;
-        else hi = mid;
-    }
-    uint32_t r = j - (uint32_t)S.f.cnt64[lo];
-    const uint64_t *hp = reinterpret_cast<const uint64_t *>(hm_scratch + lo * 4u);
-    const uint64_t m01 = ld_sc1_u64(hp), m23 = ld_sc1_u64(hp + 1);
+constexpr uint32_t FAST_LIST_CAP = 432;  // ordered minimizers held at once, in the (now dead) code-stream LDS: 432 * 12 B
+constexpr int FAST_NB = 7;               // ceil(FAST_LIST_CAP / 64)
+static_assert(FAST_LIST_CAP * 3 <= FAST_CODES_DW, "minimizer list must fit the code stream region");
+static_assert(FAST_NB * 64 >= FAST_LIST_CAP, "batches");
+
+// r-th run head (0-based) of the 64-base block whose four 16-base head masks are m[0..3] (bits at even positions)
+__device__ __forceinline__ uint32_t select_head(uint64_t m01, uint64_t m23, uint32_t r) {
     uint32_t mw = (uint32_t)m01, w = 0;
     uint32_t c = (uint32_t)__popc(mw);
     if (r >= c) {
@@ -248,7 +306,6 @@ __device__ __forceinline__ uint32_t fast_rawpos(const WaveLds &S, uint32_t n_blo
             if (r >= c) { r -= c; mw = (uint32_t)(m23 >> 32); w = 3; }
         }
     }
-    // r-th set bit of mw (bits sit at even positions)
     uint32_t bit = 0;
 #pragma unroll
     for (uint32_t width = 16; width >= 2; width >>= 1) {
@@ -259,12 +316,75 @@ __device__ __forceinline__ uint32_t fast_rawpos(const WaveLds &S, uint32_t n_blo
             bit += width;
         }
     }
-    return lo * 64u + w * 16u + (bit >> 1);
+    return w * 16u + (bit >> 1);
+}
+
+// Ordered minimizers [g_lo, g_lo + n_new) of the tile -> LDS list entries [at, at + n_new): every scratch load of the
+// chunk is issued before the first use (two exposed L2 round trips per chunk, not per minimizer).
+__device__ __forceinline__ void fast_gather(WaveLds &S, const uint4 *__restrict__ em, const uint32_t *__restrict__ hm_scratch,
+                                            uint32_t n_blocks, uint32_t n_codes, uint32_t raw_base, uint32_t g_lo, uint32_t n_new,
+                                            unsigned long long *bh, uint32_t *bp, uint32_t at) {
+    const uint32_t lane = lane_id();
+    const float scale = (float)n_blocks / (float)n_codes;
+    uint32_t jj[FAST_NB];
+    {
+        uint64_t hv[FAST_NB], jw[FAST_NB];
+#pragma unroll
+        for (int i = 0; i < FAST_NB; ++i) {
+            hv[i] = 0;
+            jw[i] = 0;
+            const uint32_t li = (uint32_t)i * 64u + lane;
+            if (li < n_new) {
+                const uint32_t g = g_lo + li;
+                uint32_t lo = 0, hi = 64;  // largest L with lane_prefix[L] <= g
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (S.f.lane_prefix[mid] <= g) lo = mid;
+                    else hi = mid;
+                }
+                const uint32_t ei = g - S.f.lane_prefix[lo];
+                const uint64_t *rec = reinterpret_cast<const uint64_t *>(em + (ei * 64u + lo));
+                hv[i] = ld_sc1_u64(rec);
+                jw[i] = ld_sc1_u64(rec + 1);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FAST_NB; ++i) {
+            const uint32_t li = (uint32_t)i * 64u + lane;
+            jj[i] = (uint32_t)jw[i];
+            if (li < n_new) bh[at + li] = hv[i];
+        }
+    }
+    uint32_t br[FAST_NB];  // block << 7 | rank of the head inside the block
+    uint64_t m01[FAST_NB], m23[FAST_NB];
+#pragma unroll
+    for (int i = 0; i < FAST_NB; ++i) {
+        br[i] = 0;
+        m01[i] = m23[i] = 0;
+        const uint32_t li = (uint32_t)i * 64u + lane;
+        if (li < n_new) {
+            const uint32_t j = jj[i];
+            uint32_t b = (uint32_t)((float)j * scale);  // interpolate, then walk to the block with cnt64[b] <= j < cnt64[b+1]
+            if (b >= n_blocks) b = n_blocks - 1u;
+            while ((uint32_t)S.f.cnt64[b] > j) --b;
+            while ((uint32_t)S.f.cnt64[b + 1u] <= j) ++b;
+            br[i] = (b << 7) | (j - (uint32_t)S.f.cnt64[b]);
+            const uint64_t *hp = reinterpret_cast<const uint64_t *>(hm_scratch + b * 4u);
+            m01[i] = ld_sc1_u64(hp);
+            m23[i] = ld_sc1_u64(hp + 1);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < FAST_NB; ++i) {
+        const uint32_t li = (uint32_t)i * 64u + lane;
+        if (li < n_new) bp[at + li] = raw_base + (br[i] >> 7) * 64u + select_head(m01[i], m23[i], br[i] & 127u);
+    }
 }
 
 template <class Sink>
-__device__ __forceinline__ void fast_stage_c(WaveLds &S, Sink &sink, uint32_t &mz_count, uint32_t my_count, const uint4 *__restrict__ em,
-                                             const uint32_t *__restrict__ hm_scratch, uint32_t n_blocks, uint32_t raw_base) {
+__device__ __forceinline__ void fast_stage_c(WaveLds &S, const DevParams &P, Sink &sink, uint32_t my_count, const uint4 *__restrict__ em,
+                                             const uint32_t *__restrict__ hm_scratch, uint32_t n_blocks, uint32_t n_codes, uint32_t raw_base,
+                                             uint32_t stop_after = 0) {
     const uint32_t lane = lane_id();
     uint32_t incl = my_count;
 #pragma unroll
@@ -277,38 +397,58 @@ __device__ __forceinline__ void fast_stage_c(WaveLds &S, Sink &sink, uint32_t &m
     if (lane == 0) S.f.lane_prefix[64] = total;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's scratch stores have reached L2
     wave_sync();
-    for (uint32_t g0 = 0; g0 < total; g0 += 64u) {
-        const uint32_t g = g0 + lane;
-        if (g < total) {
-            uint32_t lo = 0, hi = 64;  // largest L with prefix[L] <= g
-            while (hi - lo > 1u) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (S.f.lane_prefix[mid] <= g) lo = mid;
-                else hi = mid;
-            }
-            const uint32_t ei = g - S.f.lane_prefix[lo];
-            const uint64_t *rec = reinterpret_cast<const uint64_t *>(em + (ei * 64u + lo));
-            const uint64_t hv = ld_sc1_u64(rec);
-            const uint32_t j = (uint32_t)ld_sc1_u64(rec + 1);
-            S.mz_hash[mz_count + lane] = hv;
-            S.mz_pos[mz_count + lane] = raw_base + fast_rawpos(S, n_blocks, hm_scratch, j);
-        }
-        mz_count += total - g0 < 64u ? total - g0 : 64u;
+    // the code stream is dead now: its LDS holds the ordered minimizer list
+    unsigned long long *bh = reinterpret_cast<unsigned long long *>(&S.f.codes[0]);
+    uint32_t *bp = &S.f.codes[2u * FAST_LIST_CAP];
+    uint32_t carry = 0;
+    for (uint32_t g_lo = 0; g_lo < total;) {
+        const uint32_t room = FAST_LIST_CAP - carry;
+        const uint32_t n_new = total - g_lo < room ? total - g_lo : room;
+        fast_gather(S, em, hm_scratch, n_blocks, n_codes, raw_base, g_lo, n_new, bh, bp, carry);
         wave_sync();
-        sink.on_minimizers(S, mz_count);
+        const uint32_t have = carry + n_new;
+        if (stop_after != 3u) sink.template consume_list<FAST_NB>(bh, bp, have);
+        g_lo += n_new;
+        if (g_lo < total) {  // more chunks: the last k-1 minimizers open the next chunk's windows
+            const uint32_t c = P.k - 1u < have ? P.k - 1u : have;
+            unsigned long long th = 0;
+            uint32_t tp = 0;
+            if (lane < c) {
+                th = bh[have - c + lane];
+                tp = bp[have - c + lane];
+            }
+            wave_sync();
+            if (lane < c) {
+                bh[lane] = th;
+                bp[lane] = tp;
+            }
+            wave_sync();
+            carry = c;
+        }
     }
 }
 
 // Whole sequence through the fast path.  Returns false (nothing emitted to the sink) if it does not qualify.
-template <class Sink>
+// TIMING (diagnostic builds only): tacc[0..2] += cycles spent in stages A, B, C.
+template <class Sink, bool TIMING = false>
 __device__ __forceinline__ bool fast_seed_sequence(const uint8_t *__restrict__ seq, uint32_t len, const DevParams &P, const WgTables &T,
                                                    WaveLds &S, Sink &sink, uint32_t &mz_count, uint4 *__restrict__ em,
-                                                   uint32_t *__restrict__ hm_scratch) {
+                                                   uint32_t *__restrict__ hm_scratch, unsigned long long *tacc = nullptr,
+                                                   uint32_t stop_after = 0) {
     uint32_t n_codes = 0, n_blocks = 0;
-    if (!fast_stage_a(seq, len, P.use_hpc != 0, T, S, hm_scratch, n_codes, n_blocks)) return false;
+    const unsigned long long t0 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
+    const bool ok = fast_stage_a(seq, len, P.use_hpc != 0, T, S, hm_scratch, n_codes, n_blocks);
+    const unsigned long long t1 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (TIMING) tacc[0] += t1 - t0;
+    if (!ok) return false;
+    if (stop_after == 1u) return true;
     if (n_codes < P.l) return true;  // fewer compressed bases than one l-mer: no minimizers
     const uint32_t my = fast_stage_b(T, S, P, n_codes - P.l + 1u, em);
-    fast_stage_c(S, sink, mz_count, my, em, hm_scratch, n_blocks, 0u);
+    const unsigned long long t2 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (TIMING) tacc[1] += t2 - t1;
+    if (stop_after == 2u) return true;
+    fast_stage_c(S, P, sink, my, em, hm_scratch, n_blocks, n_codes, 0u, stop_after);
+    if (TIMING) tacc[2] += __builtin_amdgcn_s_memtime() - t2;
     return true;
 }
 
