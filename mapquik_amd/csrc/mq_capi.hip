@@ -349,6 +349,8 @@ static int ensure_scratch(mq_index *idx, uint32_t max_len) {
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, map_kernel<64, true>, 64 * MAP_WAVES, 0));
         if (occ < 1) occ = 1;
         if (occ > 8) occ = 8;
+        const char *oe = getenv("MQ_OCC");  // diagnostic: cap workgroups per CU
+        if (oe && atoi(oe) >= 1 && atoi(oe) < occ) occ = atoi(oe);
         idx->grid = (uint32_t)(occ * idx->n_cu);  // workgroups; MAP_WAVES persistent waves each
     }
     const size_t n_waves = (size_t)idx->grid * MAP_WAVES;

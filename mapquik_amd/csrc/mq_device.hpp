@@ -555,9 +555,10 @@ struct MapSink {
         //   forward run continues iff r.offset - p.offset == 1                                      (cf)
         const uint32_t r_id = e.id_rc >> 1;
         const uint32_t srel = (hit && (rev != ((e.id_rc & 1u) != 0))) ? 1u : 0u;  // q.rev != r.rc
-        uint32_t hit_p = (uint32_t)__shfl_up((int)(hit ? 1u : 0u), 1, 64);
-        uint32_t id_p = (uint32_t)__shfl_up((int)r_id, 1, 64);
-        uint32_t off_p = (uint32_t)__shfl_up((int)e.offset, 1, 64);
+        // previous element's entry: DPP wave shift right by one lane (lane 0 takes the carried element)
+        uint32_t hit_p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(hit ? 1u : 0u), 0x138, 0xf, 0xf, false);
+        uint32_t id_p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r_id, 0x138, 0xf, 0xf, false);
+        uint32_t off_p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)e.offset, 0x138, 0xf, 0xf, false);
         if (lane == 0) {
             hit_p = c_hit;
             id_p = c_id;
@@ -566,23 +567,25 @@ struct MapSink {
         const bool both = hit && hit_p;
         const bool cf = both && ((int32_t)(e.offset - off_p) == 1);
         const bool cr = both && r_id == id_p && srel == 1u && ((int32_t)(off_p - e.offset) == 1);
+        // Element i maps the previous state to: miss -> 0; hit -> sv = (srel ? 2 : 1) unless it continues a run
+        // (state 1 && cf -> 1, state 2 && cr -> 2).  cr implies sv == 2 and cf with sv == 1 gives 1 either way, so every
+        // element is a CONSTANT map except "cf && srel" (1 -> 1, anything else -> 2), which is idempotent under
+        // composition: the state after it is 1 iff the nearest preceding constant element (or the carry) left state 1.
         const uint32_t sv = srel ? 2u : 1u;
-        // f(N) | f(F) << 2 | f(R) << 4
-        uint32_t G = hit ? (sv | ((cf ? 1u : sv) << 2) | ((cr ? 2u : sv) << 4)) : 0u;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)G, d, 64);  // earlier elements
-            if (lane >= (uint32_t)d) {
-                const uint32_t hN = (G >> (2u * (o & 3u))) & 3u;
-                const uint32_t hF = (G >> (2u * ((o >> 2) & 3u))) & 3u;
-                const uint32_t hR = (G >> (2u * ((o >> 4) & 3u))) & 3u;
-                G = hN | (hF << 2) | (hR << 4);
-            }
+        const bool nonconst = cf && srel == 1u;
+        const uint64_t constmask = __ballot(!nonconst);
+        const uint64_t constF = __ballot(!nonconst && hit && sv == 1u);
+        const uint64_t lt_mask = lane ? (~0ull >> (64u - lane)) : 0ull;  // lanes below this one
+        uint32_t sigma;
+        {
+            const uint64_t below = constmask & lt_mask;
+            const bool baseF = below ? ((constF >> (63 - __clzll((long long)below))) & 1ull) != 0 : (c_sigma == 1u);
+            sigma = nonconst ? (baseF ? 1u : 2u) : (hit ? sv : 0u);
         }
-        const uint32_t sigma = (G >> (2u * c_sigma)) & 3u;
-        uint32_t sigma_p = (uint32_t)__shfl_up((int)sigma, 1, 64);
-        if (lane == 0) sigma_p = c_sigma;
-        const bool isnew = hit && !((sigma_p == 1u && cf) || (sigma_p == 2u && cr));
+        const uint64_t stF = __ballot(sigma == 1u), stR = __ballot(sigma == 2u);
+        const bool prevF = lane ? ((stF >> (lane - 1u)) & 1ull) != 0 : (c_sigma == 1u);
+        const bool prevR = lane ? ((stR >> (lane - 1u)) & 1ull) != 0 : (c_sigma == 2u);
+        const bool isnew = hit && !((prevF && cf) || (prevR && cr));
         const uint64_t hitmask = __ballot(hit);
         const uint64_t newmask = __ballot(isnew);
         // the run carried in from the previous batch ends unless element 0 continues it

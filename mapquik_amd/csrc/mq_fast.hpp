@@ -219,13 +219,14 @@ struct Hash2 {
 };
 
 // Rolls ntHash over windows [0, w_eff) of the tile's code stream.  Lane L owns windows [L*16d, (L+1)*16d).
-// Selected windows are appended to the lane's list in em (entry e of lane L at em[e*64+L]): {hash lo, hash hi, j, 0}.
+// Selected windows are appended to the lane's list in em (entry e of lane L at em[e*64+L]): {hash lo, hash hi, j, -}.
+// Every dynamic instruction counts here (the kernel is issue-bound): the per-step test is min(fh.hi, rh.hi) <= hi(bound)
+// (two VALU ops + one scalar branch); the exact 64-bit comparison runs only when some lane is a candidate.
 __device__ __forceinline__ uint32_t fast_stage_b(const WgTables &T, const WaveLds &S, const DevParams &P, uint32_t w_eff,
                                                  uint4 *__restrict__ em) {
     const uint32_t lane = lane_id();
     const uint32_t l = P.l;
-    uint32_t d = (w_eff + 1023u) >> 10;
-    d |= 1u;  // odd dword stride between lanes: conflict-free ds_read_b32 of the per-lane streams
+    const uint32_t d = (w_eff + 1023u) >> 10;  // 16-step blocks per lane
     const uint32_t lc = 16u * d;
     const uint32_t start = lane * lc;
     const uint32_t nvalid = start < w_eff ? (w_eff - start < lc ? w_eff - start : lc) : 0u;
@@ -239,7 +240,6 @@ __device__ __forceinline__ uint32_t fast_stage_b(const WgTables &T, const WaveLd
         for (uint32_t m = 0; m < cnt; ++m) h.roll(T.warm[(dw >> (2u * m)) & 3u]);
     }
     const uint32_t in_dw = l >> 4, in_sh = 2u * (l & 15u);
-    uint32_t e = 0;
     // nibble m of xe / xo = out | in<<2 for step 2m / 2m+1 of a 16-step block
     auto mk_xe = [](uint32_t ow, uint32_t iw) { return (ow & 0x33333333u) | ((iw & 0x33333333u) << 2); };
     auto mk_xo = [](uint32_t ow, uint32_t iw) { return ((ow >> 2) & 0x33333333u) | (iw & 0xCCCCCCCCu); };
@@ -258,6 +258,8 @@ __device__ __forceinline__ uint32_t fast_stage_b(const WgTables &T, const WaveLd
     uint4 tv[4];
 #pragma unroll
     for (uint32_t s = 0; s < 4; ++s) tv[s] = T.roll[nib(xe, xo, s)];
+    uint8_t *const emb = reinterpret_cast<uint8_t *>(em);
+    uint32_t eoff = lane * 16u;  // byte offset of this lane's next free entry (stride 64 entries = 1 KiB)
     for (uint32_t blk = 0; blk < d; ++blk) {
         uint32_t xe_n, xo_n;
         {
@@ -268,16 +270,16 @@ __device__ __forceinline__ uint32_t fast_stage_b(const WgTables &T, const WaveLd
             xe_n = mk_xe(ow, iw);
             xo_n = mk_xo(ow, iw);
         }
+        const uint32_t t_lo = 16u * blk;
 #pragma unroll
         for (uint32_t t = 0; t < 16; ++t) {
-            const bool cand = h.fhi <= bhi || h.rhi <= bhi;
+            const bool cand = (h.fhi < h.rhi ? h.fhi : h.rhi) <= bhi;  // high words only: 2 VALU ops per step
             if (__ballot(cand)) {
                 const uint64_t F = ((uint64_t)h.fhi << 32) | h.flo, R = ((uint64_t)h.rhi << 32) | h.rlo;
-                const uint32_t tt = 16u * blk + t;
-                if (tt < nvalid && (F <= P.bound || R <= P.bound)) {
-                    const uint64_t hv = F < R ? F : R;
-                    em[e * 64u + lane] = make_uint4((uint32_t)hv, (uint32_t)(hv >> 32), start + tt, 0u);
-                    e++;
+                const uint64_t hv = F < R ? F : R;
+                if (hv <= P.bound && t_lo + t < nvalid) {
+                    *reinterpret_cast<uint4 *>(emb + eoff) = make_uint4((uint32_t)hv, (uint32_t)(hv >> 32), start + t_lo + t, 0u);
+                    eoff += 1024u;
                 }
             }
             h.roll(tv[t & 3u]);
@@ -286,7 +288,7 @@ __device__ __forceinline__ uint32_t fast_stage_b(const WgTables &T, const WaveLd
         xe = xe_n;
         xo = xo_n;
     }
-    return e;
+    return eoff >> 10;
 }
 
 // ------------------------------------------------------------------ stage C
