@@ -219,7 +219,8 @@ struct Hash2 {
 };
 
 // Rolls ntHash over windows [0, w_eff) of the tile's code stream.  Lane L owns windows [L*16d, (L+1)*16d).
-// Selected windows are appended to the lane's list in em (entry e of lane L at em[e*64+L]): {hash lo, hash hi, j, -}.
+// Selected windows are appended to ONE dense per-wave list in HBM scratch (L2-resident in practice) in emission order:
+// {hash lo, hash hi, j, slot<<6 | lane}; lane L's records, in slot order, are its windows in position order.
 // Every dynamic instruction counts here (the kernel is issue-bound): the per-step test is min(fh.hi, rh.hi) <= hi(bound)
 // (two VALU ops + one scalar branch); the exact 64-bit comparison runs only when some lane is a candidate.
 __device__ __forceinline__ uint32_t fast_stage_b(const WgTables &T, const WaveLds &S, const DevParams &P, uint32_t w_eff,
@@ -258,8 +259,8 @@ __device__ __forceinline__ uint32_t fast_stage_b(const WgTables &T, const WaveLd
     uint4 tv[4];
 #pragma unroll
     for (uint32_t s = 0; s < 4; ++s) tv[s] = T.roll[nib(xe, xo, s)];
-    uint8_t *const emb = reinterpret_cast<uint8_t *>(em);
-    uint32_t eoff = lane * 16u;  // byte offset of this lane's next free entry (stride 64 entries = 1 KiB)
+    uint32_t wcount = 0;      // records written by the wave so far (wave-uniform): the list is dense, in emission order
+    uint32_t etag = lane;     // (slot in this lane's ordered list) << 6 | lane : where the record belongs in window order
     for (uint32_t blk = 0; blk < d; ++blk) {
         uint32_t xe_n, xo_n;
         {
@@ -277,10 +278,13 @@ __device__ __forceinline__ uint32_t fast_stage_b(const WgTables &T, const WaveLd
             if (__ballot(cand)) {
                 const uint64_t F = ((uint64_t)h.fhi << 32) | h.flo, R = ((uint64_t)h.rhi << 32) | h.rlo;
                 const uint64_t hv = F < R ? F : R;
-                if (hv <= P.bound && t_lo + t < nvalid) {
-                    *reinterpret_cast<uint4 *>(emb + eoff) = make_uint4((uint32_t)hv, (uint32_t)(hv >> 32), start + t_lo + t, 0u);
-                    eoff += 1024u;
+                const bool ok = hv <= P.bound && t_lo + t < nvalid;
+                const uint64_t okm = __ballot(ok);
+                if (ok) {
+                    em[wcount + mbcnt64(okm)] = make_uint4((uint32_t)hv, (uint32_t)(hv >> 32), start + t_lo + t, etag);
+                    etag += 64u;
                 }
+                wcount += (uint32_t)__popcll(okm);
             }
             h.roll(tv[t & 3u]);
             tv[t & 3u] = (t + 4u < 16u) ? T.roll[nib(xe, xo, t + 4u)] : T.roll[nib(xe_n, xo_n, t + 4u - 16u)];
@@ -288,7 +292,7 @@ __device__ __forceinline__ uint32_t fast_stage_b(const WgTables &T, const WaveLd
         xe = xe_n;
         xo = xo_n;
     }
-    return eoff >> 10;
+    return etag >> 6;
 }
 
 // ------------------------------------------------------------------ stage C
@@ -321,40 +325,41 @@ __device__ __forceinline__ uint32_t select_head(uint64_t m01, uint64_t m23, uint
     return w * 16u + (bit >> 1);
 }
 
-// Ordered minimizers [g_lo, g_lo + n_new) of the tile -> LDS list entries [at, at + n_new): every scratch load of the
-// chunk is issued before the first use (two exposed L2 round trips per chunk, not per minimizer).
+// Records [i0, i0 + 64*FAST_NB) of the wave's dense emission list -> their places in the ordered LDS list: a record of
+// lane L, slot e belongs at lane_prefix[L] + e.  Only places in [g_lo, g_lo + n_new) are taken (one pass when the tile's
+// minimizers fit the list, which is the normal case).  Every scratch load of the block is issued before its first use.
 __device__ __forceinline__ void fast_gather(WaveLds &S, const uint4 *__restrict__ em, const uint32_t *__restrict__ hm_scratch,
-                                            uint32_t n_blocks, uint32_t n_codes, uint32_t raw_base, uint32_t g_lo, uint32_t n_new,
-                                            unsigned long long *bh, uint32_t *bp, uint32_t at) {
+                                            uint32_t n_blocks, uint32_t n_codes, uint32_t raw_base, uint32_t total, uint32_t i0,
+                                            uint32_t g_lo, uint32_t n_new, unsigned long long *bh, uint32_t *bp, uint32_t at) {
     const uint32_t lane = lane_id();
     const float scale = (float)n_blocks / (float)n_codes;
-    uint32_t jj[FAST_NB];
+    uint32_t jj[FAST_NB], dst[FAST_NB];
     {
-        uint64_t hv[FAST_NB], jw[FAST_NB];
+        uint64_t hv[FAST_NB], jt[FAST_NB];
 #pragma unroll
         for (int i = 0; i < FAST_NB; ++i) {
             hv[i] = 0;
-            jw[i] = 0;
-            const uint32_t li = (uint32_t)i * 64u + lane;
-            if (li < n_new) {
-                const uint32_t g = g_lo + li;
-                uint32_t lo = 0, hi = 64;  // largest L with lane_prefix[L] <= g
-                while (hi - lo > 1u) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (S.f.lane_prefix[mid] <= g) lo = mid;
-                    else hi = mid;
-                }
-                const uint32_t ei = g - S.f.lane_prefix[lo];
-                const uint64_t *rec = reinterpret_cast<const uint64_t *>(em + (ei * 64u + lo));
+            jt[i] = 0;
+            const uint32_t ri = i0 + (uint32_t)i * 64u + lane;
+            if (ri < total) {
+                const uint64_t *rec = reinterpret_cast<const uint64_t *>(em + ri);
                 hv[i] = ld_sc1_u64(rec);
-                jw[i] = ld_sc1_u64(rec + 1);
+                jt[i] = ld_sc1_u64(rec + 1);
             }
         }
 #pragma unroll
         for (int i = 0; i < FAST_NB; ++i) {
-            const uint32_t li = (uint32_t)i * 64u + lane;
-            jj[i] = (uint32_t)jw[i];
-            if (li < n_new) bh[at + li] = hv[i];
+            const uint32_t ri = i0 + (uint32_t)i * 64u + lane;
+            jj[i] = (uint32_t)jt[i];
+            dst[i] = 0xFFFFFFFFu;
+            if (ri < total) {
+                const uint32_t tag = (uint32_t)(jt[i] >> 32);
+                const uint32_t g = S.f.lane_prefix[tag & 63u] + (tag >> 6);
+                if (g - g_lo < n_new) {
+                    dst[i] = at + (g - g_lo);
+                    bh[dst[i]] = hv[i];
+                }
+            }
         }
     }
     uint32_t br[FAST_NB];  // block << 7 | rank of the head inside the block
@@ -363,8 +368,7 @@ __device__ __forceinline__ void fast_gather(WaveLds &S, const uint4 *__restrict_
     for (int i = 0; i < FAST_NB; ++i) {
         br[i] = 0;
         m01[i] = m23[i] = 0;
-        const uint32_t li = (uint32_t)i * 64u + lane;
-        if (li < n_new) {
+        if (dst[i] != 0xFFFFFFFFu) {
             const uint32_t j = jj[i];
             uint32_t b = (uint32_t)((float)j * scale);  // interpolate, then walk to the block with cnt64[b] <= j < cnt64[b+1]
             if (b >= n_blocks) b = n_blocks - 1u;
@@ -378,8 +382,7 @@ __device__ __forceinline__ void fast_gather(WaveLds &S, const uint4 *__restrict_
     }
 #pragma unroll
     for (int i = 0; i < FAST_NB; ++i) {
-        const uint32_t li = (uint32_t)i * 64u + lane;
-        if (li < n_new) bp[at + li] = raw_base + (br[i] >> 7) * 64u + select_head(m01[i], m23[i], br[i] & 127u);
+        if (dst[i] != 0xFFFFFFFFu) bp[dst[i]] = raw_base + (br[i] >> 7) * 64u + select_head(m01[i], m23[i], br[i] & 127u);
     }
 }
 
@@ -406,7 +409,8 @@ __device__ __forceinline__ void fast_stage_c(WaveLds &S, const DevParams &P, Sin
     for (uint32_t g_lo = 0; g_lo < total;) {
         const uint32_t room = FAST_LIST_CAP - carry;
         const uint32_t n_new = total - g_lo < room ? total - g_lo : room;
-        fast_gather(S, em, hm_scratch, n_blocks, n_codes, raw_base, g_lo, n_new, bh, bp, carry);
+        for (uint32_t i0 = 0; i0 < total; i0 += 64u * (uint32_t)FAST_NB)
+            fast_gather(S, em, hm_scratch, n_blocks, n_codes, raw_base, total, i0, g_lo, n_new, bh, bp, carry);
         wave_sync();
         const uint32_t have = carry + n_new;
         if (stop_after != 3u) sink.template consume_list<FAST_NB>(bh, bp, have);
