@@ -184,3 +184,51 @@ def test_long_and_mixed_reads_take_the_right_path(mq, oracle, simlib, ecoli):
     _cmp_hits(hits, want)
     n_fast, n_gen = ix.last_map_path_counts()
     assert n_fast > 0 and n_gen > 0 and n_fast + n_gen == int(((offs[1:] - offs[:-1]) >= 35).sum())
+
+
+def test_real_read_fixture(mq):
+    """HIP k-min-mers of the reference's example reads vs the committed fixture (tests/golden/ecoli5_kminmers.json)."""
+    import hashlib
+    import json
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    exp = json.load(open(os.path.join(gold, "ecoli5_kminmers.json")))
+    recs, name = [], None
+    for line in open(os.path.join(gold, "nearperfect-ecoli.5.fa")):
+        line = line.strip()
+        if line.startswith(">"):
+            name = line[1:].split()[0]
+        elif name is not None:
+            recs.append((name, line.encode()))
+            name = None
+    bases = np.frombuffer(b"".join(s for _, s in recs), dtype=np.uint8)
+    offs = np.zeros(len(recs) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(s) for _, s in recs])
+    odt = np.dtype([("hash", "<u8"), ("start", "<u8"), ("end", "<u8"), ("offset", "<u8"), ("rev", "<i4"), ("_pad", "<i4")])
+    for case in exp["cases"]:
+        got = mq.Index(mq.Params(**case["params"])).kminmers_batch(bases, offs)
+        for km, e in zip(got, case["reads"]):
+            assert len(km) == e["n_kminmers"]
+            o = np.zeros(len(km), dtype=odt)  # the oracle's record layout, which the digest was taken over
+            for f in ("hash", "start", "end", "offset", "rev"):
+                o[f] = km[f]
+            assert hashlib.sha256(o.tobytes()).hexdigest() == e["sha256_of_tuples"]
+
+
+def test_device_resident_entry_point_and_reuse(mq, oracle, simlib, ecoli):
+    """mq_map_batch_device on caller-owned device buffers (torch only as the allocator), launched twice on one index."""
+    import torch
+    g, off, names = ecoli
+    reads = simlib.make_reads(g, off, 500, seed=12)
+    ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads, dict())
+    dev = torch.device("cuda", 0)
+    db = torch.from_numpy(reads["bases"]).to(dev)
+    do = torch.from_numpy(reads["offsets"].astype(np.int64)).to(dev)
+    out = torch.zeros(500 * 40, dtype=torch.uint8, device=dev)
+    ml = int((reads["offsets"][1:] - reads["offsets"][:-1]).max())
+    for _ in range(2):
+        out.zero_()
+        ix.map_batch_device(db.data_ptr(), do.data_ptr(), 500, ml, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = np.frombuffer(out.cpu().numpy().tobytes(), dtype=mq.hit_dtype)
+        _cmp_hits(got, want)
+    assert ix.last_map_ms() > 0
