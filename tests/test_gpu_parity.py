@@ -215,20 +215,26 @@ def test_real_read_fixture(mq):
 
 
 def test_device_resident_entry_point_and_reuse(mq, oracle, simlib, ecoli):
-    """mq_map_batch_device on caller-owned device buffers (torch only as the allocator), launched twice on one index."""
-    import torch
+    """mq_map_batch_device on caller-owned device buffers (plain hipMalloc through ctypes), launched twice on one index."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
     g, off, names = ecoli
     reads = simlib.make_reads(g, off, 500, seed=12)
     ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads, dict())
-    dev = torch.device("cuda", 0)
-    db = torch.from_numpy(reads["bases"]).to(dev)
-    do = torch.from_numpy(reads["offsets"].astype(np.int64)).to(dev)
-    out = torch.zeros(500 * 40, dtype=torch.uint8, device=dev)
-    ml = int((reads["offsets"][1:] - reads["offsets"][:-1]).max())
+    bases, offs = reads["bases"], reads["offsets"]
+    db, do, dout = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(db), bases.size) == 0 and hip.hipMalloc(C.byref(do), offs.size * 8) == 0
+    assert hip.hipMalloc(C.byref(dout), 500 * 40) == 0
+    assert hip.hipMemcpy(db, bases.ctypes.data, bases.size, 1) == 0 and hip.hipMemcpy(do, offs.ctypes.data, offs.size * 8, 1) == 0
+    ml = int((offs[1:] - offs[:-1]).max())
+    got = np.zeros(500, dtype=mq.hit_dtype)
     for _ in range(2):
-        out.zero_()
-        ix.map_batch_device(db.data_ptr(), do.data_ptr(), 500, ml, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        got = np.frombuffer(out.cpu().numpy().tobytes(), dtype=mq.hit_dtype)
+        ix.map_batch_device(db.value, do.value, 500, ml, dout.value, 0)
+        assert hip.hipMemcpy(got.ctypes.data, dout, 500 * 40, 2) == 0  # blocking D2H on the null stream orders after the kernel
         _cmp_hits(got, want)
     assert ix.last_map_ms() > 0
+    for p in (db, do, dout):
+        hip.hipFree(p)
