@@ -238,3 +238,34 @@ def test_device_resident_entry_point_and_reuse(mq, oracle, simlib, ecoli):
     assert ix.last_map_ms() > 0
     for p in (db, do, dout):
         hip.hipFree(p)
+
+
+def test_cli_end_to_end_paf_identical(mq, oracle, simlib, tmp_path, capsys):
+    """`python -m mapquik_amd` surface: files in, `<prefix>.paf` out, byte-identical to the oracle's PAF; the reference's log lines."""
+    from mapquik_amd import cli
+    g, off, names = simlib.make_genome([500000, 300000], seed=41, repeat_frac=0.1)
+    reads = simlib.make_reads(g, off, 150, seed=5, len_mean=12000, len_sd=4000)
+    rn = simlib.read_names(reads, names)
+    ref = tmp_path / "ref.fa"
+    with open(ref, "wb") as w:
+        for r in range(2):
+            s = g[int(off[r]):int(off[r + 1])].tobytes()
+            w.write(b">" + names[r].encode() + b" some description\n")
+            for i in range(0, len(s), 70):  # multi-line reference, mixed case
+                w.write((s[i:i + 70].lower() if (i // 70) % 2 else s[i:i + 70]) + b"\n")
+    rd = tmp_path / "reads.fa"
+    with open(rd, "wb") as w:
+        for i, n in enumerate(rn):
+            w.write(b">" + n.encode() + b"\n" + reads["bases"][int(reads["offsets"][i]):int(reads["offsets"][i + 1])].tobytes() + b"\n")
+    prefix = str(tmp_path / "out")
+    assert cli.main([str(rd), "--reference", str(ref), "-p", prefix, "--batch-bases", "400000"]) == 0
+    po = oracle.params()
+    ox = oracle.Index()
+    for r in range(2):
+        ox.add_ref(r, names[r], g[int(off[r]):int(off[r + 1])], po)
+    want = ox.map_batch(reads["bases"], reads["offsets"], po, threads=2)
+    want_txt = "".join(x + "\n" for x in oracle.paf_lines(ox, rn, want))
+    assert open(prefix + ".paf").read() == want_txt and len(want_txt) > 1000
+    out = capsys.readouterr().out
+    assert "Indexed reference %s: " % names[0] in out and "Indexed %d unique k-min-mers in " % ox.count() in out
+    assert "Mapped query sequences in " in out and "Total execution time: " in out and "Maximum RSS: " in out
