@@ -114,11 +114,13 @@ int mq_index_get_stats(const mq_index *idx, mq_index_stats *out);
 int mq_index_ref_info(const mq_index *idx, uint32_t ref_id, const char **name, uint64_t *len);
 
 /* find_matches (src/mers.rs:77-102) for n reads.  bases: concatenated reads; offsets: n+1 prefix offsets.
- * Host-buffer form: copies in, runs, copies out, synchronises. */
+ * Host-buffer form: copies in, runs, copies out, synchronises.  Reads that overflow the per-wave Match scratch are mapped
+ * again on the GPU with a worst-case scratch, so no MQ_HIT_OVERFLOW is returned from this entry point. */
 int mq_map_batch(mq_index *idx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out);
 /* Device-resident form: all pointers are device memory on the index's device; asynchronous on `stream`
  * (a hipStream_t, may be NULL).  max_len = longest read in the batch (0 => computed on the host is not possible:
  * must be given).  No allocation happens here unless the scratch has to grow for a larger max_len / n. */
+/* A read with more Match runs than the scratch holds (MQ_MATCH_CAP, default 2048) gets status MQ_HIT_OVERFLOW here. */
 int mq_map_batch_device(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint32_t max_len,
                         mq_hit *d_out, void *stream);
 /* Pre-size the per-launch scratch so that mq_map_batch_device never allocates. */

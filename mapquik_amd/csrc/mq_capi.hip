@@ -616,7 +616,8 @@ int mq_map_reserve(mq_index *idx, uint32_t max_len) {
 }  // extern "C"
 
 static int launch_map(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, mq_hit *d_out,
-                      mq_kminmer *d_dump, const uint64_t *d_dump_off, uint32_t *d_dump_counts, hipStream_t st) {
+                      mq_kminmer *d_dump, const uint64_t *d_dump_off, uint32_t *d_dump_counts, hipStream_t st,
+                      MatchRec *scratch_override = nullptr, uint32_t cap_override = 0, uint32_t grid_override = 0) {
     if (n == 0) return MQ_OK;
     HIPCHK(hipMemsetAsync(idx->d_counter, 0, 64, st));
     HIPCHK(hipEventRecord(idx->ev0, st));
@@ -628,8 +629,8 @@ static int launch_map(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_o
     A.table = idx->table;
     A.mask = idx->nslots - 1;
     A.ref_lens = idx->d_ref_lens;
-    A.scratch_all = idx->scratch;
-    A.cap_matches = idx->cap_matches;
+    A.scratch_all = scratch_override ? scratch_override : idx->scratch;
+    A.cap_matches = scratch_override ? cap_override : idx->cap_matches;
     A.fast_scratch = idx->fast_scratch;
     A.work_counter = idx->d_counter;
     A.out = d_out;
@@ -638,7 +639,8 @@ static int launch_map(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_o
     A.dump_counts = d_dump_counts;
     A.stats = idx->d_counter + 2;
     A.stop_after = idx->stop_after;  // [2] fast reads, [3] general reads, [4..15] six 64-bit stage cycle sums
-    const uint32_t grid = std::min<uint32_t>(idx->grid, (n + MAP_WAVES - 1) / MAP_WAVES);
+    uint32_t grid = std::min<uint32_t>(idx->grid, (n + MAP_WAVES - 1) / MAP_WAVES);
+    if (grid_override) grid = std::min(grid, grid_override);
     const dim3 blk(64 * MAP_WAVES);
     if (idx->stage_timing) hipLaunchKernelGGL((map_kernel<64, true, true>), dim3(grid), blk, 0, st, A);
     else if (idx->chain_chunk == 4 && idx->force_general) hipLaunchKernelGGL((map_kernel<4, false>), dim3(grid), blk, 0, st, A);
@@ -701,6 +703,44 @@ int mq_map_batch(mq_index *idx, const uint8_t *bases, const uint64_t *offsets, u
     rc = launch_map(idx, idx->st_bases, idx->st_off, n, idx->st_out, nullptr, nullptr, nullptr, 0);
     if (rc) return rc;
     HIPCHK(hipMemcpy(out, idx->st_out, (size_t)n * sizeof(mq_hit), hipMemcpyDeviceToHost));
+    // Reads whose Match runs did not fit the per-wave scratch come back as MQ_HIT_OVERFLOW: map those again on the GPU
+    // with a worst-case scratch (a read cannot have more runs than bases) on a small grid.  Never a CPU path.
+    std::vector<uint32_t> redo;
+    for (uint32_t i = 0; i < n; ++i)
+        if (out[i].status == MQ_HIT_OVERFLOW) redo.push_back(i);
+    if (!redo.empty()) {
+        uint64_t sub_total = 0, sub_max = 0;
+        std::vector<uint64_t> so(redo.size() + 1, 0);
+        for (size_t j = 0; j < redo.size(); ++j) {
+            const uint64_t L = offsets[redo[j] + 1] - offsets[redo[j]];
+            so[j + 1] = so[j] + L;
+            sub_max = std::max(sub_max, L);
+        }
+        sub_total = so.back();
+        std::vector<uint8_t> sb(sub_total ? sub_total : 1);
+        for (size_t j = 0; j < redo.size(); ++j)
+            memcpy(sb.data() + so[j], bases + offsets[redo[j]], (size_t)(so[j + 1] - so[j]));
+        const uint32_t cap = (uint32_t)std::max<uint64_t>(sub_max, 1);
+        const uint32_t rgrid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(idx->grid, (1ull << 30) / ((uint64_t)cap * sizeof(MatchRec) * MAP_WAVES)));
+        MatchRec *big = nullptr;
+        uint8_t *d_sb = nullptr;
+        uint64_t *d_so = nullptr;
+        mq_hit *d_sh = nullptr;
+        hipError_t e = hipMalloc((void **)&big, (size_t)rgrid * MAP_WAVES * cap * sizeof(MatchRec));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_sb, sub_total + 1);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_so, so.size() * 8);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_sh, redo.size() * sizeof(mq_hit));
+        if (e == hipSuccess && sub_total) e = hipMemcpy(d_sb, sb.data(), sub_total, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_so, so.data(), so.size() * 8, hipMemcpyHostToDevice);
+        int rrc = MQ_OK;
+        std::vector<mq_hit> sh(redo.size());
+        if (e == hipSuccess) rrc = launch_map(idx, d_sb, d_so, (uint32_t)redo.size(), d_sh, nullptr, nullptr, nullptr, 0, big, cap, rgrid);
+        if (e == hipSuccess && rrc == MQ_OK) e = hipMemcpy(sh.data(), d_sh, redo.size() * sizeof(mq_hit), hipMemcpyDeviceToHost);
+        hipFree(big); hipFree(d_sb); hipFree(d_so); hipFree(d_sh);
+        if (e != hipSuccess) return set_err(e == hipErrorOutOfMemory ? MQ_ENOMEM : MQ_EHIP, std::string("overflow retry: ") + hipGetErrorString(e));
+        if (rrc) return rrc;
+        for (size_t j = 0; j < redo.size(); ++j) out[redo[j]] = sh[j];
+    }
     return MQ_OK;
 }
 

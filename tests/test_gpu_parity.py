@@ -142,14 +142,29 @@ def test_map_chain_multichunk_path(mq, oracle, simlib, monkeypatch):
     _cmp_hits(hits, want)
 
 
-def test_match_overflow_is_loud(mq, oracle, simlib, monkeypatch):
+def test_match_overflow_is_loud_on_device_form_and_retried_on_host_form(mq, oracle, simlib, monkeypatch):
+    """MQ_MATCH_CAP=1: almost every read has more Match runs than the scratch.  The device-resident entry point reports
+    MQ_HIT_OVERFLOW (never a wrong line); the host-buffer entry point maps those reads again with a worst-case scratch."""
+    import ctypes as C
     monkeypatch.setenv("MQ_MATCH_CAP", "1")
     g, off, names = simlib.make_genome([200000], seed=5, repeat_frac=0.3)
     reads = simlib.make_reads(g, off, 50, seed=2, len_mean=12000, err=0.03)
     ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads, dict(k=3, l=15, density=0.03))
-    assert (hits["status"] == 2).any()
-    ok = hits["status"] != 2
-    assert np.array_equal(hits["status"][ok] == 1, want["mapped"][ok] != 0)
+    _cmp_hits(hits, want)  # host form: retried, complete and identical
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    bases, offs = reads["bases"], reads["offsets"]
+    db, do, dout = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(db), bases.size) == 0 and hip.hipMalloc(C.byref(do), offs.size * 8) == 0 and hip.hipMalloc(C.byref(dout), 50 * 40) == 0
+    hip.hipMemcpy(db, bases.ctypes.data, bases.size, 1)
+    hip.hipMemcpy(do, offs.ctypes.data, offs.size * 8, 1)
+    ix.map_batch_device(db.value, do.value, 50, int((offs[1:] - offs[:-1]).max()), dout.value, 0)
+    raw = np.zeros(50, dtype=mq.hit_dtype)
+    hip.hipMemcpy(raw.ctypes.data, dout, 50 * 40, 2)
+    assert (raw["status"] == 2).any()
+    ok = raw["status"] != 2
+    assert np.array_equal(raw["status"][ok] == 1, want["mapped"][ok] != 0)
 
 
 def test_fast_path_taken_and_general_path_agrees(mq, oracle, simlib, ecoli, monkeypatch):
