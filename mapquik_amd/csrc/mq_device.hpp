@@ -78,6 +78,8 @@ struct WaveLds {
         struct {
             uint32_t codes[FAST_CODES_DW];
             uint32_t lane_prefix[68];
+            uint32_t carry_pos[64];    // raw positions of the compressed bases carried into the next tile
+            uint32_t carry_codes[4];   // their 2-bit codes (<= 63)
             uint16_t cnt64[FAST_CNT_N];
         } f;
     };

@@ -1,4 +1,4 @@
-// mq_fast.hpp -- the fast seeding path (ACGT-only sequences that fit one LDS tile).
+// mq_fast.hpp -- the fast seeding path (ACGT-only sequences; long ones are cut into LDS tiles).
 //
 //   stage A  lanes own 16 consecutive raw bases (one 16-B load each, 1 KiB per wave row):
 //            SWAR decode ASCII -> 2-bit codes, validity check with v_perm_b32, homopolymer compression through a
@@ -11,7 +11,9 @@
 //            per-lane list in HBM scratch (worst-case sized: no overflow path).
 //   stage C  64 minimizers at a time, in order: locate (lane, slot) by binary search over the lane prefix sums, fetch,
 //            map the HPC index back to the raw position (block search + select on the head mask), hand to the sink.
-// Anything else (non-ACGT bytes, sequences longer than the tile) takes the general streaming path in mq_device.hpp.
+// A sequence longer than one tile (32,768 bases / 20,480 compressed bases) is processed tile by tile: the last l-1
+// compressed bases (codes + raw positions) and the last k-1 minimizers carry over.  Sequences with a non-ACGT byte take the
+// general streaming path in mq_device.hpp.
 #pragma once
 #include "mq_device.hpp"
 
@@ -87,12 +89,14 @@ __device__ __forceinline__ uint32_t pack16(uint32_t t0, uint32_t t1, uint32_t t2
 // ------------------------------------------------------------------ stage A
 // A super-row is 4096 raw bases: every lane owns 64 consecutive bases = one 64-base block (four 16-B loads in flight,
 // plus the next super-row's four: 8 KiB per wave outstanding), one wave prefix sum per super-row.
-// Returns false when the sequence needs the general path (non-ACGT byte, too long for the tile).
-__device__ __forceinline__ bool fast_stage_a(const uint8_t *__restrict__ seq, uint32_t len, bool use_hpc, const WgTables &T,
-                                             WaveLds &S, uint32_t *__restrict__ hm_scratch, uint32_t &n_codes, uint32_t &n_blocks) {
+// One tile: raw bases [raw0, raw_end) where raw_end is the end of the sequence or the last super-row boundary the code
+// stream (which starts with carry_n carried codes) and the block tables can hold.  Returns false on a non-ACGT byte.
+__device__ __forceinline__ bool fast_stage_a(const uint8_t *__restrict__ seq, uint32_t len, uint32_t raw0, uint32_t carry_n,
+                                             uint32_t &carry_prev, bool use_hpc, const WgTables &T, WaveLds &S,
+                                             uint32_t *__restrict__ hm_scratch, uint32_t &n_codes, uint32_t &n_blocks, uint32_t &raw_end) {
     const uint32_t lane = lane_id();
-    const uint32_t n_sr = (len + 4095u) >> 12;
-    if (n_sr * 4u > FAST_MAX_ROWS) return false;
+    uint32_t n_sr = (len - raw0 + 4095u) >> 12;
+    if (n_sr * 4u > FAST_MAX_ROWS) n_sr = FAST_MAX_ROWS / 4u;
     const uint32_t fill = (uint32_t)seq[len - 1] * 0x01010101u;
     // 16 bases at pos; bytes past the end repeat the last base (never a run head under HPC; masked without HPC)
     auto load_piece = [&](uint32_t pos) -> uint4 {
@@ -108,7 +112,7 @@ __device__ __forceinline__ bool fast_stage_a(const uint8_t *__restrict__ seq, ui
     };
     uint4 nx0, nx1, nx2, nx3;
     {
-        const uint32_t pos = lane * 64u;
+        const uint32_t pos = raw0 + lane * 64u;
         nx0 = load_piece(pos);
         nx1 = load_piece(pos + 16u);
         nx2 = load_piece(pos + 32u);
@@ -116,12 +120,13 @@ __device__ __forceinline__ bool fast_stage_a(const uint8_t *__restrict__ seq, ui
     }
     for (uint32_t i = lane * 4u; i < FAST_CODES_DW; i += 256u) *reinterpret_cast<uint4 *>(&S.f.codes[i]) = make_uint4(0, 0, 0, 0);
     wave_sync();
-    uint32_t b2 = 0;  // bits written so far = 2 * codes
+    if (lane < 4u && carry_n) S.f.codes[lane] = S.f.carry_codes[lane];  // the carried codes open the stream
+    uint32_t b2 = 2u * carry_n;  // bits written so far = 2 * codes
     uint32_t bad = 0;
-    uint32_t carry_prev = 0;
+    uint32_t sr_done = n_sr;
     constexpr uint32_t S1 = 0x00430041u, S0 = 0x00470054u;  // v_perm pool: selector 0,2 -> 'A','C' ; 4,6 -> 'T','G'
     for (uint32_t sr = 0; sr < n_sr; ++sr) {
-        const uint32_t pos = (sr << 12) + lane * 64u;
+        const uint32_t pos = raw0 + (sr << 12) + lane * 64u;
         const uint4 c0 = nx0, c1 = nx1, c2 = nx2, c3 = nx3;
         if (sr + 1u < n_sr) {
             const uint32_t np = pos + 4096u;
@@ -145,7 +150,7 @@ __device__ __forceinline__ bool fast_stage_a(const uint8_t *__restrict__ seq, ui
         uint32_t out[4], n2[4], hm[4];
         if (use_hpc) {
             uint32_t pc = (uint32_t)__shfl_up((int)(p[3] >> 30), 1, 64);
-            if (lane == 0) pc = sr == 0 ? ((p[0] & 3u) ^ 1u) : carry_prev;  // first base of the sequence is always a head
+            if (lane == 0) pc = (sr == 0 && raw0 == 0) ? ((p[0] & 3u) ^ 1u) : carry_prev;  // first base of the sequence is always a head
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t q = (p[j] << 2) | pc;
@@ -181,7 +186,10 @@ __device__ __forceinline__ bool fast_stage_a(const uint8_t *__restrict__ seq, ui
             if (lane >= (uint32_t)dd) incl += o;
         }
         const uint32_t total = rdlane(incl, 63);
-        if (b2 + total > 2u * FAST_CODES_CAP) return false;
+        if (b2 + total > 2u * FAST_CODES_CAP) {  // does not fit: the tile ends before this super-row (sr > 0 always)
+            sr_done = sr;
+            break;
+        }
         uint32_t bo = b2 + incl - mine;
         S.f.cnt64[sr * 64u + lane] = (uint16_t)(bo >> 1);
 #pragma unroll
@@ -198,7 +206,8 @@ __device__ __forceinline__ bool fast_stage_a(const uint8_t *__restrict__ seq, ui
         b2 += total;
         carry_prev = rdlane(p[3], 63) >> 30;
     }
-    n_blocks = n_sr * 64u;
+    n_blocks = sr_done * 64u;
+    raw_end = raw0 + (sr_done << 12) < len ? raw0 + (sr_done << 12) : len;
     n_codes = b2 >> 1;
     if (lane == 0) S.f.cnt64[n_blocks] = (uint16_t)n_codes;
     wave_sync();
@@ -329,8 +338,8 @@ __device__ __forceinline__ uint32_t select_head(uint64_t m01, uint64_t m23, uint
 // lane L, slot e belongs at lane_prefix[L] + e.  Only places in [g_lo, g_lo + n_new) are taken (one pass when the tile's
 // minimizers fit the list, which is the normal case).  Every scratch load of the block is issued before its first use.
 __device__ __forceinline__ void fast_gather(WaveLds &S, const uint4 *__restrict__ em, const uint32_t *__restrict__ hm_scratch,
-                                            uint32_t n_blocks, uint32_t n_codes, uint32_t raw_base, uint32_t total, uint32_t i0,
-                                            uint32_t g_lo, uint32_t n_new, unsigned long long *bh, uint32_t *bp, uint32_t at) {
+                                            uint32_t n_blocks, uint32_t n_codes, uint32_t raw_base, uint32_t carry_n, uint32_t total,
+                                            uint32_t i0, uint32_t g_lo, uint32_t n_new, unsigned long long *bh, uint32_t *bp, uint32_t at) {
     const uint32_t lane = lane_id();
     const float scale = (float)n_blocks / (float)n_codes;
     uint32_t jj[FAST_NB], dst[FAST_NB];
@@ -368,7 +377,7 @@ __device__ __forceinline__ void fast_gather(WaveLds &S, const uint4 *__restrict_
     for (int i = 0; i < FAST_NB; ++i) {
         br[i] = 0;
         m01[i] = m23[i] = 0;
-        if (dst[i] != 0xFFFFFFFFu) {
+        if (dst[i] != 0xFFFFFFFFu && jj[i] >= carry_n) {
             const uint32_t j = jj[i];
             uint32_t b = (uint32_t)((float)j * scale);  // interpolate, then walk to the block with cnt64[b] <= j < cnt64[b+1]
             if (b >= n_blocks) b = n_blocks - 1u;
@@ -382,14 +391,29 @@ __device__ __forceinline__ void fast_gather(WaveLds &S, const uint4 *__restrict_
     }
 #pragma unroll
     for (int i = 0; i < FAST_NB; ++i) {
-        if (dst[i] != 0xFFFFFFFFu) bp[dst[i]] = raw_base + (br[i] >> 7) * 64u + select_head(m01[i], m23[i], br[i] & 127u);
+        if (dst[i] != 0xFFFFFFFFu)
+            bp[dst[i]] = jj[i] < carry_n ? S.f.carry_pos[jj[i]]  // a window that starts in the previous tile's last l-1 bases
+                                         : raw_base + (br[i] >> 7) * 64u + select_head(m01[i], m23[i], br[i] & 127u);
     }
 }
 
+// Raw position of compressed base j of the current tile (used for the bases carried into the next tile)
+__device__ __forceinline__ uint32_t fast_rawpos_one(const WaveLds &S, const uint32_t *__restrict__ hm_scratch, uint32_t n_blocks,
+                                                    uint32_t n_codes, uint32_t raw_base, uint32_t carry_n, uint32_t j) {
+    if (j < carry_n) return S.f.carry_pos[j];
+    uint32_t b = (uint32_t)((float)j * ((float)n_blocks / (float)n_codes));
+    if (b >= n_blocks) b = n_blocks - 1u;
+    while ((uint32_t)S.f.cnt64[b] > j) --b;
+    while ((uint32_t)S.f.cnt64[b + 1u] <= j) ++b;
+    const uint64_t *hp = reinterpret_cast<const uint64_t *>(hm_scratch + b * 4u);
+    return raw_base + b * 64u + select_head(ld_sc1_u64(hp), ld_sc1_u64(hp + 1), j - (uint32_t)S.f.cnt64[b]);
+}
+
+// mz_carry (in/out): minimizers carried from the previous tile, stashed in S.mz_hash / S.mz_pos (outside the tile's LDS).
 template <class Sink>
 __device__ __forceinline__ void fast_stage_c(WaveLds &S, const DevParams &P, Sink &sink, uint32_t my_count, const uint4 *__restrict__ em,
                                              const uint32_t *__restrict__ hm_scratch, uint32_t n_blocks, uint32_t n_codes, uint32_t raw_base,
-                                             uint32_t stop_after = 0) {
+                                             uint32_t carry_n, uint32_t &mz_carry, bool more_tiles, uint32_t stop_after = 0) {
     const uint32_t lane = lane_id();
     uint32_t incl = my_count;
 #pragma unroll
@@ -405,14 +429,19 @@ __device__ __forceinline__ void fast_stage_c(WaveLds &S, const DevParams &P, Sin
     // the code stream is dead now: its LDS holds the ordered minimizer list
     unsigned long long *bh = reinterpret_cast<unsigned long long *>(&S.f.codes[0]);
     uint32_t *bp = &S.f.codes[2u * FAST_LIST_CAP];
-    uint32_t carry = 0;
+    uint32_t carry = mz_carry;
+    if (lane < carry) {
+        bh[lane] = S.mz_hash[lane];
+        bp[lane] = S.mz_pos[lane];
+    }
+    uint32_t have = carry;
     for (uint32_t g_lo = 0; g_lo < total;) {
         const uint32_t room = FAST_LIST_CAP - carry;
         const uint32_t n_new = total - g_lo < room ? total - g_lo : room;
         for (uint32_t i0 = 0; i0 < total; i0 += 64u * (uint32_t)FAST_NB)
-            fast_gather(S, em, hm_scratch, n_blocks, n_codes, raw_base, total, i0, g_lo, n_new, bh, bp, carry);
+            fast_gather(S, em, hm_scratch, n_blocks, n_codes, raw_base, carry_n, total, i0, g_lo, n_new, bh, bp, carry);
         wave_sync();
-        const uint32_t have = carry + n_new;
+        have = carry + n_new;
         if (stop_after != 3u) sink.template consume_list<FAST_NB>(bh, bp, have);
         g_lo += n_new;
         if (g_lo < total) {  // more chunks: the last k-1 minimizers open the next chunk's windows
@@ -430,31 +459,106 @@ __device__ __forceinline__ void fast_stage_c(WaveLds &S, const DevParams &P, Sin
             }
             wave_sync();
             carry = c;
+            have = c;
         }
+    }
+    if (more_tiles) {  // the last k-1 minimizers seen so far open the next tile's k-min-mers
+        const uint32_t c = P.k - 1u < have ? P.k - 1u : have;
+        if (lane < c) {
+            S.mz_hash[lane] = bh[have - c + lane];
+            S.mz_pos[lane] = bp[have - c + lane];
+        }
+        mz_carry = c;
+        wave_sync();
     }
 }
 
-// Whole sequence through the fast path.  Returns false (nothing emitted to the sink) if it does not qualify.
+// true iff every byte of seq[from, len) is one of A C G T
+__device__ __forceinline__ bool fast_all_acgt(const uint8_t *__restrict__ seq, uint32_t from, uint32_t len) {
+    const uint32_t lane = lane_id();
+    constexpr uint32_t S1 = 0x00430041u, S0 = 0x00470054u;
+    uint32_t bad = 0;
+    for (uint32_t pos = from + lane * 16u; pos < len; pos += 1024u) {
+        if (pos + 16u <= len) {
+            const uint4 v = *reinterpret_cast<const uint4_unaligned *>(seq + pos);
+            bad |= (__builtin_amdgcn_perm(S0, S1, v.x & 0x06060606u) ^ v.x) | (__builtin_amdgcn_perm(S0, S1, v.y & 0x06060606u) ^ v.y) |
+                   (__builtin_amdgcn_perm(S0, S1, v.z & 0x06060606u) ^ v.z) | (__builtin_amdgcn_perm(S0, S1, v.w & 0x06060606u) ^ v.w);
+        } else {
+            for (uint32_t q = pos; q < len; ++q) {
+                const uint32_t b = seq[q];
+                bad |= (b != 'A' && b != 'C' && b != 'G' && b != 'T') ? 1u : 0u;
+            }
+        }
+    }
+    return __ballot(bad != 0) == 0;
+}
+
+// Whole sequence through the fast path, tile by tile.  Returns false (nothing emitted to the sink) if it does not qualify.
 // TIMING (diagnostic builds only): tacc[0..2] += cycles spent in stages A, B, C.
 template <class Sink, bool TIMING = false>
 __device__ __forceinline__ bool fast_seed_sequence(const uint8_t *__restrict__ seq, uint32_t len, const DevParams &P, const WgTables &T,
                                                    WaveLds &S, Sink &sink, uint32_t &mz_count, uint4 *__restrict__ em,
                                                    uint32_t *__restrict__ hm_scratch, unsigned long long *tacc = nullptr,
                                                    uint32_t stop_after = 0) {
-    uint32_t n_codes = 0, n_blocks = 0;
-    const unsigned long long t0 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
-    const bool ok = fast_stage_a(seq, len, P.use_hpc != 0, T, S, hm_scratch, n_codes, n_blocks);
-    const unsigned long long t1 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
-    if (TIMING) tacc[0] += t1 - t0;
-    if (!ok) return false;
-    if (stop_after == 1u) return true;
-    if (n_codes < P.l) return true;  // fewer compressed bases than one l-mer: no minimizers
-    const uint32_t my = fast_stage_b(T, S, P, n_codes - P.l + 1u, em);
-    const unsigned long long t2 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
-    if (TIMING) tacc[1] += t2 - t1;
-    if (stop_after == 2u) return true;
-    fast_stage_c(S, P, sink, my, em, hm_scratch, n_blocks, n_codes, 0u, stop_after);
-    if (TIMING) tacc[2] += __builtin_amdgcn_s_memtime() - t2;
+    (void)mz_count;
+    const uint32_t lane = lane_id();
+    uint32_t raw0 = 0, carry_n = 0, carry_prev = 0, mz_carry = 0;
+    bool rest_checked = false;
+    while (raw0 < len) {
+        uint32_t n_codes = 0, n_blocks = 0, raw_end = 0;
+        const unsigned long long t0 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
+        const bool ok = fast_stage_a(seq, len, raw0, carry_n, carry_prev, P.use_hpc != 0, T, S, hm_scratch, n_codes, n_blocks, raw_end);
+        const unsigned long long t1 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
+        if (TIMING) tacc[0] += t1 - t0;
+        if (!ok) return false;  // only ever in the first tile: later tiles were pre-checked below before anything was emitted
+        const bool more = raw_end < len;
+        if (more && !rest_checked) {
+            if (!fast_all_acgt(seq, raw_end, len)) return false;
+            rest_checked = true;
+        }
+        if (stop_after == 1u) return true;
+        if (n_codes >= P.l) {
+            const uint32_t my = fast_stage_b(T, S, P, n_codes - P.l + 1u, em);
+            const unsigned long long t2 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
+            if (TIMING) tacc[1] += t2 - t1;
+            if (stop_after == 2u) return true;
+            // the bases carried into the next tile: read their codes and raw positions before stage C reuses the code stream
+            uint32_t new_cn = 0, cpos = 0, ccode = 0;
+            if (more) {
+                new_cn = P.l - 1u;  // n_codes >= l here
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane < new_cn) cpos = fast_rawpos_one(S, hm_scratch, n_blocks, n_codes, raw0, carry_n, n_codes - new_cn + lane);
+                if (lane < 4u) {
+                    const uint32_t sb = 2u * (n_codes - new_cn) + 32u * lane;
+                    ccode = __builtin_amdgcn_alignbit(S.f.codes[(sb >> 5) + 1u], S.f.codes[sb >> 5], sb & 31u);
+                }
+            }
+            fast_stage_c(S, P, sink, my, em, hm_scratch, n_blocks, n_codes, raw0, carry_n, mz_carry, more, stop_after);
+            if (more) {
+                if (lane < new_cn) S.f.carry_pos[lane] = cpos;
+                if (lane < 4u) S.f.carry_codes[lane] = ccode;  // bits beyond 2*new_cn are cleared by the mask below
+                wave_sync();
+                if (lane < 4u) {
+                    const uint32_t keep = 2u * new_cn > 32u * lane ? 2u * new_cn - 32u * lane : 0u;
+                    S.f.carry_codes[lane] = keep >= 32u ? ccode : (ccode & ((1u << keep) - 1u));
+                }
+                carry_n = new_cn;
+            }
+            if (TIMING) tacc[2] += __builtin_amdgcn_s_memtime() - t2;
+        } else if (more) {
+            // fewer compressed bases than one l-mer so far (a very long homopolymer run): carry every one of them
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            uint32_t cpos = 0, ccode = 0;
+            if (lane < n_codes) cpos = fast_rawpos_one(S, hm_scratch, n_blocks, n_codes, raw0, carry_n, lane);
+            if (lane < 4u) ccode = S.f.codes[lane];
+            wave_sync();
+            if (lane < n_codes) S.f.carry_pos[lane] = cpos;
+            if (lane < 4u) S.f.carry_codes[lane] = ccode;
+            carry_n = n_codes;
+        }
+        wave_sync();
+        raw0 = raw_end;
+    }
     return true;
 }
 

@@ -284,3 +284,28 @@ def test_cli_end_to_end_paf_identical(mq, oracle, simlib, tmp_path, capsys):
     out = capsys.readouterr().out
     assert "Indexed reference %s: " % names[0] in out and "Indexed %d unique k-min-mers in " % ox.count() in out
     assert "Mapped query sequences in " in out and "Total execution time: " in out and "Maximum RSS: " in out
+
+
+def test_multi_tile_fast_path_long_reads(mq, oracle, simlib, ecoli):
+    """Reads longer than one LDS tile stay on the fast path (tile by tile, carried codes / positions / minimizers)."""
+    g, off, names = ecoli
+    reads = simlib.make_reads(g, off, 24, seed=31, len_mean=120000, len_sd=80000, len_min=30000, len_max=400000)
+    rng = np.random.default_rng(2)
+    bases = reads["bases"].copy()
+    offs = reads["offsets"]
+    for i in (1, 5, 9):  # homopolymer runs longer than a tile, and one ending exactly at the end of a read
+        lo, hi = int(offs[i]), int(offs[i + 1])
+        a = lo + int(rng.integers(1000, 20000))
+        bases[a:min(hi, a + 40000 * (1 + i % 2))] = ord("A")
+    bases[int(offs[12]) - 5000:int(offs[12])] = ord("T")
+    reads2 = dict(reads)
+    reads2["bases"] = bases
+    for ps in (dict(), dict(use_hpc=False), dict(k=3, l=12, density=0.05), dict(k=8, l=64, density=0.02)):
+        ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads2, ps)
+        _cmp_hits(hits, want)
+        n_fast, n_gen = ix.last_map_path_counts()
+        assert n_gen == 0 and n_fast == 24, (ps, n_fast, n_gen)
+        got = ix.kminmers_batch(bases, offs)
+        po = oracle.params(**ps)
+        for i in range(0, 24, 5):
+            _cmp_kmm(got[i], oracle.kminmers(bases[int(offs[i]):int(offs[i + 1])], po), (ps, i))
