@@ -50,6 +50,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
+    path = path or os.environ.get("MQ_LIB")  # A/B benchmarking of two builds in one session
     p = path or _build.LIB
     if path is None:
         try:

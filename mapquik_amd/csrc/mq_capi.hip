@@ -41,8 +41,11 @@ struct MapArgs {
 
 constexpr int MAP_WAVES = 4;
 
+#ifndef MQ_MIN_WAVES
+#define MQ_MIN_WAVES 4
+#endif
 template <int CH, bool FAST, bool TIMING = false>
-__global__ __launch_bounds__(64 * MAP_WAVES, 4) void map_kernel(const MapArgs A) {
+__global__ __launch_bounds__(64 * MAP_WAVES, MQ_MIN_WAVES) void map_kernel(const MapArgs A) {
     __shared__ WgTables T;
     __shared__ WaveLds SS[MAP_WAVES];
     build_tables(T, A.P.l);

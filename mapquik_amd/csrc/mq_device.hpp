@@ -68,15 +68,17 @@ constexpr uint32_t FAST_CNT_N = 516;      // HPC count at every 64-base block (+
 
 // Per-wave LDS.  The general streaming path uses the ring, the fast path the packed tile: never at the same time.
 struct WaveLds {
-    unsigned long long mz_hash[MZ_CAP];
-    uint32_t mz_pos[MZ_CAP];
     union {
-        struct {
+        struct {  // general streaming path
+            unsigned long long mz_hash[MZ_CAP];
+            uint32_t mz_pos[MZ_CAP];
             uint32_t ring_pos[RING];
             uint8_t ring_code[RING];
         };
-        struct {
+        struct {  // fast path
             uint32_t codes[FAST_CODES_DW];
+            unsigned long long stash_hash[MAX_K];  // the last k-1 minimizers, carried into the next tile
+            uint32_t stash_pos[MAX_K];
             uint32_t lane_prefix[68];
             uint32_t carry_pos[64];    // raw positions of the compressed bases carried into the next tile
             uint32_t carry_codes[4];   // their 2-bit codes (<= 63)

@@ -242,64 +242,66 @@ __device__ __forceinline__ uint32_t fast_stage_b(const WgTables &T, const WaveLd
     const uint32_t nvalid = start < w_eff ? (w_eff - start < lc ? w_eff - start : lc) : 0u;
     const uint32_t base_dw = nvalid ? lane * d : 0u;
     const uint32_t bhi = (uint32_t)(P.bound >> 32);
-    Hash2 h = {0, 0, 0, 0};
-    // warm-up: the lane's first window, Horner form (fh = rol(fh,1)^h(c), rh = ror(rh,1)^rol(hc(c),l-1))
-    for (uint32_t m0 = 0; m0 < l; m0 += 16u) {
-        const uint32_t dw = S.f.codes[base_dw + (m0 >> 4)];
-        const uint32_t cnt = l - m0 < 16u ? l - m0 : 16u;
-        for (uint32_t m = 0; m < cnt; ++m) h.roll(T.warm[(dw >> (2u * m)) & 3u]);
-    }
-    const uint32_t in_dw = l >> 4, in_sh = 2u * (l & 15u);
-    // nibble m of xe / xo = out | in<<2 for step 2m / 2m+1 of a 16-step block
-    auto mk_xe = [](uint32_t ow, uint32_t iw) { return (ow & 0x33333333u) | ((iw & 0x33333333u) << 2); };
-    auto mk_xo = [](uint32_t ow, uint32_t iw) { return ((ow >> 2) & 0x33333333u) | (iw & 0xCCCCCCCCu); };
-    auto nib = [](uint32_t xe, uint32_t xo, uint32_t s) { return (((s & 1u) ? xo : xe) >> (4u * (s >> 1))) & 0xFu; };
-    uint32_t prev_in = S.f.codes[base_dw + in_dw];
-    uint32_t xe, xo;
-    {
-        const uint32_t ow = S.f.codes[base_dw];
-        const uint32_t nxt = S.f.codes[base_dw + in_dw + 1u];
-        const uint32_t iw = __builtin_amdgcn_alignbit(nxt, prev_in, in_sh);
-        prev_in = nxt;
-        xe = mk_xe(ow, iw);
-        xo = mk_xo(ow, iw);
-    }
-    // ring of table values for the next four steps: their LDS reads are in flight while a step tests / emits
-    uint4 tv[4];
-#pragma unroll
-    for (uint32_t s = 0; s < 4; ++s) tv[s] = T.roll[nib(xe, xo, s)];
-    uint32_t wcount = 0;      // records written by the wave so far (wave-uniform): the list is dense, in emission order
     uint32_t etag = lane;     // (slot in this lane's ordered list) << 6 | lane : where the record belongs in window order
-    for (uint32_t blk = 0; blk < d; ++blk) {
-        uint32_t xe_n, xo_n;
+    if (nvalid) {  // lanes beyond the last window sit out (exec-masked): they would only burn power
+        Hash2 h = {0, 0, 0, 0};
+        // warm-up: the lane's first window, Horner form (fh = rol(fh,1)^h(c), rh = ror(rh,1)^rol(hc(c),l-1))
+        for (uint32_t m0 = 0; m0 < l; m0 += 16u) {
+            const uint32_t dw = S.f.codes[base_dw + (m0 >> 4)];
+            const uint32_t cnt = l - m0 < 16u ? l - m0 : 16u;
+            for (uint32_t m = 0; m < cnt; ++m) h.roll(T.warm[(dw >> (2u * m)) & 3u]);
+        }
+        const uint32_t in_dw = l >> 4, in_sh = 2u * (l & 15u);
+        // nibble m of xe / xo = out | in<<2 for step 2m / 2m+1 of a 16-step block
+        auto mk_xe = [](uint32_t ow, uint32_t iw) { return (ow & 0x33333333u) | ((iw & 0x33333333u) << 2); };
+        auto mk_xo = [](uint32_t ow, uint32_t iw) { return ((ow >> 2) & 0x33333333u) | (iw & 0xCCCCCCCCu); };
+        auto nib = [](uint32_t xe, uint32_t xo, uint32_t s) { return (((s & 1u) ? xo : xe) >> (4u * (s >> 1))) & 0xFu; };
+        uint32_t prev_in = S.f.codes[base_dw + in_dw];
+        uint32_t xe, xo;
         {
-            const uint32_t ow = S.f.codes[base_dw + blk + 1u];
-            const uint32_t nxt = S.f.codes[base_dw + blk + in_dw + 2u];
+            const uint32_t ow = S.f.codes[base_dw];
+            const uint32_t nxt = S.f.codes[base_dw + in_dw + 1u];
             const uint32_t iw = __builtin_amdgcn_alignbit(nxt, prev_in, in_sh);
             prev_in = nxt;
-            xe_n = mk_xe(ow, iw);
-            xo_n = mk_xo(ow, iw);
+            xe = mk_xe(ow, iw);
+            xo = mk_xo(ow, iw);
         }
-        const uint32_t t_lo = 16u * blk;
-#pragma unroll
-        for (uint32_t t = 0; t < 16; ++t) {
-            const bool cand = (h.fhi < h.rhi ? h.fhi : h.rhi) <= bhi;  // high words only: 2 VALU ops per step
-            if (__ballot(cand)) {
-                const uint64_t F = ((uint64_t)h.fhi << 32) | h.flo, R = ((uint64_t)h.rhi << 32) | h.rlo;
-                const uint64_t hv = F < R ? F : R;
-                const bool ok = hv <= P.bound && t_lo + t < nvalid;
-                const uint64_t okm = __ballot(ok);
-                if (ok) {
-                    em[wcount + mbcnt64(okm)] = make_uint4((uint32_t)hv, (uint32_t)(hv >> 32), start + t_lo + t, etag);
-                    etag += 64u;
-                }
-                wcount += (uint32_t)__popcll(okm);
+        // ring of table values for the next four steps: their LDS reads are in flight while a step tests / emits
+        uint4 tv[4];
+    #pragma unroll
+        for (uint32_t s = 0; s < 4; ++s) tv[s] = T.roll[nib(xe, xo, s)];
+        uint32_t wcount = 0;      // records written by the wave so far (wave-uniform): the list is dense, in emission order
+        for (uint32_t blk = 0; blk < d; ++blk) {
+            uint32_t xe_n, xo_n;
+            {
+                const uint32_t ow = S.f.codes[base_dw + blk + 1u];
+                const uint32_t nxt = S.f.codes[base_dw + blk + in_dw + 2u];
+                const uint32_t iw = __builtin_amdgcn_alignbit(nxt, prev_in, in_sh);
+                prev_in = nxt;
+                xe_n = mk_xe(ow, iw);
+                xo_n = mk_xo(ow, iw);
             }
-            h.roll(tv[t & 3u]);
-            tv[t & 3u] = (t + 4u < 16u) ? T.roll[nib(xe, xo, t + 4u)] : T.roll[nib(xe_n, xo_n, t + 4u - 16u)];
+            const uint32_t t_lo = 16u * blk;
+    #pragma unroll
+            for (uint32_t t = 0; t < 16; ++t) {
+                const bool cand = (h.fhi < h.rhi ? h.fhi : h.rhi) <= bhi;  // high words only: 2 VALU ops per step
+                if (__ballot(cand)) {
+                    const uint64_t F = ((uint64_t)h.fhi << 32) | h.flo, R = ((uint64_t)h.rhi << 32) | h.rlo;
+                    const uint64_t hv = F < R ? F : R;
+                    const bool ok = hv <= P.bound && t_lo + t < nvalid;
+                    const uint64_t okm = __ballot(ok);
+                    if (ok) {
+                        em[wcount + mbcnt64(okm)] = make_uint4((uint32_t)hv, (uint32_t)(hv >> 32), start + t_lo + t, etag);
+                        etag += 64u;
+                    }
+                    wcount += (uint32_t)__popcll(okm);
+                }
+                h.roll(tv[t & 3u]);
+                tv[t & 3u] = (t + 4u < 16u) ? T.roll[nib(xe, xo, t + 4u)] : T.roll[nib(xe_n, xo_n, t + 4u - 16u)];
+            }
+            xe = xe_n;
+            xo = xo_n;
         }
-        xe = xe_n;
-        xo = xo_n;
     }
     return etag >> 6;
 }
@@ -409,7 +411,7 @@ __device__ __forceinline__ uint32_t fast_rawpos_one(const WaveLds &S, const uint
     return raw_base + b * 64u + select_head(ld_sc1_u64(hp), ld_sc1_u64(hp + 1), j - (uint32_t)S.f.cnt64[b]);
 }
 
-// mz_carry (in/out): minimizers carried from the previous tile, stashed in S.mz_hash / S.mz_pos (outside the tile's LDS).
+// mz_carry (in/out): minimizers carried from the previous tile, stashed in S.f.stash_hash / stash_pos.
 template <class Sink>
 __device__ __forceinline__ void fast_stage_c(WaveLds &S, const DevParams &P, Sink &sink, uint32_t my_count, const uint4 *__restrict__ em,
                                              const uint32_t *__restrict__ hm_scratch, uint32_t n_blocks, uint32_t n_codes, uint32_t raw_base,
@@ -431,8 +433,8 @@ __device__ __forceinline__ void fast_stage_c(WaveLds &S, const DevParams &P, Sin
     uint32_t *bp = &S.f.codes[2u * FAST_LIST_CAP];
     uint32_t carry = mz_carry;
     if (lane < carry) {
-        bh[lane] = S.mz_hash[lane];
-        bp[lane] = S.mz_pos[lane];
+        bh[lane] = S.f.stash_hash[lane];
+        bp[lane] = S.f.stash_pos[lane];
     }
     uint32_t have = carry;
     for (uint32_t g_lo = 0; g_lo < total;) {
@@ -465,8 +467,8 @@ __device__ __forceinline__ void fast_stage_c(WaveLds &S, const DevParams &P, Sin
     if (more_tiles) {  // the last k-1 minimizers seen so far open the next tile's k-min-mers
         const uint32_t c = P.k - 1u < have ? P.k - 1u : have;
         if (lane < c) {
-            S.mz_hash[lane] = bh[have - c + lane];
-            S.mz_pos[lane] = bp[have - c + lane];
+            S.f.stash_hash[lane] = bh[have - c + lane];
+            S.f.stash_pos[lane] = bp[have - c + lane];
         }
         mz_carry = c;
         wave_sync();
