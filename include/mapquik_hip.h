@@ -123,6 +123,11 @@ int mq_map_batch(mq_index *idx, const uint8_t *bases, const uint64_t *offsets, u
 /* A read with more Match runs than the scratch holds (MQ_MATCH_CAP, default 2048) gets status MQ_HIT_OVERFLOW here. */
 int mq_map_batch_device(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint32_t max_len,
                         mq_hit *d_out, void *stream);
+/* Page-locked host memory for the buffers handed to mq_map_batch / mq_index_add_ref (a feeder that parses FASTX straight
+ * into such buffers gets the full PCIe rate on the copy in; pageable buffers work too, at roughly a quarter of it). */
+void *mq_host_alloc(size_t bytes);
+void mq_host_free(void *p);
+
 /* Pre-size the per-launch scratch so that mq_map_batch_device never allocates. */
 int mq_map_reserve(mq_index *idx, uint32_t max_len);
 

@@ -22,7 +22,7 @@ assert hit_dtype.itemsize == 40 and kminmer_dtype.itemsize == 24
 EXPORTS = ["mq_last_error", "mq_abi_version", "mq_device_count", "mq_params_default", "mq_index_new", "mq_index_free",
            "mq_index_add_ref", "mq_index_add_ref_device", "mq_index_finalize", "mq_index_get_stats", "mq_index_ref_info",
            "mq_map_batch", "mq_map_batch_device", "mq_map_reserve", "mq_kminmers_batch", "mq_index_lookup", "mq_format_paf",
-           "mq_last_map_ms", "mq_last_map_path_counts", "mq_last_stage_cycles"]
+           "mq_last_map_ms", "mq_last_map_path_counts", "mq_last_stage_cycles", "mq_host_alloc", "mq_host_free"]
 
 
 class MapquikError(RuntimeError):
@@ -86,6 +86,9 @@ def load_library(path=None):
     L.mq_format_paf.argtypes = [vp, C.c_char_p, u64, vp, C.c_char_p, C.c_size_t]
     L.mq_last_map_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.mq_last_stage_cycles.argtypes = [vp, vp]
+    L.mq_host_alloc.restype = vp
+    L.mq_host_alloc.argtypes = [C.c_size_t]
+    L.mq_host_free.argtypes = [vp]
     L.mq_last_map_path_counts.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     if path is None:
         _lib = L
@@ -94,6 +97,25 @@ def load_library(path=None):
 
 def _err(L, what):
     return MapquikError("%s: %s" % (what, (L.mq_last_error() or b"").decode(errors="replace")))
+
+
+class PinnedBuffer:
+    """Page-locked host bytes (mq_host_alloc) exposed as a numpy uint8 array: fill it, pass `.array` to Index.map_batch."""
+
+    def __init__(self, nbytes):
+        self._L = load_library()
+        self._p = self._L.mq_host_alloc(nbytes)
+        if not self._p:
+            raise _err(self._L, "mq_host_alloc")
+        self.array = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(self._p))
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            self._L.mq_host_free(self._p)
+            self._p = None
+
+    __del__ = close
 
 
 def device_count():

@@ -841,6 +841,20 @@ int mq_format_paf(const mq_index *idx, const char *q_id, uint64_t q_len, const m
     return w;
 }
 
+void *mq_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_err(e == hipErrorOutOfMemory ? MQ_ENOMEM : MQ_EHIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+void mq_host_free(void *p) {
+    if (p) hipHostFree(p);
+}
+
 int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general) {
     if (!idx || !n_fast || !n_general) return set_err(MQ_EINVAL, "bad arguments");
     if (!idx->ev_valid) return set_err(MQ_ESTATE, "no map launch recorded");
