@@ -309,3 +309,31 @@ def test_multi_tile_fast_path_long_reads(mq, oracle, simlib, ecoli):
         po = oracle.params(**ps)
         for i in range(0, 24, 5):
             _cmp_kmm(got[i], oracle.kminmers(bases[int(offs[i]):int(offs[i + 1])], po), (ps, i))
+
+
+def test_scale_properties_permutation_and_idempotence(mq, oracle, simlib):
+    """Larger case (312 Mbp, 25 contigs, 8192 reads): GPU == oracle, results do not depend on the order of reads in the batch
+    (dynamic work distribution), and a second launch gives the same bytes."""
+    lens = [max(40, int(x * 0.1)) for x in simlib.CHM13_LIKE]
+    g, off, names = simlib.make_genome(lens, seed=77, threads=8, repeat_frac=0.05, tandem_frac=0.01)
+    reads = simlib.make_reads(g, off, 8192, seed=78, threads=8)
+    P, po = mq.Params(), oracle.params()
+    ix, ox = mq.Index(P), oracle.Index()
+    for r in range(len(lens)):
+        ix.add_ref(r, names[r], g[int(off[r]):int(off[r + 1])])
+    ox.build_mt(g, off, names, po, threads=8)
+    assert ix.finalize() == ox.count()
+    bases, offs = reads["bases"], reads["offsets"]
+    hits = ix.map_batch(bases, offs)
+    want = ox.map_batch(bases, offs, po, threads=8)
+    _cmp_hits(hits, want)
+    assert np.array_equal(hits.view(np.uint8), ix.map_batch(bases, offs).view(np.uint8))
+    perm = np.random.default_rng(0).permutation(8192)
+    lens_r = (offs[1:] - offs[:-1]).astype(np.int64)
+    poffs = np.zeros(8193, dtype=np.uint64)
+    poffs[1:] = np.cumsum(lens_r[perm])
+    pb = np.concatenate([bases[int(offs[i]):int(offs[i + 1])] for i in perm])
+    ph = ix.map_batch(pb, poffs)
+    assert np.array_equal(ph.view(np.uint8).reshape(8192, -1), hits.view(np.uint8).reshape(8192, -1)[perm])
+    n_mapped, n_q60, n_wrong = simlib.mapeval(reads, want)
+    assert n_q60 > 7800 and n_wrong <= 2
