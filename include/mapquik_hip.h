@@ -111,6 +111,10 @@ int64_t mq_index_add_ref_device(mq_index *idx, uint32_t ref_id, const char *name
  * src/index.rs:94-104), build the HBM-resident table.  Returns the unique count or <0. */
 int64_t mq_index_finalize(mq_index *idx);
 int mq_index_get_stats(const mq_index *idx, mq_index_stats *out);
+/* On-disk form of a finalized index (the reference has none: it re-indexes the FASTA on every run, src/closures.rs:24-94).
+ * The file holds the parameters, the reference names/lengths and the slot table; mq_index_load returns a finalized index. */
+int mq_index_save(const mq_index *idx, const char *path);
+mq_index *mq_index_load(const char *path, int device);
 int mq_index_ref_info(const mq_index *idx, uint32_t ref_id, const char **name, uint64_t *len);
 
 /* find_matches (src/mers.rs:77-102) for n reads.  bases: concatenated reads; offsets: n+1 prefix offsets.

@@ -22,7 +22,7 @@ assert hit_dtype.itemsize == 40 and kminmer_dtype.itemsize == 24
 EXPORTS = ["mq_last_error", "mq_abi_version", "mq_device_count", "mq_params_default", "mq_index_new", "mq_index_free",
            "mq_index_add_ref", "mq_index_add_ref_device", "mq_index_finalize", "mq_index_get_stats", "mq_index_ref_info",
            "mq_map_batch", "mq_map_batch_device", "mq_map_reserve", "mq_kminmers_batch", "mq_index_lookup", "mq_format_paf",
-           "mq_last_map_ms", "mq_last_map_path_counts", "mq_last_stage_cycles", "mq_host_alloc", "mq_host_free"]
+           "mq_last_map_ms", "mq_last_map_path_counts", "mq_last_stage_cycles", "mq_host_alloc", "mq_host_free", "mq_index_save", "mq_index_load"]
 
 
 class MapquikError(RuntimeError):
@@ -86,6 +86,9 @@ def load_library(path=None):
     L.mq_format_paf.argtypes = [vp, C.c_char_p, u64, vp, C.c_char_p, C.c_size_t]
     L.mq_last_map_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.mq_last_stage_cycles.argtypes = [vp, vp]
+    L.mq_index_save.argtypes = [vp, C.c_char_p]
+    L.mq_index_load.restype = vp
+    L.mq_index_load.argtypes = [C.c_char_p, C.c_int]
     L.mq_host_alloc.restype = vp
     L.mq_host_alloc.argtypes = [C.c_size_t]
     L.mq_host_free.argtypes = [vp]
@@ -135,13 +138,28 @@ def _p(a):
 class Index:
     """Index + ReadOnlyIndex (src/index.rs:73-128) + ref_map (src/closures.rs:30), resident in HBM."""
 
-    def __init__(self, params=None, device=0):
+    def __init__(self, params=None, device=0, _handle=None):
         self._L = load_library()
         self.params = params or Params()
-        self._h = self._L.mq_index_new(C.byref(self.params), device)
+        self._h = _handle if _handle is not None else self._L.mq_index_new(C.byref(self.params), device)
         if not self._h:
             raise _err(self._L, "mq_index_new")
         self.device = device
+
+    def save(self, path):
+        """Write the finalized index to disk (parameters, reference table, slot table)."""
+        if self._L.mq_index_save(self._h, os.fsencode(path)) != 0:
+            raise _err(self._L, "mq_index_save")
+
+    @classmethod
+    def load(cls, path, device=0):
+        """A finalized index read back from Index.save; the parameters stored in the file are not exposed here,
+        pass the same Params you built it with if you need them on the Python side."""
+        L = load_library()
+        h = L.mq_index_load(os.fsencode(path), device)
+        if not h:
+            raise _err(L, "mq_index_load")
+        return cls(None, device, _handle=h)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -101,6 +101,9 @@ def build_parser():
     ap.add_argument("-q", type=int)
     ap.add_argument("--device", type=int, default=0, help="HIP device ordinal (extension)")
     ap.add_argument("--batch-bases", type=int, default=1 << 30, help="bases per GPU batch (extension)")
+    ap.add_argument("--unmapped", action="store_true",
+                    help="also write <prefix>.unmapped.out with the ids of reads that got no PAF line (extension; the reference "
+                         "has this writer commented out, src/closures.rs:38-43; feeds a second pass with other parameters)")
     return ap
 
 
@@ -157,6 +160,7 @@ def main(argv=None):
     params = api.Params(k=st["k"], l=st["l"], density=st["density"], use_hpc=st["use_hpc"], c=st["c"], s=st["s"], g=st["g"])
     index = api.Index(params, device=opt.device)
     paf = open(st["prefix"] + ".paf", "w")  # src/closures.rs:32
+    unm = open(st["prefix"] + ".unmapped.out", "w") if opt.unmapped else None
 
     t0 = time.time()
     for ref_idx, (name, seq) in enumerate(read_fastx(opt.reference, st["ref_fasta"])):
@@ -178,6 +182,10 @@ def main(argv=None):
         hits = index.map_batch(bases, offs)
         for ln in index.paf_lines(names, offs, hits):  # input order, unmapped reads write nothing (src/closures.rs:117-123)
             paf.write(ln + "\n")
+        if unm is not None:
+            for nm, h in zip(names, hits):
+                if int(h["status"]) != api.MQ_HIT_MAPPED:
+                    unm.write(nm + "\n")
 
     names, seqs, acc = [], [], 0
     for name, seq in read_fastx(opt.reads, st["reads_fasta"]):
@@ -189,6 +197,8 @@ def main(argv=None):
             names, seqs, acc = [], [], 0
     flush(names, seqs)
     paf.close()
+    if unm is not None:
+        unm.close()
     print("Mapped query sequences in %s." % rust_duration(time.time() - t0))  # src/closures.rs:211
     print("Total execution time: %s" % rust_duration(time.time() - start))  # src/main.rs:270
     rss_gb = np.float32(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss * 1024) / np.float32(1024.0 ** 3)

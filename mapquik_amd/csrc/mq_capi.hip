@@ -600,6 +600,100 @@ int mq_index_get_stats(const mq_index *idx, mq_index_stats *out) {
     return MQ_OK;
 }
 
+// On-disk index (the reference has none and rebuilds on every run, src/closures.rs:24-94): header, parameters, reference
+// table, then the finalized slot table verbatim.  Little-endian, this library's layout (MQ_INDEX_MAGIC names the version).
+static const char MQ_INDEX_MAGIC[8] = {'M', 'Q', 'H', 'I', 'P', 'I', 'X', '1'};
+
+int mq_index_save(const mq_index *idx, const char *path) {
+    if (!idx || !path) return set_err(MQ_EINVAL, "bad arguments");
+    if (!idx->finalized) return set_err(MQ_ESTATE, "index not finalized");
+    int rc = use_device(idx);
+    if (rc) return rc;
+    FILE *f = fopen(path, "wb");
+    if (!f) return set_err(MQ_EINVAL, std::string("cannot open for writing: ") + path);
+    bool ok = fwrite(MQ_INDEX_MAGIC, 1, 8, f) == 8;
+    const uint64_t hdr[6] = {sizeof(Slot), idx->nslots, idx->n_kmm_total, idx->n_keys, idx->n_unique, (uint64_t)idx->refs.size()};
+    ok = ok && fwrite(&idx->params, sizeof(mq_params), 1, f) == 1 && fwrite(hdr, sizeof(hdr), 1, f) == 1;
+    for (auto &kv : idx->refs) {
+        const uint32_t id = kv.first, nl = (uint32_t)kv.second.first.size();
+        ok = ok && fwrite(&id, 4, 1, f) == 1 && fwrite(&nl, 4, 1, f) == 1 && fwrite(&kv.second.second, 8, 1, f) == 1 &&
+             (nl == 0 || fwrite(kv.second.first.data(), 1, nl, f) == nl);
+    }
+    const size_t total = (size_t)(idx->nslots + 1) * sizeof(Slot), chunk = 64u << 20;
+    std::vector<uint8_t> buf(std::min(total, chunk));
+    for (size_t o = 0; ok && o < total; o += chunk) {
+        const size_t n = std::min(chunk, total - o);
+        if (hipMemcpy(buf.data(), (const uint8_t *)idx->table + o, n, hipMemcpyDeviceToHost) != hipSuccess) {
+            fclose(f);
+            return set_err(MQ_EHIP, "hipMemcpy D2H failed while saving the index");
+        }
+        ok = fwrite(buf.data(), 1, n, f) == n;
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? MQ_OK : set_err(MQ_EINVAL, std::string("short write: ") + path);
+}
+
+mq_index *mq_index_load(const char *path, int device) {
+    if (!path) {
+        set_err(MQ_EINVAL, "path is NULL");
+        return nullptr;
+    }
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        set_err(MQ_EINVAL, std::string("cannot open: ") + path);
+        return nullptr;
+    }
+    char magic[8];
+    mq_params p;
+    uint64_t hdr[6];
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, MQ_INDEX_MAGIC, 8) != 0 || fread(&p, sizeof(p), 1, f) != 1 ||
+        fread(hdr, sizeof(hdr), 1, f) != 1 || hdr[0] != sizeof(Slot) || hdr[1] == 0 || (hdr[1] & (hdr[1] - 1)) != 0) {
+        fclose(f);
+        set_err(MQ_EINVAL, std::string("not a mapquik HIP index (or another layout version): ") + path);
+        return nullptr;
+    }
+    mq_index *idx = mq_index_new(&p, device);
+    if (!idx) {
+        fclose(f);
+        return nullptr;
+    }
+    bool ok = true;
+    for (uint64_t i = 0; ok && i < hdr[5]; ++i) {
+        uint32_t id = 0, nl = 0;
+        uint64_t len = 0;
+        ok = fread(&id, 4, 1, f) == 1 && fread(&nl, 4, 1, f) == 1 && fread(&len, 8, 1, f) == 1 && nl < (1u << 20);
+        std::string name(nl, '\0');
+        ok = ok && (nl == 0 || fread(&name[0], 1, nl, f) == nl);
+        if (ok) idx->refs[id] = std::make_pair(name, len);
+    }
+    if (ok && alloc_table(idx, hdr[1]) != MQ_OK) ok = false;
+    const size_t total = (size_t)(hdr[1] + 1) * sizeof(Slot), chunk = 64u << 20;
+    std::vector<uint8_t> buf(std::min(total, chunk));
+    for (size_t o = 0; ok && o < total; o += chunk) {
+        const size_t n = std::min(chunk, total - o);
+        ok = fread(buf.data(), 1, n, f) == n && hipMemcpy((uint8_t *)idx->table + o, buf.data(), n, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    fclose(f);
+    if (ok) {
+        uint32_t max_id = 0;
+        for (auto &kv : idx->refs) max_id = std::max(max_id, kv.first);
+        std::vector<uint64_t> lens((size_t)max_id + 1, 0);
+        for (auto &kv : idx->refs) lens[kv.first] = kv.second.second;
+        ok = hipMalloc((void **)&idx->d_ref_lens, lens.size() * sizeof(uint64_t)) == hipSuccess &&
+             hipMemcpy(idx->d_ref_lens, lens.data(), lens.size() * sizeof(uint64_t), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok) {
+        mq_index_free(idx);
+        set_err(MQ_EINVAL, std::string("truncated or unreadable index file: ") + path);
+        return nullptr;
+    }
+    idx->n_kmm_total = hdr[2];
+    idx->n_keys = hdr[3];
+    idx->n_unique = hdr[4];
+    idx->finalized = true;
+    return idx;
+}
+
 int mq_index_ref_info(const mq_index *idx, uint32_t ref_id, const char **name, uint64_t *len) {
     if (!idx) return set_err(MQ_EINVAL, "idx is NULL");
     auto it = idx->refs.find(ref_id);

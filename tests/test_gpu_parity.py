@@ -337,3 +337,22 @@ def test_scale_properties_permutation_and_idempotence(mq, oracle, simlib):
     assert np.array_equal(ph.view(np.uint8).reshape(8192, -1), hits.view(np.uint8).reshape(8192, -1)[perm])
     n_mapped, n_q60, n_wrong = simlib.mapeval(reads, want)
     assert n_q60 > 7800 and n_wrong <= 2
+
+
+def test_index_save_load_roundtrip(mq, oracle, simlib, tmp_path):
+    g, off, names = simlib.make_genome([400000, 100000], seed=9, repeat_frac=0.2)
+    reads = simlib.make_reads(g, off, 200, seed=3, len_mean=9000)
+    ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads, dict(k=4, l=20, density=0.02))
+    p = str(tmp_path / "ix.mqx")
+    ix.save(p)
+    assert os.path.getsize(p) > ix.stats()["table_bytes"]
+    ix2 = mq.Index.load(p)
+    assert ix2.stats() == ix.stats() and ix2.ref_info(1) == ix.ref_info(1)
+    hits2 = ix2.map_batch(reads["bases"], reads["offsets"])
+    assert np.array_equal(hits.view(np.uint8), hits2.view(np.uint8))
+    rn = simlib.read_names(reads, names)
+    assert ix2.paf_lines(rn, reads["offsets"], hits2) == oracle.paf_lines(ox, rn, want)
+    with open(p, "r+b") as f:
+        f.write(b"XXXX")
+    with pytest.raises(mq.MapquikError):
+        mq.Index.load(p)
