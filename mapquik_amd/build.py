@@ -21,6 +21,25 @@ def hipcc():
     return "hipcc"
 
 
+HOST_DIR = os.path.join(CSRC, "host")
+CLI = os.path.join(LIBDIR, "mapquik")
+CLI_DEPS = [os.path.join(HOST_DIR, "mapquik_main.cc"), os.path.join(HOST_DIR, "mapquik_host.hpp"),
+            os.path.join(os.path.dirname(_HERE), "include", "mapquik_hip.h")]
+
+
+def build_cli(force=False, verbose=False):
+    """The native `mapquik` driver (C++ host mirror over the C ABI): g++ -lz, linked against the in-tree library."""
+    build(force=False, verbose=verbose)
+    if not force and os.path.exists(CLI) and all(os.path.getmtime(CLI) >= os.path.getmtime(d) for d in CLI_DEPS + [LIB]):
+        return CLI
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI, CLI_DEPS[0], "-L" + LIBDIR, "-lmapquik_hip", "-lz",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + "/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return CLI
+
+
 def is_fresh():
     return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS)
 

@@ -1,0 +1,278 @@
+// mapquik (HIP backend) -- command-line driver with the reference's surface: src/main.rs:77-272 (flags, defaults, log
+// lines) and src/closures.rs:22-212 (index the reference, map the reads, write <prefix>.paf in input order).
+// The hot path runs on the GPU through mapquik_host.hpp / the C ABI.  Single-threaded FASTX reader (raw or gzip).
+#include <zlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <sys/resource.h>
+
+#include "mapquik_host.hpp"
+
+using namespace mapquik;
+using Clock = std::chrono::steady_clock;
+
+static double secs(Clock::time_point a) { return std::chrono::duration<double>(Clock::now() - a).count(); }
+
+// `{:?}` of a std::time::Duration
+static std::string rust_duration(double seconds) {
+    unsigned long long ns = (unsigned long long)(seconds * 1e9 + 0.5);
+    const char *unit[4] = {"s", "ms", "\xC2\xB5s", "ns"};
+    const unsigned long long div[4] = {1000000000ull, 1000000ull, 1000ull, 1ull};
+    for (int u = 0; u < 4; ++u) {
+        if (ns >= div[u] || u == 3) {
+            unsigned long long whole = ns / div[u], frac = ns % div[u];
+            char buf[64];
+            if (frac == 0 || div[u] == 1) {
+                snprintf(buf, sizeof(buf), "%llu%s", whole, unit[u]);
+                return buf;
+            }
+            int digits = u == 0 ? 9 : u == 1 ? 6 : 3;
+            char fr[16];
+            snprintf(fr, sizeof(fr), "%0*llu", digits, frac);
+            std::string f(fr);
+            while (!f.empty() && f.back() == '0') f.pop_back();
+            snprintf(buf, sizeof(buf), "%llu.%s%s", whole, f.c_str(), unit[u]);
+            return buf;
+        }
+    }
+    return "0ns";
+}
+
+// `{}` of an f64 for the values that occur here
+static std::string rust_float(double x) {
+    char buf[64];
+    if (x == (double)(long long)x && std::abs(x) < 1e15) {
+        snprintf(buf, sizeof(buf), "%lld", (long long)x);
+        return buf;
+    }
+    for (int prec = 1; prec < 18; ++prec) {
+        snprintf(buf, sizeof(buf), "%.*g", prec, x);
+        if (strtod(buf, nullptr) == x) break;
+    }
+    return buf;
+}
+
+static bool contains(const std::string &s, const char *t) { return s.find(t) != std::string::npos; }
+static bool ends_with(const std::string &s, const char *t) {
+    const size_t n = strlen(t);
+    return s.size() >= n && s.compare(s.size() - n, n, t) == 0;
+}
+// src/main.rs:196,202
+static bool is_fasta_name(const std::string &n) {
+    return contains(n, ".fasta.") || ends_with(n, ".fna") || contains(n, ".fna.") || contains(n, ".fa.") || ends_with(n, ".fa") ||
+           ends_with(n, ".fasta");
+}
+
+// get_reader (src/main.rs:60-75): raw or gzip through zlib (which also reads plain files); lz4 is not supported here
+struct Reader {
+    gzFile f = nullptr;
+    std::vector<char> buf;
+    explicit Reader(const std::string &path) : buf(1 << 20) {
+        if (ends_with(path, ".lz4")) {
+            fprintf(stderr, "Error opening compressed file: lz4 input is not supported by this driver\n");
+            exit(2);
+        }
+        f = gzopen(path.c_str(), "rb");
+        if (!f) {
+            fprintf(stderr, "Error opening compressed file: %s\n", path.c_str());
+            exit(2);
+        }
+        gzbuffer(f, 1 << 20);
+    }
+    ~Reader() { if (f) gzclose(f); }
+    bool line(std::string &out) {
+        out.clear();
+        for (;;) {
+            if (!gzgets(f, buf.data(), (int)buf.size())) return !out.empty();
+            const size_t n = strlen(buf.data());
+            out.append(buf.data(), n);
+            if (n && buf[n - 1] == '\n') break;
+        }
+        while (!out.empty() && (out.back() == '\n' || out.back() == '\r')) out.pop_back();
+        return true;
+    }
+};
+
+static std::string first_word(const std::string &h) {
+    size_t e = 1;
+    while (e < h.size() && !isspace((unsigned char)h[e])) ++e;
+    return h.substr(1, e - 1);
+}
+static void upper(std::string &s) {
+    for (auto &c : s)
+        if (c >= 'a' && c <= 'z') c = (char)(c - 32);  // to_ascii_uppercase (src/closures.rs:63,106)
+}
+
+// calls fn(id, seq) per record; FASTA may be multi-line, FASTQ is 4-line
+template <class Fn>
+static void read_fastx(const std::string &path, bool fasta, Fn fn) {
+    Reader r(path);
+    std::string ln, id, seq;
+    if (fasta) {
+        bool have = false;
+        while (r.line(ln)) {
+            if (!ln.empty() && ln[0] == '>') {
+                if (have) { upper(seq); fn(id, seq); }
+                id = first_word(ln);
+                seq.clear();
+                have = true;
+            } else if (have) {
+                seq += ln;
+            }
+        }
+        if (have) { upper(seq); fn(id, seq); }
+    } else {
+        std::string plus, qual;
+        while (r.line(ln)) {
+            if (ln.empty()) continue;
+            id = first_word(ln);
+            if (!r.line(seq)) break;
+            r.line(plus);
+            r.line(qual);
+            upper(seq);
+            fn(id, seq);
+        }
+    }
+}
+
+struct Opt {
+    std::string reads, reference, prefix;
+    bool has_prefix = false, debug = false, low_memory = false, nosimd = false, nohpc = false, parallelfastx = false, unmapped = false;
+    long k = -1, l = -1, c = -1, s = -1, g = -1, threads = -1, b = -1, q = -1;
+    double density = -1;
+    int device = 0;
+    unsigned long long batch_bases = 1ull << 30;
+};
+
+static void usage() {
+    puts("mapquik 0.1.0 (HIP backend)\nOriginal implementation of mapquik, a fast HiFi read mapper.\n\n"
+         "USAGE:\n    mapquik [FLAGS] [OPTIONS] [reads]\n\nFLAGS:\n        --debug\n        --low-memory\n        --nohpc\n        --nosimd\n"
+         "        --parallelfastx\n        --unmapped      (extension) also write <prefix>.unmapped.out\n\nOPTIONS:\n"
+         "    -b <b>\n    -c, --chain <chain>\n    -d, --density <density>\n    -g, --gap-diff <gap-diff>\n    -k <k>\n    -l <l>\n"
+         "    -p, --prefix <prefix>\n    -q <q>\n        --reference <reference>\n    -s, --seed <seed>\n        --threads <threads>\n"
+         "        --device <n>    (extension) HIP device ordinal\n        --batch-bases <n> (extension)\n\nARGS:\n    <reads>");
+}
+
+int main(int argc, char **argv) {
+    const auto start = Clock::now();
+    Opt o;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> const char * {
+            if (i + 1 >= argc) { fprintf(stderr, "error: %s needs a value\n", a.c_str()); exit(2); }
+            return argv[++i];
+        };
+        if (a == "-h" || a == "--help") { usage(); return 0; }
+        else if (a == "--debug") o.debug = true;
+        else if (a == "--low-memory") o.low_memory = true;
+        else if (a == "--nosimd") o.nosimd = true;
+        else if (a == "--nohpc") o.nohpc = true;
+        else if (a == "--parallelfastx") o.parallelfastx = true;
+        else if (a == "--unmapped") o.unmapped = true;
+        else if (a == "-p" || a == "--prefix") { o.prefix = val(); o.has_prefix = true; }
+        else if (a == "-k") o.k = atol(val());
+        else if (a == "-l") o.l = atol(val());
+        else if (a == "-d" || a == "--density") o.density = atof(val());
+        else if (a == "-c" || a == "--chain") o.c = atol(val());
+        else if (a == "-s" || a == "--seed") o.s = atol(val());
+        else if (a == "-g" || a == "--gap-diff") o.g = atol(val());
+        else if (a == "--reference") o.reference = val();
+        else if (a == "--threads") o.threads = atol(val());
+        else if (a == "-b") o.b = atol(val());
+        else if (a == "-q") o.q = atol(val());
+        else if (a == "--device") o.device = atoi(val());
+        else if (a == "--batch-bases") o.batch_bases = strtoull(val(), nullptr, 10);
+        else if (!a.empty() && a[0] == '-') { fprintf(stderr, "error: Found argument '%s' which wasn't expected\n", a.c_str()); return 2; }
+        else o.reads = a;
+    }
+    if (o.reads.empty()) { fprintf(stderr, "Please specify an input file.\n"); return 101; }          // panic!, src/main.rs:191
+    if (o.reference.empty()) { fprintf(stderr, "Please specify a reference file.\n"); return 101; }   // src/main.rs:192
+
+    Params P;
+    size_t threads = 8;
+    const bool reads_fasta = is_fasta_name(o.reads), ref_fasta = is_fasta_name(o.reference);
+    if (reads_fasta) printf("Input file: %s\nFormat: FASTA\n", o.reads.c_str());
+    if (ref_fasta) printf("Reference file: %s\nFormat: FASTA\n", o.reference.c_str());
+    if (o.k >= 0) P.k = (size_t)o.k; else printf("Warning: Using default k value (%zu).\n", P.k);
+    if (o.l >= 0) P.l = (size_t)o.l; else printf("Warning: Using default l value (%zu).\n", P.l);
+    if (o.b >= 0) P.b = (size_t)o.b; else printf("Warning: Using default buffer size (%zuX).\n", P.b);
+    if (o.q >= 0) P.q = (size_t)o.q; else printf("Warning: Using default queue length (%zu).\n", P.q);
+    if (o.density >= 0) P.density = o.density; else printf("Warning: Using default density value (%s%%).\n", rust_float(P.density * 100.0).c_str());
+    if (o.threads >= 0) threads = (size_t)o.threads; else printf("Warning: Using default number of threads (8).\n");
+    if (o.c >= 0) P.c = (size_t)o.c; else printf("Warning: Using default minimum chain length (%zu).\n", P.c);
+    if (o.s >= 0) P.s = (size_t)o.s; else printf("Warning: Using default minimum number of matching seeds (%zu).\n", P.s);
+    if (o.g >= 0) P.g = (size_t)o.g; else printf("Warning: Using default maximum seed gap difference (%zu).\n", P.g);
+    std::string prefix = "mapquik-k" + std::to_string(P.k) + "-d" + rust_float(P.density) + "-l" + std::to_string(P.l);
+    if (o.has_prefix) prefix = o.prefix; else printf("Warning: Using default output prefix (%s).\n", prefix.c_str());
+    P.debug = o.debug;
+    P.use_hpc = !o.nohpc;
+    P.use_simd = !o.nosimd;
+    P.use_pfx = o.parallelfastx;
+    (void)threads;
+    if (P.use_hpc) puts(P.use_simd ? "Using HPC ntHash, with SIMD" : "Using HPC ntHash, scalar");
+    else puts(P.use_simd ? "Using regular ntHash (not HPC), with SIMD" : "Using regular ntHash (not HPC), scalar");
+
+    try {
+        FILE *paf = fopen((prefix + ".paf").c_str(), "w");  // src/closures.rs:32
+        if (!paf) { fprintf(stderr, "Couldn't create %s.paf\n", prefix.c_str()); return 101; }
+        FILE *unm = o.unmapped ? fopen((prefix + ".unmapped.out").c_str(), "w") : nullptr;
+
+        auto t0 = Clock::now();
+        Index index(P, o.device);
+        size_t ref_i = 0;
+        read_fastx(o.reference, ref_fasta, [&](const std::string &id, const std::string &seq) {
+            const size_t n = mers::ref_extract(ref_i++, id, (const uint8_t *)seq.data(), seq.size(), P, index);
+            printf("Indexed reference %s: %zu k-min-mers.\n", id.c_str(), n);  // src/closures.rs:58
+        });
+        ReadOnlyIndex ro = std::move(index).into_read_only();
+        printf("Indexed %llu unique k-min-mers in %s.\n", (unsigned long long)ro.unique_count(), rust_duration(secs(t0)).c_str());
+
+        t0 = Clock::now();
+        if (P.use_pfx && !ends_with(o.reads, ".gz") && !ends_with(o.reads, ".lz4")) puts("Warning: using experimental rust-parallelfastx (exciting!)");
+        std::vector<std::string> ids;
+        std::string bases;
+        std::vector<uint64_t> offs(1, 0);
+        auto flush = [&]() {
+            if (ids.empty()) return;
+            auto res = mers::find_matches_batch(ids, (const uint8_t *)bases.data(), offs, ro, P);
+            for (size_t i = 0; i < res.size(); ++i) {
+                if (res[i]) fprintf(paf, "%s\n", res[i]->c_str());  // main_thread_mer, input order (src/closures.rs:117-123)
+                else if (unm) fprintf(unm, "%s\n", ids[i].c_str());
+            }
+            ids.clear();
+            bases.clear();
+            offs.assign(1, 0);
+        };
+        read_fastx(o.reads, reads_fasta, [&](const std::string &id, const std::string &seq) {
+            ids.push_back(id);
+            bases += seq;
+            offs.push_back(bases.size());
+            if (bases.size() >= o.batch_bases) flush();
+        });
+        flush();
+        fclose(paf);
+        if (unm) fclose(unm);
+        printf("Mapped query sequences in %s.\n", rust_duration(secs(t0)).c_str());  // src/closures.rs:211
+    } catch (const Error &e) {
+        fprintf(stderr, "mapquik: %s\n", e.what());
+        return 101;
+    }
+    printf("Total execution time: %s\n", rust_duration(secs(start)).c_str());  // src/main.rs:270
+    struct rusage ru;
+    getrusage(RUSAGE_SELF, &ru);
+    const float gb = (float)((double)ru.ru_maxrss * 1024.0) / 1024.0f / 1024.0f / 1024.0f;
+    char fb[64];
+    for (int prec = 1; prec < 12; ++prec) {
+        snprintf(fb, sizeof(fb), "%.*g", prec, (double)gb);
+        if ((float)strtod(fb, nullptr) == gb) break;
+    }
+    printf("Maximum RSS: %sGB\n", strchr(fb, '.') || strchr(fb, 'e') ? fb : (std::string(fb) + ".0").c_str());  // src/main.rs:271
+    return 0;
+}

@@ -63,3 +63,27 @@ def test_missing_arguments_exit_like_the_reference():
     with pytest.raises(SystemExit) as e:
         cli.main(["reads.fa"])
     assert "Please specify a reference file." in str(e.value)
+
+
+def _native():
+    from mapquik_amd import build
+    return build.build_cli()
+
+
+def test_native_cli_builds_and_mirrors_banner(tmp_path):
+    """The C++ driver (mapquik_amd/csrc/host) prints the same pre-run lines as the reference (and as the Python driver)."""
+    import subprocess
+    exe = _native()
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 101 and "Please specify an input file." in r.stderr
+    r = subprocess.run([exe, "reads.fq"], capture_output=True, text=True)
+    assert r.returncode == 101 and "Please specify a reference file." in r.stderr
+    argv = ["reads.fq", "--reference", "ref.fa", "-p", str(tmp_path / "o")]
+    r = subprocess.run([exe] + argv, capture_output=True, text=True, cwd=tmp_path)
+    want, _ = cli.banner_lines(cli.build_parser().parse_args(argv))
+    got = r.stdout.splitlines()
+    assert got[:len(want)] == want
+    argv = "nearperfect-ecoli.100.fa --reference ecoli.genome.fa --debug -k 8 -d 0.01 -l 16 -p mapquik -g 100 --threads 11 --nohpc".split()
+    r = subprocess.run([exe] + argv, capture_output=True, text=True, cwd=tmp_path)
+    want, _ = cli.banner_lines(cli.build_parser().parse_args(argv))
+    assert r.stdout.splitlines()[:len(want)] == want

@@ -356,3 +356,41 @@ def test_index_save_load_roundtrip(mq, oracle, simlib, tmp_path):
         f.write(b"XXXX")
     with pytest.raises(mq.MapquikError):
         mq.Index.load(p)
+
+
+def test_native_cli_end_to_end_paf_identical(mq, oracle, simlib, tmp_path):
+    """The C++ `mapquik` driver: gzip'ed multi-line mixed-case reference, FASTQ reads, `<prefix>.paf` identical to the oracle."""
+    import gzip
+    import subprocess
+    from mapquik_amd import build
+    exe = build.build_cli()
+    g, off, names = simlib.make_genome([500000, 300000], seed=43, repeat_frac=0.1)
+    reads = simlib.make_reads(g, off, 150, seed=6, len_mean=12000, len_sd=4000)
+    rn = simlib.read_names(reads, names)
+    ref = tmp_path / "ref.fa.gz"
+    with gzip.open(ref, "wb") as w:
+        for r in range(2):
+            s = g[int(off[r]):int(off[r + 1])].tobytes()
+            w.write(b">" + names[r].encode() + b" desc\n")
+            for i in range(0, len(s), 60):
+                w.write((s[i:i + 60].lower() if (i // 60) % 3 == 0 else s[i:i + 60]) + b"\n")
+    rd = tmp_path / "reads.fastq"
+    with open(rd, "wb") as w:
+        for i, n in enumerate(rn):
+            s = reads["bases"][int(reads["offsets"][i]):int(reads["offsets"][i + 1])].tobytes()
+            w.write(b"@" + n.encode() + b" x\n" + s + b"\n+\n" + b"I" * len(s) + b"\n")
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([exe, str(rd), "--reference", str(ref), "-p", prefix, "--batch-bases", "500000", "--unmapped"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    po = oracle.params()
+    ox = oracle.Index()
+    for k in range(2):
+        ox.add_ref(k, names[k], g[int(off[k]):int(off[k + 1])], po)
+    want = ox.map_batch(reads["bases"], reads["offsets"], po, threads=2)
+    want_txt = "".join(x + "\n" for x in oracle.paf_lines(ox, rn, want))
+    assert open(prefix + ".paf").read() == want_txt and len(want_txt) > 1000
+    unm = open(prefix + ".unmapped.out").read().split()
+    assert unm == [n for n, w_ in zip(rn, want) if not w_["mapped"]]
+    assert "Indexed %d unique k-min-mers in " % ox.count() in r.stdout and "Mapped query sequences in " in r.stdout
+    assert "Maximum RSS: " in r.stdout
