@@ -394,3 +394,46 @@ def test_native_cli_end_to_end_paf_identical(mq, oracle, simlib, tmp_path):
     assert unm == [n for n, w_ in zip(rn, want) if not w_["mapped"]]
     assert "Indexed %d unique k-min-mers in " % ox.count() in r.stdout and "Mapped query sequences in " in r.stdout
     assert "Maximum RSS: " in r.stdout
+
+
+def test_fuzz_params_and_sequences(mq, oracle, simlib):
+    """Random (k, l, density, hpc, c, s, g) x random genomes/reads incl. N runs, lowercase, low-complexity stretches."""
+    rng = np.random.default_rng(20240)
+    for it in range(24):
+        k = int(rng.integers(1, 13))
+        l = int(rng.choice([1, 2, 5, 8, 12, 15, 16, 17, 24, 31, 32, 33, 47, 63, 64]))
+        dens = float(rng.choice([0.002, 0.01, 0.03, 0.1, 0.3]))
+        ps = dict(k=k, l=l, density=dens, use_hpc=bool(rng.integers(0, 2)), c=int(rng.integers(0, 6)), s=int(rng.integers(0, 15)),
+                  g=int(rng.choice([0, 50, 500, 2000, 100000])))
+        lens = [int(x) for x in rng.integers(30, 120000, size=int(rng.integers(1, 5)))]
+        g, off, names = simlib.make_genome(lens, seed=int(rng.integers(1, 1 << 30)), repeat_frac=float(rng.choice([0, 0.2, 0.6])),
+                                           tandem_frac=float(rng.choice([0, 0.1])), threads=2)
+        reads = simlib.make_reads(g, off, 40, seed=int(rng.integers(1, 1 << 30)), len_mean=float(rng.choice([300, 3000, 20000])),
+                                  len_sd=2000, len_min=1, len_max=60000, err=float(rng.choice([0, 0.01, 0.05])), threads=2)
+        bases = reads["bases"].copy()
+        offs = reads["offsets"]
+        for i in range(0, 40, 7):  # damage some reads: N run, lowercase, homopolymer, dinucleotide repeat
+            lo, hi = int(offs[i]), int(offs[i + 1])
+            if hi - lo < 50:
+                continue
+            a = lo + int(rng.integers(0, hi - lo - 40))
+            kind = (i // 7) % 4
+            if kind == 0:
+                bases[a:a + 30] = ord("N")
+            elif kind == 1:
+                bases[a:a + 20] |= 0x20
+            elif kind == 2:
+                bases[a:min(hi, a + 3000)] = ord("G")
+            else:
+                seg = bases[a:min(hi, a + 2000)]
+                seg[:] = np.where(np.arange(seg.size) % 2 == 0, ord("A"), ord("C"))
+        reads2 = dict(reads)
+        reads2["bases"] = bases
+        ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads2, ps)
+        _cmp_hits(hits, want)
+        got = ix.kminmers_batch(bases, offs)
+        po = oracle.params(**ps)
+        for i in range(0, 40, 3):
+            s = bases[int(offs[i]):int(offs[i + 1])]
+            w = oracle.kminmers(s, po) if s.size >= po.l + po.k - 1 else np.zeros(0, dtype=oracle.kminmer_dtype)
+            _cmp_kmm(got[i], w, (it, ps, i))
