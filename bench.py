@@ -150,9 +150,15 @@ def main():
     n_over = int((hits["status"] == 2).sum())
 
     # ---- roofline of the dominant (only) kernel of a step: map_kernel
-    # algorithmic bytes per launch (DESIGN.md "Measurement"): 1 B per base (ASCII in HBM) + one 32-B slot per k-min-mer
-    # lookup (extra linear-probe steps are NOT counted as algorithmic) + 8 B offset + 40 B result per read
-    alg_bytes = total_bases * 1 + n_kmm * st["slot_bytes"] + n * (8 + 40)
+    # algorithmic bytes per launch = SURVEY.md 8(d): L*b_in + n_kmm*S_slot*p_bar + S_out per read, with b_in = 1 B (ASCII in
+    # HBM), S_slot = 32 B, p_bar = mean probes per lookup MEASURED on this batch by one instrumented launch outside the timed
+    # region, S_out = 40 B (+ 8 B offset)
+    d_out2 = torch.zeros_like(d_out)
+    lookups, extra = ix.probe_stats(d_bases.data_ptr(), d_offs.data_ptr(), n, max_len, d_out2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(d_out, d_out2), "instrumented launch disagrees with the timed one"
+    p_bar = 1.0 + extra / max(lookups, 1)
+    alg_bytes = total_bases * 1 + n_kmm * st["slot_bytes"] * p_bar + n * (8 + 40)
     achieved = alg_bytes / avg_kern_s / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -165,7 +171,7 @@ def main():
             traffic = None
     roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=8000.0, unit="GB/s", frac=round(achieved / 8000.0, 4),
                     traffic=traffic, kernel="map_kernel", avg_launch_ms=round(avg_kern_s * 1e3, 4),
-                    algorithmic_bytes_per_launch=int(alg_bytes))
+                    algorithmic_bytes_per_launch=int(alg_bytes), mean_probes_per_lookup=round(p_bar, 4))
 
     # ---- CPU baseline: the C oracle ("port") on a bounded sample of the same reads, rank 0 at N=1 only
     cpu = None

@@ -152,8 +152,14 @@ int mq_format_paf(const mq_index *idx, const char *q_id, uint64_t q_len, const m
 int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general);
 
 /* Diagnostic builds only (env MQ_STAGE_TIMING=1 selects an instrumented kernel; its run time is never a reported number):
- * shader-clock cycles summed over all waves of the last launch in {stage A, stage B, stage C + consume, finish, chain, whole wave}. */
-int mq_last_stage_cycles(mq_index *idx, uint64_t *cycles6);
+ * shader-clock cycles summed over all waves of the last launch in {stage A, stage B, stage C + consume, finish, chain, whole wave},
+ * then {index slots visited beyond the home slot, index lookups}. */
+int mq_last_stage_cycles(mq_index *idx, uint64_t *cycles8);
+
+/* Measurement aid: one instrumented (slower, never timed) launch of the same batch that counts index lookups and the slots
+ * visited beyond each lookup's home slot: mean probes per lookup = 1 + extra_steps / lookups (SURVEY 8d's p-bar). */
+int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint32_t max_len, mq_hit *d_out,
+                       uint64_t *lookups, uint64_t *extra_steps);
 
 /* Timing of the last mq_map_batch_device launch sequence on its stream, from HIP events recorded around the
  * kernels (milliseconds).  Synchronises on the end event. */

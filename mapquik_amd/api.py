@@ -22,7 +22,7 @@ assert hit_dtype.itemsize == 40 and kminmer_dtype.itemsize == 24
 EXPORTS = ["mq_last_error", "mq_abi_version", "mq_device_count", "mq_params_default", "mq_index_new", "mq_index_free",
            "mq_index_add_ref", "mq_index_add_ref_device", "mq_index_finalize", "mq_index_get_stats", "mq_index_ref_info",
            "mq_map_batch", "mq_map_batch_device", "mq_map_reserve", "mq_kminmers_batch", "mq_index_lookup", "mq_format_paf",
-           "mq_last_map_ms", "mq_last_map_path_counts", "mq_last_stage_cycles", "mq_host_alloc", "mq_host_free", "mq_index_save", "mq_index_load"]
+           "mq_last_map_ms", "mq_last_map_path_counts", "mq_last_stage_cycles", "mq_host_alloc", "mq_host_free", "mq_index_save", "mq_index_load", "mq_map_probe_stats"]
 
 
 class MapquikError(RuntimeError):
@@ -86,6 +86,7 @@ def load_library(path=None):
     L.mq_format_paf.argtypes = [vp, C.c_char_p, u64, vp, C.c_char_p, C.c_size_t]
     L.mq_last_map_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.mq_last_stage_cycles.argtypes = [vp, vp]
+    L.mq_map_probe_stats.argtypes = [vp, vp, vp, u32, u32, vp, C.POINTER(u64), C.POINTER(u64)]
     L.mq_index_save.argtypes = [vp, C.c_char_p]
     L.mq_index_load.restype = vp
     L.mq_index_load.argtypes = [C.c_char_p, C.c_int]
@@ -233,10 +234,18 @@ class Index:
 
     def last_stage_cycles(self):
         """Diagnostic (MQ_STAGE_TIMING=1): cycles summed over waves in [A, B, C+consume, finish, chain, total]."""
-        v = np.zeros(6, dtype=np.uint64)
+        v = np.zeros(8, dtype=np.uint64)
         if self._L.mq_last_stage_cycles(self._h, _p(v)) != 0:
             raise _err(self._L, "mq_last_stage_cycles")
         return v
+
+    def probe_stats(self, d_bases, d_offsets, n, max_len, d_out):
+        """(index lookups, slots visited beyond the home slot) of one instrumented launch: p-bar = 1 + extra / lookups."""
+        a, b = C.c_uint64(), C.c_uint64()
+        if self._L.mq_map_probe_stats(self._h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n, max_len, C.c_void_p(d_out),
+                                      C.byref(a), C.byref(b)) != 0:
+            raise _err(self._L, "mq_map_probe_stats")
+        return a.value, b.value
 
     def last_map_path_counts(self):
         """(reads through the fast seeding path, reads through the general path) of the last launch."""

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MIN_WAVES) void map_kernel(const
     uint32_t *hm = reinterpret_cast<uint32_t *>(fs + FAST_EM_BYTES);
     const DevParams &P = A.P;
     uint32_t n_fast = 0, n_general = 0;
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};  // diagnostic build only: cycles in A, B, C(+consume), finish, chain, total
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostic build only: cycles in A, B, C(+consume), finish, chain, total; extra probe steps; lookups
     const unsigned long long t_begin = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
     for (;;) {
         uint32_t r = 0;
@@ -102,7 +102,11 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MIN_WAVES) void map_kernel(const
                 wave_sync();
                 chain_stage<CH>(scratch, sink.n_matches, P, len, A.ref_lens, h);
             }
-            if (TIMING) tacc[4] += __builtin_amdgcn_s_memtime() - t_f1;
+            if (TIMING) {
+                tacc[4] += __builtin_amdgcn_s_memtime() - t_f1;
+                tacc[6] += wave_sum_u32(sink.probe_steps);
+                tacc[7] += n_kmm;
+            }
         }
         h.n_kminmers = n_kmm;
         if (lane == 0) {
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MIN_WAVES) void map_kernel(const
         if (TIMING) {
             tacc[5] = __builtin_amdgcn_s_memtime() - t_begin;
             unsigned long long *ts = reinterpret_cast<unsigned long long *>(A.stats + 2);
-            for (int i = 0; i < 6; ++i) atomicAdd(&ts[i], tacc[i]);
+            for (int i = 0; i < 8; ++i) atomicAdd(&ts[i], tacc[i]);
         }
     }
 }
@@ -275,6 +279,7 @@ struct mq_index {
     uint8_t *fast_scratch = nullptr;
     bool force_general = false;     // test hook MQ_FORCE_GENERAL=1: never take the fast seeding path
     uint32_t stop_after = 0;        // diagnostic MQ_STOP_AFTER (instruction-count attribution; results are NOT valid)
+    bool timing_once = false;       // set by mq_map_probe_stats for one instrumented launch
     bool stage_timing = false;      // diagnostic MQ_STAGE_TIMING=1: s_memtime stamps per stage (never for reported numbers)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -716,7 +721,7 @@ static int launch_map(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_o
                       mq_kminmer *d_dump, const uint64_t *d_dump_off, uint32_t *d_dump_counts, hipStream_t st,
                       MatchRec *scratch_override = nullptr, uint32_t cap_override = 0, uint32_t grid_override = 0) {
     if (n == 0) return MQ_OK;
-    HIPCHK(hipMemsetAsync(idx->d_counter, 0, 64, st));
+    HIPCHK(hipMemsetAsync(idx->d_counter, 0, 128, st));
     HIPCHK(hipEventRecord(idx->ev0, st));
     MapArgs A;
     A.bases = d_bases;
@@ -739,7 +744,7 @@ static int launch_map(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_o
     uint32_t grid = std::min<uint32_t>(idx->grid, (n + MAP_WAVES - 1) / MAP_WAVES);
     if (grid_override) grid = std::min(grid, grid_override);
     const dim3 blk(64 * MAP_WAVES);
-    if (idx->stage_timing) hipLaunchKernelGGL((map_kernel<64, true, true>), dim3(grid), blk, 0, st, A);
+    if (idx->stage_timing || idx->timing_once) hipLaunchKernelGGL((map_kernel<64, true, true>), dim3(grid), blk, 0, st, A);
     else if (idx->chain_chunk == 4 && idx->force_general) hipLaunchKernelGGL((map_kernel<4, false>), dim3(grid), blk, 0, st, A);
     else if (idx->chain_chunk == 4) hipLaunchKernelGGL((map_kernel<4, true>), dim3(grid), blk, 0, st, A);
     else if (idx->force_general) hipLaunchKernelGGL((map_kernel<64, false>), dim3(grid), blk, 0, st, A);
@@ -962,13 +967,28 @@ int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general
     return MQ_OK;
 }
 
-int mq_last_stage_cycles(mq_index *idx, uint64_t *cycles6) {
-    if (!idx || !cycles6) return set_err(MQ_EINVAL, "bad arguments");
+int mq_last_stage_cycles(mq_index *idx, uint64_t *cycles8) {
+    if (!idx || !cycles8) return set_err(MQ_EINVAL, "bad arguments");
     if (!idx->ev_valid) return set_err(MQ_ESTATE, "no map launch recorded");
     int rc = use_device(idx);
     if (rc) return rc;
     HIPCHK(hipEventSynchronize(idx->ev1));
-    HIPCHK(hipMemcpy(cycles6, idx->d_counter + 4, 48, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cycles8, idx->d_counter + 4, 64, hipMemcpyDeviceToHost));
+    return MQ_OK;
+}
+
+int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint32_t max_len, mq_hit *d_out,
+                       uint64_t *lookups, uint64_t *extra_steps) {
+    if (!idx || !lookups || !extra_steps) return set_err(MQ_EINVAL, "bad arguments");
+    idx->timing_once = true;
+    int rc = mq_map_batch_device(idx, d_bases, d_offsets, n, max_len, d_out, nullptr);
+    idx->timing_once = false;
+    if (rc) return rc;
+    uint64_t v[8];
+    rc = mq_last_stage_cycles(idx, v);
+    if (rc) return rc;
+    *extra_steps = v[6];
+    *lookups = v[7];
     return MQ_OK;
 }
 

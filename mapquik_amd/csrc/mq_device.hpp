@@ -486,6 +486,7 @@ struct MapSink {
     bool c_open = false;  // a run is open across the batch boundary; M holds it so far
     MatchRec M = {};
     uint32_t c_hit = 0, c_id = 0, c_off = 0, c_sigma = 0;  // last element of the previous batch
+    uint32_t probe_steps = 0;  // per lane: slots visited beyond the home slot (diagnostic: mean probes per lookup)
 
     __device__ MapSink(const Slot *t, uint64_t m, const DevParams &p, MatchRec *s, uint32_t cap, mq_kminmer *d, uint32_t dc)
         : table(t), mask(m), P(p), scratch(s), cap_matches(cap), dump(d), dump_cap(dc) {}
@@ -509,7 +510,7 @@ struct MapSink {
         return table[key == 0 ? mask + 1 : (key & mask)].key;
     }
     // ReadOnlyIndex::get (src/index.rs:118-126) continuing from an already loaded home-slot key
-    __device__ __forceinline__ bool probe_resolve(uint64_t key, unsigned long long k0, Slot &out) const {
+    __device__ __forceinline__ bool probe_resolve(uint64_t key, unsigned long long k0, Slot &out) {
         if (key == 0) {
             out = table[mask + 1];
             return out.count == 1 && out.end != 0;
@@ -523,6 +524,7 @@ struct MapSink {
             if (k0 == 0) return false;
             s = (s + 1) & mask;
             k0 = table[s].key;
+            probe_steps++;
         }
     }
 

@@ -24,6 +24,7 @@ torch.cuda.synchronize()
 cyc = ix.last_stage_cycles().astype(np.float64)
 names_ = ["A decode+HPC", "B rolling hash", "C gather+consume", "finish", "chain", "wave total"]
 print("kernel ms (instrumented):", ix.last_map_ms())
-for n_, c in zip(names_, cyc):
+for n_, c in zip(names_, cyc[:6]):
     print("%-18s %14.0f cycles  %5.1f %% of wave total" % (n_, c, 100 * c / cyc[5]))
 print("other (work pull, epilogue): %.1f %%" % (100 * (cyc[5] - cyc[:5].sum()) / cyc[5]))
+print("index lookups %d, extra probe steps %d -> mean probes per lookup %.3f" % (cyc[7], cyc[6], 1 + cyc[6] / max(cyc[7], 1)))
