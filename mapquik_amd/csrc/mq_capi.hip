@@ -559,7 +559,10 @@ int64_t mq_index_finalize(mq_index *idx) {
     int rc = use_device(idx);
     if (rc) return rc;
     uint64_t nslots = 1024;
-    while (nslots < 2 * idx->n_kmm_total) nslots <<= 1;
+    const char *lf = getenv("MQ_TABLE_FACTOR");  // slots per inserted k-min-mer (power-of-two rounding on top); default 4 => load <= 0.25:
+    // ~85 % of a read's lookups miss, a miss walks to the first empty slot, and every extra step is a dependent 128-B line fill
+    const uint64_t factor = lf && atoi(lf) >= 1 ? (uint64_t)atoi(lf) : 4ull;
+    while (nslots < factor * idx->n_kmm_total) nslots <<= 1;
     rc = alloc_table(idx, nslots);
     if (rc) return rc;
     for (auto &c : idx->chunks) {
