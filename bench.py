@@ -34,6 +34,10 @@ def parse():
     ap.add_argument("--reads", type=int, default=49152, help="reads per step per GPU")
     ap.add_argument("--genome-scale", type=float, default=1.0, help="1.0 = CHM13-like 3.117 Gbp")
     ap.add_argument("--seed", type=int, default=2013)
+    ap.add_argument("--repeat-frac", type=float, default=0.05, help="fraction of the genome overwritten by copied 1-20 kb segments "
+                    "(0.8 = maize-like stress: most k-min-mers are tombstoned, lookups miss, Matches are short)")
+    ap.add_argument("--tandem-frac", type=float, default=0.01)
+    ap.add_argument("--repeat-div", type=float, default=0.01, help="per-base divergence of the planted copies")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     return ap.parse_args()
@@ -81,7 +85,8 @@ def main():
     # ---- genome (same on every rank: the index is replicated)
     t0 = time.time()
     lens = [max(40, int(x * args.genome_scale)) for x in sim.CHM13_LIKE]
-    genome, ctg_off, ctg_names = sim.make_genome(lens, seed=args.seed, threads=threads, repeat_frac=0.05, tandem_frac=0.01, div=0.01)
+    genome, ctg_off, ctg_names = sim.make_genome(lens, seed=args.seed, threads=threads, repeat_frac=args.repeat_frac,
+                                                 tandem_frac=args.tandem_frac, div=args.repeat_div)
     t_genome = time.time() - t0
 
     # ---- index on this rank's GPU (Index::add_with_mer + into_read_only on device)
@@ -219,8 +224,9 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": "CHM13v2.0-like synthetic genome (25 contigs, %.3f Gbp, scale %.3g, 5%% planted repeats) "
-                            "x pbsim-like HiFi reads (mean 24 kb, 1%% error); k=5 l=31 d=0.01 HPC" % (st and sum(lens) / 1e9, args.genome_scale),
+                "workload": "CHM13v2.0-like synthetic genome (25 contigs, %.3f Gbp, scale %.3g, %g%% planted repeats) "
+                            "x pbsim-like HiFi reads (mean 24 kb, 1%% error); k=5 l=31 d=0.01 HPC"
+                            % (sum(lens) / 1e9, args.genome_scale, 100 * args.repeat_frac),
                 "reads_per_step_per_gpu": n,
                 "bases_per_step_per_gpu": total_bases,
                 "index_unique_kminmers": int(n_unique),
