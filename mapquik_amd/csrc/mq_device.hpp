@@ -1,7 +1,9 @@
 // mq_device.hpp -- gfx950 device code for mapquik's hot path (seeding, index probe, Match runs, pseudo-chain).
 //
 // One wavefront (64 lanes) owns one sequence (or one segment of a long reference).  Everything is
-// integer / byte work: no MFMA.  Structure of the streaming seeder (lanes = consecutive positions):
+// integer / byte work: no MFMA.  This header holds the GENERAL streaming seeder (any length, any bytes; the fast path for
+// ACGT-only sequences is mq_fast.hpp), the index probe, the Match-run builder and the chain stage.
+// Structure of the streaming seeder (lanes = consecutive positions):
 //   raw bytes --(head flags, ballot/mbcnt compaction)--> HPC ring in LDS --(64-wide XOR prefix scan of
 //   rotated ntHash seeds)--> canonical l-mer hashes --(density predicate, ballot compaction)--> ordered
 //   minimizer list in LDS --> sink (k-min-mers -> probe -> runs, or a global minimizer list).
@@ -11,9 +13,9 @@
 // (all rotation amounts mod 64; blocks of 64 HPC positions are 64-aligned so amounts are lane constants).
 //
 // Reference semantics restated here (citations relative to the reference tree):
-//   KminmersIterator (rust-seq2kminmers, call sites src/mers.rs:27,53)   -> seed_segment + MapSink::consume
+//   KminmersIterator (rust-seq2kminmers, call sites src/mers.rs:27,53)   -> seed_segment / fast_seed_sequence + kminmer_hash
 //   ReadOnlyIndex::get (src/index.rs:118-126)                           -> probe_table
-//   Match::new/update/check/extend (src/match.rs:20-58), chain_matches (src/mers.rs:57-73) -> MapSink::runs
+//   Match::new/update/check/extend (src/match.rs:20-58), chain_matches (src/mers.rs:57-73) -> MapSink::batch_runs
 //   Chain::get_match (src/chain.rs:147-169) and helpers                  -> chain_stage
 //   find_largest_two_chains/determine_best_match/find_coords (src/mers.rs:104-183) -> chain_stage
 #pragma once

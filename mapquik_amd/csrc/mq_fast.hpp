@@ -1,16 +1,18 @@
 // mq_fast.hpp -- the fast seeding path (ACGT-only sequences; long ones are cut into LDS tiles).
 //
-//   stage A  lanes own 16 consecutive raw bases (one 16-B load each, 1 KiB per wave row):
-//            SWAR decode ASCII -> 2-bit codes, validity check with v_perm_b32, homopolymer compression through a
-//            1024-entry LDS look-up (index = previous code + 4 codes), wave prefix sum, ds_or of the packed bits into
-//            the tile's code stream in LDS.  By-products: HPC count at every 64-base block (LDS) and the run-head
-//            bit mask (HBM scratch, read back only for the ~2 % selected positions).
-//   stage B  lanes own contiguous chunks of HPC positions and ROLL ntHash over them:
+//   stage A  super-rows of 4096 raw bases, every lane owns one 64-base block (four 16-B loads, the next super-row's four
+//            already in flight): SWAR decode ASCII -> 2-bit codes (OR-merge + 4x4 transpose of 2-bit elements), validity
+//            check with v_perm_b32, homopolymer compression through a 1024-entry LDS look-up (index = previous code +
+//            4 codes), one wave prefix sum per super-row, ds_or of the packed bits into the tile's code stream in LDS.
+//            By-products: compressed count at every 64-base block (LDS) and the run-head bit masks (HBM scratch, read
+//            back only for the ~2 % selected positions).
+//   stage B  lanes own contiguous chunks of compressed positions and ROLL ntHash over them:
 //            fh' = rol(fh,1) ^ rol(h(out),l) ^ h(in),  rh' = ror(rh,1) ^ ror(hc(out),1) ^ rol(hc(in),l-1)
-//            with one 16-entry LDS table indexed by (out,in) -> one ds_read_b128 per step.  Selected l-mers go to a
-//            per-lane list in HBM scratch (worst-case sized: no overflow path).
-//   stage C  64 minimizers at a time, in order: locate (lane, slot) by binary search over the lane prefix sums, fetch,
-//            map the HPC index back to the raw position (block search + select on the head mask), hand to the sink.
+//            with one 16-entry LDS table indexed by (out,in) -> one ds_read_b128 per step, four look-ups in flight.
+//            Selected l-mers are appended (ballot + mbcnt) to one dense per-wave list in HBM scratch, tagged (slot, lane).
+//   stage C  the code stream is dead, its LDS becomes the ordered minimizer list: a record of lane L, slot e belongs at
+//            lane_prefix[L] + e; raw position = block search in the per-block counts + select on the head mask; then the
+//            sink hashes every k-min-mer, issues all home-slot probes together and runs the Match-run logic per 64.
 // A sequence longer than one tile (32,768 bases / 20,480 compressed bases) is processed tile by tile: the last l-1
 // compressed bases (codes + raw positions) and the last k-1 minimizers carry over.  Sequences with a non-ACGT byte take the
 // general streaming path in mq_device.hpp.
