@@ -32,7 +32,7 @@ def build_cli(force=False, verbose=False):
     build(force=False, verbose=verbose)
     if not force and os.path.exists(CLI) and all(os.path.getmtime(CLI) >= os.path.getmtime(d) for d in CLI_DEPS + [LIB]):
         return CLI
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI, CLI_DEPS[0], "-L" + LIBDIR, "-lmapquik_hip", "-lz",
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI, CLI_DEPS[0], "-L" + LIBDIR, "-lmapquik_hip", "-lz", "-lpthread",
            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + "/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))

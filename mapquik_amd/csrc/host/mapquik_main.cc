@@ -8,7 +8,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <sys/resource.h>
@@ -148,6 +154,7 @@ struct Opt {
     long k = -1, l = -1, c = -1, s = -1, g = -1, threads = -1, b = -1, q = -1;
     double density = -1;
     int device = 0;
+    int gpus = 1;
     unsigned long long batch_bases = 1ull << 30;
 };
 
@@ -157,7 +164,7 @@ static void usage() {
          "        --parallelfastx\n        --unmapped      (extension) also write <prefix>.unmapped.out\n\nOPTIONS:\n"
          "    -b <b>\n    -c, --chain <chain>\n    -d, --density <density>\n    -g, --gap-diff <gap-diff>\n    -k <k>\n    -l <l>\n"
          "    -p, --prefix <prefix>\n    -q <q>\n        --reference <reference>\n    -s, --seed <seed>\n        --threads <threads>\n"
-         "        --device <n>    (extension) HIP device ordinal\n        --batch-bases <n> (extension)\n\nARGS:\n    <reads>");
+         "        --device <n>    (extension) first HIP device ordinal\n        --gpus <n>      (extension) shard read batches over n GPUs, index replicated\n        --batch-bases <n> (extension)\n\nARGS:\n    <reads>");
 }
 
 int main(int argc, char **argv) {
@@ -188,6 +195,7 @@ int main(int argc, char **argv) {
         else if (a == "-b") o.b = atol(val());
         else if (a == "-q") o.q = atol(val());
         else if (a == "--device") o.device = atoi(val());
+        else if (a == "--gpus") o.gpus = std::max(1, atoi(val()));
         else if (a == "--batch-bases") o.batch_bases = strtoull(val(), nullptr, 10);
         else if (!a.empty() && a[0] == '-') { fprintf(stderr, "error: Found argument '%s' which wasn't expected\n", a.c_str()); return 2; }
         else o.reads = a;
@@ -224,39 +232,132 @@ int main(int argc, char **argv) {
         if (!paf) { fprintf(stderr, "Couldn't create %s.paf\n", prefix.c_str()); return 101; }
         FILE *unm = o.unmapped ? fopen((prefix + ".unmapped.out").c_str(), "w") : nullptr;
 
+        // --gpus N: the index is replicated (every GPU indexes the same reference), read batches are dealt round-robin,
+        // PAF lines are written in batch order = input order.  No collective: reads are independent.
+        const int n_dev = mq_device_count();
+        const bool fake = getenv("MQ_FAKE_MULTI") != nullptr;  // test hook: several workers on one device
+        if (!fake && o.device + o.gpus > n_dev && n_dev > 0) {
+            fprintf(stderr, "mapquik: --gpus %d from device %d needs %d devices, %d visible\n", o.gpus, o.device, o.device + o.gpus, n_dev);
+            return 101;
+        }
+        auto dev_of = [&](int g) { return fake && n_dev > 0 ? (o.device + g) % n_dev : o.device + g; };
+
         auto t0 = Clock::now();
-        Index index(P, o.device);
-        size_t ref_i = 0;
-        read_fastx(o.reference, ref_fasta, [&](const std::string &id, const std::string &seq) {
-            const size_t n = mers::ref_extract(ref_i++, id, (const uint8_t *)seq.data(), seq.size(), P, index);
-            printf("Indexed reference %s: %zu k-min-mers.\n", id.c_str(), n);  // src/closures.rs:58
-        });
-        ReadOnlyIndex ro = std::move(index).into_read_only();
-        printf("Indexed %llu unique k-min-mers in %s.\n", (unsigned long long)ro.unique_count(), rust_duration(secs(t0)).c_str());
+        std::vector<std::pair<std::string, std::string>> refs;
+        read_fastx(o.reference, ref_fasta, [&](const std::string &id, const std::string &seq) { refs.emplace_back(id, seq); });
+        std::vector<std::unique_ptr<ReadOnlyIndex>> ro((size_t)o.gpus);
+        std::vector<std::vector<size_t>> counts((size_t)o.gpus);
+        std::vector<std::string> errs((size_t)o.gpus);
+        {
+            std::vector<std::thread> th;
+            for (int g = 0; g < o.gpus; ++g)
+                th.emplace_back([&, g]() {
+                    try {
+                        Index index(P, dev_of(g));
+                        for (size_t r = 0; r < refs.size(); ++r)
+                            counts[g].push_back(mers::ref_extract(r, refs[r].first, (const uint8_t *)refs[r].second.data(), refs[r].second.size(), P, index));
+                        ro[g].reset(new ReadOnlyIndex(std::move(index).into_read_only()));
+                    } catch (const Error &e) { errs[g] = e.what(); }
+                });
+            for (auto &t : th) t.join();
+        }
+        for (auto &e : errs) if (!e.empty()) throw Error(e);
+        for (size_t r = 0; r < refs.size(); ++r) printf("Indexed reference %s: %zu k-min-mers.\n", refs[r].first.c_str(), counts[0][r]);  // src/closures.rs:58
+        refs.clear();
+        refs.shrink_to_fit();
+        printf("Indexed %llu unique k-min-mers in %s.\n", (unsigned long long)ro[0]->unique_count(), rust_duration(secs(t0)).c_str());
 
         t0 = Clock::now();
         if (P.use_pfx && !ends_with(o.reads, ".gz") && !ends_with(o.reads, ".lz4")) puts("Warning: using experimental rust-parallelfastx (exciting!)");
-        std::vector<std::string> ids;
-        std::string bases;
-        std::vector<uint64_t> offs(1, 0);
-        auto flush = [&]() {
-            if (ids.empty()) return;
-            auto res = mers::find_matches_batch(ids, (const uint8_t *)bases.data(), offs, ro, P);
-            for (size_t i = 0; i < res.size(); ++i) {
-                if (res[i]) fprintf(paf, "%s\n", res[i]->c_str());  // main_thread_mer, input order (src/closures.rs:117-123)
-                else if (unm) fprintf(unm, "%s\n", ids[i].c_str());
+        struct Batch {
+            size_t seq_no = 0;
+            std::vector<std::string> ids;
+            std::string bases;
+            std::vector<uint64_t> offs{0};
+            std::vector<std::optional<std::string>> res;
+        };
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<std::unique_ptr<Batch>> todo;            // parsed, waiting for a GPU
+        std::map<size_t, std::unique_ptr<Batch>> done;      // mapped, waiting for their turn in the output
+        bool eof = false;
+        std::string werr;
+        std::vector<std::thread> workers;
+        for (int g = 0; g < o.gpus; ++g)
+            workers.emplace_back([&, g]() {
+                for (;;) {
+                    std::unique_ptr<Batch> bt;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return !todo.empty() || eof; });
+                        if (todo.empty()) return;
+                        bt = std::move(todo.front());
+                        todo.pop_front();
+                    }
+                    cv.notify_all();
+                    try {
+                        bt->res = mers::find_matches_batch(bt->ids, (const uint8_t *)bt->bases.data(), bt->offs, *ro[g], P);
+                    } catch (const Error &e) {
+                        std::lock_guard<std::mutex> lk(mu);
+                        werr = e.what();
+                    }
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        const size_t k = bt->seq_no;
+                        done[k] = std::move(bt);
+                    }
+                    cv.notify_all();
+                }
+            });
+        size_t next_out = 0, n_batches = 0;
+        auto drain = [&](bool all) {  // main thread writes in input order (main_thread_mer, src/closures.rs:117-123)
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                auto it = done.find(next_out);
+                if (it == done.end()) {
+                    if (!all || next_out >= n_batches) return;
+                    cv.wait(lk, [&] { return done.count(next_out) != 0; });
+                    continue;
+                }
+                std::unique_ptr<Batch> bt = std::move(it->second);
+                done.erase(it);
+                lk.unlock();
+                for (size_t i = 0; i < bt->res.size(); ++i) {
+                    if (bt->res[i]) fprintf(paf, "%s\n", bt->res[i]->c_str());
+                    else if (unm) fprintf(unm, "%s\n", bt->ids[i].c_str());
+                }
+                ++next_out;
+                lk.lock();
             }
-            ids.clear();
-            bases.clear();
-            offs.assign(1, 0);
+        };
+        std::unique_ptr<Batch> cur(new Batch());
+        auto submit = [&]() {
+            if (cur->ids.empty()) return;
+            cur->seq_no = n_batches++;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return todo.size() < (size_t)(2 * o.gpus); });  // bounded queue (the reference's -q idea)
+                todo.push_back(std::move(cur));
+            }
+            cv.notify_all();
+            cur.reset(new Batch());
+            drain(false);
         };
         read_fastx(o.reads, reads_fasta, [&](const std::string &id, const std::string &seq) {
-            ids.push_back(id);
-            bases += seq;
-            offs.push_back(bases.size());
-            if (bases.size() >= o.batch_bases) flush();
+            cur->ids.push_back(id);
+            cur->bases += seq;
+            cur->offs.push_back(cur->bases.size());
+            if (cur->bases.size() >= o.batch_bases) submit();
         });
-        flush();
+        submit();
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            eof = true;
+        }
+        cv.notify_all();
+        drain(true);
+        for (auto &t : workers) t.join();
+        if (!werr.empty()) throw Error(werr);
         fclose(paf);
         if (unm) fclose(unm);
         printf("Mapped query sequences in %s.\n", rust_duration(secs(t0)).c_str());  // src/closures.rs:211

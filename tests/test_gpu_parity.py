@@ -383,6 +383,15 @@ def test_native_cli_end_to_end_paf_identical(mq, oracle, simlib, tmp_path):
     r = subprocess.run([exe, str(rd), "--reference", str(ref), "-p", prefix, "--batch-bases", "500000", "--unmapped"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    # --gpus 3 on this 1-GPU box through the test hook: three workers with their own index replica, batches dealt round-robin,
+    # output still in input order and byte-identical
+    env = dict(os.environ, MQ_FAKE_MULTI="1")
+    r3 = subprocess.run([exe, str(rd), "--reference", str(ref), "-p", prefix + "3", "--batch-bases", "150000", "--gpus", "3"],
+                        capture_output=True, text=True, env=env)
+    assert r3.returncode == 0, r3.stderr
+    assert open(prefix + "3.paf").read() == open(prefix + ".paf").read()
+    r9 = subprocess.run([exe, str(rd), "--reference", str(ref), "-p", prefix + "9", "--gpus", "9"], capture_output=True, text=True)
+    assert r9.returncode == 101 and "devices" in r9.stderr
     po = oracle.params()
     ox = oracle.Index()
     for k in range(2):
