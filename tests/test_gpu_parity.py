@@ -446,3 +446,34 @@ def test_fuzz_params_and_sequences(mq, oracle, simlib):
             s = bases[int(offs[i]):int(offs[i + 1])]
             w = oracle.kminmers(s, po) if s.size >= po.l + po.k - 1 else np.zeros(0, dtype=oracle.kminmer_dtype)
             _cmp_kmm(got[i], w, (it, ps, i))
+
+
+def test_no_device_memory_growth(mq, simlib):
+    """Creating/freeing indexes and mapping repeatedly must not leak device memory."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    g, off, names = simlib.make_genome([300000], seed=3)
+    reads = simlib.make_reads(g, off, 64, seed=4, len_mean=8000)
+
+    def cycle():
+        ix = mq.Index(mq.Params())
+        ix.add_ref(0, names[0], g)
+        ix.finalize()
+        for _ in range(5):
+            ix.map_batch(reads["bases"], reads["offsets"])
+        ix.kminmers_batch(reads["bases"], reads["offsets"])
+        ix.close()
+
+    cycle()
+    before = free_bytes()
+    for _ in range(6):
+        cycle()
+    after = free_bytes()
+    assert before - after < (64 << 20), (before, after)
