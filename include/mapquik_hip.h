@@ -153,8 +153,8 @@ int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general
 
 /* Diagnostic builds only (env MQ_STAGE_TIMING=1 selects an instrumented kernel; its run time is never a reported number):
  * shader-clock cycles summed over all waves of the last launch in {stage A, stage B, stage C + consume, finish, chain, whole wave},
- * then {index slots visited beyond the home slot, index lookups}. */
-int mq_last_stage_cycles(mq_index *idx, uint64_t *cycles8);
+ * then {index slots visited beyond the home slot, index lookups, 100-MHz real-time ticks summed over waves}: nine values. */
+int mq_last_stage_cycles(mq_index *idx, uint64_t *cycles9);
 
 /* Measurement aid: one instrumented (slower, never timed) launch of the same batch that counts index lookups and the slots
  * visited beyond each lookup's home slot: mean probes per lookup = 1 + extra_steps / lookups (SURVEY 8d's p-bar). */

@@ -234,7 +234,7 @@ class Index:
 
     def last_stage_cycles(self):
         """Diagnostic (MQ_STAGE_TIMING=1): cycles summed over waves in [A, B, C+consume, finish, chain, total]."""
-        v = np.zeros(8, dtype=np.uint64)
+        v = np.zeros(9, dtype=np.uint64)
         if self._L.mq_last_stage_cycles(self._h, _p(v)) != 0:
             raise _err(self._L, "mq_last_stage_cycles")
         return v

@@ -60,8 +60,9 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MIN_WAVES) void map_kernel(const
     uint32_t *hm = reinterpret_cast<uint32_t *>(fs + FAST_EM_BYTES);
     const DevParams &P = A.P;
     uint32_t n_fast = 0, n_general = 0;
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostic build only: cycles in A, B, C(+consume), finish, chain, total; extra probe steps; lookups
+    unsigned long long tacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // diagnostic build only: cycles in A, B, C(+consume), finish, chain, total; extra probe steps; lookups
     const unsigned long long t_begin = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long r_begin = TIMING ? __builtin_amdgcn_s_memrealtime() : 0ull;  // 100 MHz
     for (;;) {
         uint32_t r = 0;
         if (lane == 0) r = atomicAdd(A.work_counter, 1u);
@@ -120,8 +121,9 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MIN_WAVES) void map_kernel(const
         if (n_general) atomicAdd(&A.stats[1], n_general);
         if (TIMING) {
             tacc[5] = __builtin_amdgcn_s_memtime() - t_begin;
+            tacc[8] = __builtin_amdgcn_s_memrealtime() - r_begin;
             unsigned long long *ts = reinterpret_cast<unsigned long long *>(A.stats + 2);
-            for (int i = 0; i < 8; ++i) atomicAdd(&ts[i], tacc[i]);
+            for (int i = 0; i < 9; ++i) atomicAdd(&ts[i], tacc[i]);
         }
     }
 }
@@ -970,13 +972,13 @@ int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general
     return MQ_OK;
 }
 
-int mq_last_stage_cycles(mq_index *idx, uint64_t *cycles8) {
-    if (!idx || !cycles8) return set_err(MQ_EINVAL, "bad arguments");
+int mq_last_stage_cycles(mq_index *idx, uint64_t *cycles9) {
+    if (!idx || !cycles9) return set_err(MQ_EINVAL, "bad arguments");
     if (!idx->ev_valid) return set_err(MQ_ESTATE, "no map launch recorded");
     int rc = use_device(idx);
     if (rc) return rc;
     HIPCHK(hipEventSynchronize(idx->ev1));
-    HIPCHK(hipMemcpy(cycles8, idx->d_counter + 4, 64, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cycles9, idx->d_counter + 4, 72, hipMemcpyDeviceToHost));
     return MQ_OK;
 }
 
@@ -987,7 +989,7 @@ int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_
     int rc = mq_map_batch_device(idx, d_bases, d_offsets, n, max_len, d_out, nullptr);
     idx->timing_once = false;
     if (rc) return rc;
-    uint64_t v[8];
+    uint64_t v[9];
     rc = mq_last_stage_cycles(idx, v);
     if (rc) return rc;
     *extra_steps = v[6];

@@ -27,4 +27,5 @@ print("kernel ms (instrumented):", ix.last_map_ms())
 for n_, c in zip(names_, cyc[:6]):
     print("%-18s %14.0f cycles  %5.1f %% of wave total" % (n_, c, 100 * c / cyc[5]))
 print("other (work pull, epilogue): %.1f %%" % (100 * (cyc[5] - cyc[:5].sum()) / cyc[5]))
+print("in-kernel clock (s_memtime / s_memrealtime x 100 MHz): %.3f GHz" % (cyc[5] / max(cyc[8], 1) * 0.1))
 print("index lookups %d, extra probe steps %d -> mean probes per lookup %.3f" % (cyc[7], cyc[6], 1 + cyc[6] / max(cyc[7], 1)))
