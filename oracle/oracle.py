@@ -19,7 +19,7 @@ def build(force=False):
     if not force and os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in src):
         return _LIB
     subprocess.check_call(
-        ["gcc", "-O3", "-march=native", "-std=c11", "-fPIC", "-shared", "-o", _LIB, src[0], "-lpthread"], cwd=_HERE
+        ["gcc", "-O3", "-march=x86-64-v3", "-std=c11", "-fPIC", "-shared", "-o", _LIB, src[0], "-lpthread"], cwd=_HERE
     )
     return _LIB
 
