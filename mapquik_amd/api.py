@@ -289,11 +289,15 @@ class Index:
     def format_paf(self, q_id, q_len, hit):
         rec = np.zeros(1, dtype=hit_dtype)
         rec[0] = hit
-        buf = C.create_string_buffer(4096)
-        w = self._L.mq_format_paf(self._h, q_id.encode(), int(q_len), _p(rec), buf, 4096)
-        if w < 0:
-            raise _err(self._L, "mq_format_paf")
-        return buf.value.decode()
+        cap = 4096
+        while True:
+            buf = C.create_string_buffer(cap)
+            w = self._L.mq_format_paf(self._h, q_id.encode(), int(q_len), _p(rec), buf, cap)
+            if w < 0:
+                raise _err(self._L, "mq_format_paf")
+            if w < cap:  # the return value is the full line length (snprintf): never hand back a cut line
+                return buf.value.decode()
+            cap = w + 1
 
     def paf_lines(self, names, offsets, hits):
         """PAF text in input order; unmapped reads produce no line (src/closures.rs:117-123)."""

@@ -11,7 +11,14 @@ CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmapquik_hip.so")
 SOURCES = [os.path.join(CSRC, "mq_capi.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "mq_device.hpp"), os.path.join(os.path.dirname(_HERE), "include", "mapquik_hip.h")]
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+
+def _deps():
+    """Every file the library is compiled from: csrc/*.hip, csrc/*.hpp, include/*.h (a stale .so would make parity and
+    perf numbers describe an old kernel)."""
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(INCLUDE, "*.h")))
 
 
 def hipcc():
@@ -23,16 +30,20 @@ def hipcc():
 
 HOST_DIR = os.path.join(CSRC, "host")
 CLI = os.path.join(LIBDIR, "mapquik")
-CLI_DEPS = [os.path.join(HOST_DIR, "mapquik_main.cc"), os.path.join(HOST_DIR, "mapquik_host.hpp"),
-            os.path.join(os.path.dirname(_HERE), "include", "mapquik_hip.h")]
+CLI_SRC = os.path.join(HOST_DIR, "mapquik_main.cc")
+
+
+def _cli_deps():
+    import glob
+    return sorted(glob.glob(os.path.join(HOST_DIR, "*.cc")) + glob.glob(os.path.join(HOST_DIR, "*.hpp")) + glob.glob(os.path.join(INCLUDE, "*.h")))
 
 
 def build_cli(force=False, verbose=False):
     """The native `mapquik` driver (C++ host mirror over the C ABI): g++ -lz, linked against the in-tree library."""
     build(force=False, verbose=verbose)
-    if not force and os.path.exists(CLI) and all(os.path.getmtime(CLI) >= os.path.getmtime(d) for d in CLI_DEPS + [LIB]):
+    if not force and os.path.exists(CLI) and all(os.path.getmtime(CLI) >= os.path.getmtime(d) for d in _cli_deps() + [LIB]):
         return CLI
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI, CLI_DEPS[0], "-L" + LIBDIR, "-lmapquik_hip", "-lz", "-lpthread",
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI, CLI_SRC, "-L" + LIBDIR, "-lmapquik_hip", "-lz", "-lpthread",
            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + "/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
@@ -41,7 +52,7 @@ def build_cli(force=False, verbose=False):
 
 
 def is_fresh():
-    return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS)
+    return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in _deps())
 
 
 def build(force=False, verbose=False):

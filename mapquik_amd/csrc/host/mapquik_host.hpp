@@ -127,12 +127,16 @@ inline std::vector<std::optional<std::string>> find_matches_batch(const std::vec
     if (!n) return out;
     std::vector<mq_hit> hits(n);
     if (mq_map_batch(mers_index.handle(), bases, offsets.data(), n, hits.data()) != MQ_OK) throw Error("find_matches: " + last_error());
-    char buf[4096];
+    std::vector<char> buf(4096);
     for (uint32_t i = 0; i < n; ++i) {
         if (hits[i].status == MQ_HIT_MAPPED) {
-            const int w = mq_format_paf(mers_index.handle(), q_ids[i].c_str(), offsets[i + 1] - offsets[i], &hits[i], buf, sizeof(buf));
+            int w = mq_format_paf(mers_index.handle(), q_ids[i].c_str(), offsets[i + 1] - offsets[i], &hits[i], buf.data(), buf.size());
+            if (w >= (int)buf.size()) {  // long read / contig names: the return value is the full length, format again
+                buf.resize((size_t)w + 1);
+                w = mq_format_paf(mers_index.handle(), q_ids[i].c_str(), offsets[i + 1] - offsets[i], &hits[i], buf.data(), buf.size());
+            }
             if (w < 0) throw Error("find_coords: " + last_error());
-            out[i] = std::string(buf, (size_t)std::min<int>(w, (int)sizeof(buf) - 1));
+            out[i] = std::string(buf.data(), (size_t)w);
         } else if (hits[i].status != MQ_HIT_UNMAPPED) {
             throw Error("find_matches: read " + q_ids[i] + " could not be processed");
         }

@@ -1,0 +1,472 @@
+// mq_seed.hpp -- the seed kernel's fast path: an ACGT-only sequence -> its ordered minimizer list (hash, raw position) in HBM.
+//
+// One wave per sequence, tile by tile (8192 raw bases = two super-rows of 64 bases per lane); per-wave LDS 5.9 KB so that 24
+// waves (6 per SIMD) share a CU.  Everything lives in LDS between the stages; nothing but the final list goes to HBM.
+//   stage A  decode + homopolymer compression: SWAR ASCII -> 2-bit codes (OR-merge + 4x4 transpose of 2-bit elements),
+//            validity by v_perm_b32 reconstruction, a 1024-entry LDS look-up (previous code + 4 codes -> compacted codes,
+//            count, run-head bits), one DPP prefix sum per super-row, ds_or of the packed codes into the tile's code stream.
+//            By-products kept in LDS: run-head bit mask (1 bit per raw base) and the compressed count at every 64-base block.
+//   stage B  lanes own contiguous chunks of ceil(windows / 64) compressed positions and ROLL ntHash over them:
+//            fh' = rol(fh,1) ^ rol(h(out),l) ^ h(in),  rh' = ror(rh,1) ^ ror(hc(out),1) ^ rol(hc(in),l-1)
+//            with one 16-entry LDS table indexed by (out,in) -> one ds_read_b128 per step, four look-ups in flight.
+//            The per-step test is min(fh.hi, rh.hi) <= hi(bound); candidates are appended (ballot + mbcnt) to a dense LDS
+//            list {hash, j | lane | slot}; a list that outgrows LDS continues in a per-wave HBM spill area.
+//   stage R  lane = candidate: exact 64-bit test, its place in position order (lane_prefix[lane] + slot), raw position =
+//            block search in the per-block counts + select on the 64-bit head mask, then {hash, pos} go to the
+//            sequence's region of the minimizer buffer.
+// A sequence with a byte other than A C G T (or a candidate that passes the high-word test but not the exact one) is
+// handed to the general streaming seeder (mq_device.hpp) through a queue; both produce the same list.
+#pragma once
+#include "mq_device.hpp"
+
+namespace mq {
+
+constexpr uint32_t SD_SR_RAW = 4096;                       // raw bases per super-row: 64 per lane
+constexpr uint32_t SD_MAX_SR = 2;                          // super-rows per tile
+constexpr uint32_t SD_TILE_RAW = SD_SR_RAW * SD_MAX_SR;    // 8192
+constexpr uint32_t SD_BLOCKS = SD_TILE_RAW / 64;           // 64-base blocks per tile
+constexpr uint32_t SD_CODES_MAX = SD_TILE_RAW + MAX_L - 1; // codes of one tile incl. the carried l-1 (no compression at all)
+constexpr uint32_t SD_LC_MAX = (SD_CODES_MAX + 63) / 64;   // windows per lane
+constexpr uint32_t SD_CODES_DW = 528;                      // packed 2-bit codes + zero read-ahead padding
+constexpr uint32_t SD_CAND_CAP = 176;                      // candidates of one tile kept in LDS (expected ~125); the rest spill
+constexpr uint32_t SD_SPILL_CAP = SD_CODES_MAX;            // per-wave HBM spill records (16 B each): every window a candidate
+static_assert((63 * SD_LC_MAX + 16 * ((SD_LC_MAX + 15) / 16) + MAX_L + 32) / 16 < SD_CODES_DW, "code stream read-ahead padding");
+static_assert(SD_CODES_MAX < (1u << 16) && SD_LC_MAX < 256, "tag packing: j 16 bits | lane 6 bits | slot 8 bits");
+
+// workgroup-shared look-up tables (built once per workgroup)
+struct SeedTables {
+    uint4 roll[16];      // index out | in<<2 : {rol(h(out),l)^h(in) lo,hi ; ror(hc(out),1)^rol(hc(in),l-1) lo,hi}
+    uint4 warm[4];       // index code        : {h(c) lo,hi ; rol(hc(c),l-1) lo,hi}
+    uint16_t lut[1024];  // index prev | c0<<2 | c1<<4 | c2<<6 | c3<<8 : compacted codes (8 bits) | 2*count << 8 | head bits << 12
+};
+
+// per-wave LDS of the seed kernel's fast path
+struct SeedLds {
+    uint32_t codes[SD_CODES_DW];                 // the tile's 2-bit code stream (carried l-1 codes first)
+    unsigned long long heads[SD_BLOCKS];         // bit b of heads[k]: raw base 64k + b of the tile is a run head
+    uint16_t cnt[SD_BLOCKS + 4];                 // index in the code stream of block k's first run head; cnt[n_blocks] = n_codes
+    unsigned long long cand_hash[SD_CAND_CAP];   // stage B's dense candidate list (emission order)
+    uint32_t cand_tag[SD_CAND_CAP];              // j | lane << 16 | slot << 22
+    uint32_t carry_codes[4];                     // codes carried into the next tile (<= 63)
+    uint32_t carry_pos[64];                      // their raw positions
+    uint16_t lane_prefix[66];                    // exclusive prefix of the lanes' candidate counts
+};
+
+// 2-bit code = (ASCII >> 1) & 3 : A=0 C=1 T=2 G=3 ; complement = code ^ 2
+__device__ __forceinline__ uint64_t seed_of(uint32_t code) {
+    return code == 0 ? 0x3c8bfbb395c60474ULL : code == 1 ? 0x3193c18562a02b4cULL : code == 2 ? 0x295549f54be24456ULL : 0x20323ed082572324ULL;
+}
+
+__device__ __forceinline__ void build_seed_tables(SeedTables &T, uint32_t l) {
+    for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) {
+        uint32_t prev = i & 3u, out = 0, n = 0, hb = 0;
+        for (uint32_t m = 0; m < 4; ++m) {
+            const uint32_t c = (i >> (2 + 2 * m)) & 3u;
+            if (c != prev) {
+                out |= c << (2 * n);
+                n++;
+                hb |= 1u << m;
+            }
+            prev = c;
+        }
+        T.lut[i] = (uint16_t)(out | ((2 * n) << 8) | (hb << 12));
+    }
+    if (threadIdx.x < 16) {
+        const uint32_t o = threadIdx.x & 3u, in = threadIdx.x >> 2;
+        const uint64_t f = rotl64(seed_of(o), l) ^ seed_of(in);
+        const uint64_t r = rotr64(seed_of(o ^ 2u), 1) ^ rotl64(seed_of(in ^ 2u), l - 1u);
+        T.roll[threadIdx.x] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
+    }
+    if (threadIdx.x < 4) {
+        const uint64_t f = seed_of(threadIdx.x);
+        const uint64_t r = rotl64(seed_of(threadIdx.x ^ 2u), l - 1u);
+        T.warm[threadIdx.x] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
+    }
+}
+
+typedef uint4 __attribute__((aligned(1))) uint4_unaligned;
+
+// ------------------------------------------------------------------ DPP wave scan (no LDS crossbar: ds_bpermute costs ~24 cycles)
+// inclusive prefix sum over the 64 lanes: 4 row_shr steps inside each row of 16, then row_bcast:15 / row_bcast:31
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
+// 16 ASCII bases (four dwords masked with 0x06060606: code<<1 in every byte) -> 32 bits, code j at bits 2j..2j+1.
+// Merge the dwords so that byte b holds bases b, 4+b, 8+b, 12+b, then transpose the 4x4 matrix of 2-bit elements.
+__device__ __forceinline__ uint32_t pack16(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
+    uint32_t v = (t0 >> 1) | (t1 << 1) | (t2 << 3) | (t3 << 5);
+    uint32_t x = ((v >> 6) ^ v) & 0x00CC00CCu;
+    v ^= x ^ (x << 6);
+    x = ((v >> 12) ^ v) & 0x0000F0F0u;
+    v ^= x ^ (x << 12);
+    return v;
+}
+
+// ------------------------------------------------------------------ stage A
+// One tile: raw bases [raw0, raw_end), raw_end = min(raw0 + 8192, len); the code stream opens with carry_n carried codes.
+// prev_code0: the code before the first base of the sequence when raw0 == 0 (4 = none: the first base is a head).
+// Returns false on a byte other than A C G T.
+__device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, uint32_t len, uint32_t raw0, uint32_t carry_n,
+                                             uint32_t &carry_prev, bool use_hpc, const SeedTables &T, SeedLds &S, uint32_t &n_codes,
+                                             uint32_t &n_blocks, uint32_t &raw_end) {
+    const uint32_t lane = lane_id();
+    uint32_t n_sr = (len - raw0 + SD_SR_RAW - 1u) / SD_SR_RAW;
+    if (n_sr > SD_MAX_SR) n_sr = SD_MAX_SR;
+    const uint32_t fill = (uint32_t)seq[len - 1] * 0x01010101u;
+    // 16 bases at pos; bytes past the end repeat the last base (never a run head under HPC; masked without HPC)
+    auto load_piece = [&](uint32_t pos) -> uint4 {
+        if (pos + 16u <= len) return *reinterpret_cast<const uint4_unaligned *>(seq + pos);
+        unsigned long long lo = ((unsigned long long)fill << 32) | fill, hi = lo;
+        const uint32_t nv = pos < len ? len - pos : 0u;
+        for (uint32_t j = 0; j < nv; ++j) {
+            const unsigned long long b = seq[pos + j];
+            if (j < 8u) lo = (lo & ~(0xFFull << (8u * j))) | (b << (8u * j));
+            else hi = (hi & ~(0xFFull << (8u * (j - 8u)))) | (b << (8u * (j - 8u)));
+        }
+        return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+    };
+    uint4 nx0, nx1, nx2, nx3;
+    {
+        const uint32_t pos = raw0 + lane * 64u;
+        nx0 = load_piece(pos);
+        nx1 = load_piece(pos + 16u);
+        nx2 = load_piece(pos + 32u);
+        nx3 = load_piece(pos + 48u);
+    }
+    for (uint32_t i = lane * 4u; i < SD_CODES_DW; i += 256u) *reinterpret_cast<uint4 *>(&S.codes[i]) = make_uint4(0, 0, 0, 0);
+    wave_sync();
+    if (lane < 4u && carry_n) S.codes[lane] = S.carry_codes[lane];  // the carried codes open the stream
+    uint32_t b2 = 2u * carry_n;  // bits written so far = 2 * codes
+    uint32_t bad = 0;
+    constexpr uint32_t S1 = 0x00430041u, S0 = 0x00470054u;  // v_perm pool: selector 0,2 -> 'A','C' ; 4,6 -> 'T','G'
+    for (uint32_t sr = 0; sr < n_sr; ++sr) {
+        const uint32_t pos = raw0 + sr * SD_SR_RAW + lane * 64u;
+        const uint4 c0 = nx0, c1 = nx1, c2 = nx2, c3 = nx3;
+        if (sr + 1u < n_sr) {
+            const uint32_t np = pos + SD_SR_RAW;
+            nx0 = load_piece(np);
+            nx1 = load_piece(np + 16u);
+            nx2 = load_piece(np + 32u);
+            nx3 = load_piece(np + 48u);
+        }
+        uint32_t p[4];
+        {
+            const uint4 cc[4] = {c0, c1, c2, c3};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t t0 = cc[j].x & 0x06060606u, t1 = cc[j].y & 0x06060606u, t2 = cc[j].z & 0x06060606u, t3 = cc[j].w & 0x06060606u;
+                // reconstructs each byte iff it was A/C/G/T
+                bad |= (__builtin_amdgcn_perm(S0, S1, t0) ^ cc[j].x) | (__builtin_amdgcn_perm(S0, S1, t1) ^ cc[j].y) |
+                       (__builtin_amdgcn_perm(S0, S1, t2) ^ cc[j].z) | (__builtin_amdgcn_perm(S0, S1, t3) ^ cc[j].w);
+                p[j] = pack16(t0, t1, t2, t3);
+            }
+        }
+        uint32_t out[4], n2[4], hb[4];
+        if (use_hpc) {
+            // code of the base before this lane's block: the previous lane's last base (DPP wave_shr:1), lane 0 takes the carry
+            uint32_t pc = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(p[3] >> 30), 0x138, 0xf, 0xf, false);
+            if (lane == 0) pc = (sr == 0 && raw0 == 0) ? ((p[0] & 3u) ^ 1u) : carry_prev;  // first base of the sequence is always a head
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t q = (p[j] << 2) | pc;
+                pc = p[j] >> 30;
+                const uint32_t e0 = T.lut[q & 0x3FFu], e1 = T.lut[(q >> 8) & 0x3FFu], e2 = T.lut[(q >> 16) & 0x3FFu], e3 = T.lut[p[j] >> 22];
+                uint32_t o = e0 & 0xFFu, sh = (e0 >> 8) & 15u;
+                o |= (e1 & 0xFFu) << sh;
+                sh += (e1 >> 8) & 15u;
+                o |= (e2 & 0xFFu) << sh;
+                sh += (e2 >> 8) & 15u;
+                o |= (e3 & 0xFFu) << sh;
+                out[j] = o;
+                n2[j] = sh + ((e3 >> 8) & 15u);
+                hb[j] = (e0 >> 12) | ((e1 >> 12) << 4) | ((e2 >> 12) << 8) | ((e3 >> 12) << 12);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t pp = pos + 16u * (uint32_t)j;
+                const uint32_t nv = pp < len ? (len - pp < 16u ? len - pp : 16u) : 0u;
+                const uint32_t m = nv >= 16u ? 0xFFFFFFFFu : ((1u << (2u * nv)) - 1u);
+                out[j] = p[j] & m;
+                n2[j] = 2u * nv;
+                hb[j] = nv >= 16u ? 0xFFFFu : ((1u << nv) - 1u);
+            }
+        }
+        const uint32_t mine = n2[0] + n2[1] + n2[2] + n2[3];
+        const uint32_t incl = wave_incl_scan_u32(mine);
+        const uint32_t total = rdlane(incl, 63);
+        uint32_t bo = b2 + incl - mine;
+        S.cnt[sr * 64u + lane] = (uint16_t)(bo >> 1);
+        S.heads[sr * 64u + lane] = (unsigned long long)(hb[0] | (hb[1] << 16)) | ((unsigned long long)(hb[2] | (hb[3] << 16)) << 32);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (n2[j]) {
+                const uint32_t sh = bo & 31u;
+                atomicOr(&S.codes[bo >> 5], out[j] << sh);
+                const uint32_t hi = sh ? out[j] >> (32u - sh) : 0u;
+                if (hi) atomicOr(&S.codes[(bo >> 5) + 1u], hi);
+            }
+            bo += n2[j];
+        }
+        b2 += total;
+        carry_prev = rdlane(p[3], 63) >> 30;
+    }
+    n_blocks = n_sr * 64u;
+    raw_end = raw0 + n_sr * SD_SR_RAW < len ? raw0 + n_sr * SD_SR_RAW : len;
+    n_codes = b2 >> 1;
+    if (lane == 0) S.cnt[n_blocks] = (uint16_t)n_codes;
+    wave_sync();
+    return __ballot(bad != 0) == 0;
+}
+
+// ------------------------------------------------------------------ stage B
+struct Hash2 {
+    uint32_t flo, fhi, rlo, rhi;
+    __device__ __forceinline__ void roll(const uint4 tv) {
+        const uint32_t nfhi = __builtin_amdgcn_alignbit(fhi, flo, 31), nflo = __builtin_amdgcn_alignbit(flo, fhi, 31);  // rol 1
+        const uint32_t nrlo = __builtin_amdgcn_alignbit(rhi, rlo, 1), nrhi = __builtin_amdgcn_alignbit(rlo, rhi, 1);    // ror 1
+        flo = nflo ^ tv.x;
+        fhi = nfhi ^ tv.y;
+        rlo = nrlo ^ tv.z;
+        rhi = nrhi ^ tv.w;
+    }
+};
+
+// Rolls ntHash over windows [0, w_eff) of the tile's code stream; lane L owns windows [L*lc, (L+1)*lc), lc = ceil(w_eff/64).
+// Candidates (high-word test) go to the dense list in emission order; lane L's records, in slot order, are its windows in
+// position order.  Returns this lane's record count; wcount = records of the whole wave.
+__device__ __forceinline__ uint32_t seed_stage_b(const SeedTables &T, SeedLds &S, const DevParams &P, uint32_t w_eff,
+                                                 uint4 *__restrict__ spill, uint32_t &wcount_out) {
+    const uint32_t lane = lane_id();
+    const uint32_t l = P.l;
+    const uint32_t lc = (w_eff + 63u) >> 6;
+    const uint32_t s0 = lane * lc;
+    const uint32_t bhi = (uint32_t)(P.bound >> 32);
+    uint32_t tagbase = lane << 16;  // | slot << 22
+    uint32_t wcount = 0;            // records written by the wave so far (wave-uniform)
+    if (s0 < w_eff) {  // lanes beyond the last window sit out (exec-masked)
+        Hash2 h = {0, 0, 0, 0};
+        // 16 codes starting at code index a (any alignment)
+        auto codes16 = [&](uint32_t a) -> uint32_t {
+            const uint32_t d = a >> 4;
+            return __builtin_amdgcn_alignbit(S.codes[d + 1u], S.codes[d], 2u * (a & 15u));
+        };
+        // warm-up: the lane's first window, Horner form (fh = rol(fh,1)^h(c), rh = ror(rh,1)^rol(hc(c),l-1))
+        for (uint32_t m0 = 0; m0 < l; m0 += 16u) {
+            const uint32_t dw = codes16(s0 + m0);
+            const uint32_t cnt = l - m0 < 16u ? l - m0 : 16u;
+            for (uint32_t m = 0; m < cnt; ++m) h.roll(T.warm[(dw >> (2u * m)) & 3u]);
+        }
+        // nibble m of xe / xo = out | in<<2 for step 2m / 2m+1 of a 16-step block
+        auto mk_xe = [](uint32_t ow, uint32_t iw) { return (ow & 0x33333333u) | ((iw & 0x33333333u) << 2); };
+        auto mk_xo = [](uint32_t ow, uint32_t iw) { return ((ow >> 2) & 0x33333333u) | (iw & 0xCCCCCCCCu); };
+        auto nib = [](uint32_t xe, uint32_t xo, uint32_t s) { return (((s & 1u) ? xo : xe) >> (4u * (s >> 1))) & 0xFu; };
+        const uint32_t o_dw = s0 >> 4, o_sh = 2u * (s0 & 15u);
+        const uint32_t i_dw = (s0 + l) >> 4, i_sh = 2u * ((s0 + l) & 15u);
+        uint32_t prev_o = S.codes[o_dw], prev_i = S.codes[i_dw];
+        uint32_t xe, xo;
+        {
+            const uint32_t no = S.codes[o_dw + 1u], ni = S.codes[i_dw + 1u];
+            const uint32_t ow = __builtin_amdgcn_alignbit(no, prev_o, o_sh), iw = __builtin_amdgcn_alignbit(ni, prev_i, i_sh);
+            prev_o = no;
+            prev_i = ni;
+            xe = mk_xe(ow, iw);
+            xo = mk_xo(ow, iw);
+        }
+        // ring of table values for the next four steps: their LDS reads are in flight while a step tests / emits
+        uint4 tv[4];
+#pragma unroll
+        for (uint32_t s = 0; s < 4; ++s) tv[s] = T.roll[nib(xe, xo, s)];
+        const uint32_t nb = (lc + 15u) >> 4;
+        uint32_t jbase = s0;  // j of step 0 of the current block
+        for (uint32_t blk = 0; blk < nb; ++blk) {
+            uint32_t xe_n, xo_n;
+            {
+                const uint32_t no = S.codes[o_dw + blk + 2u], ni = S.codes[i_dw + blk + 2u];
+                const uint32_t ow = __builtin_amdgcn_alignbit(no, prev_o, o_sh), iw = __builtin_amdgcn_alignbit(ni, prev_i, i_sh);
+                prev_o = no;
+                prev_i = ni;
+                xe_n = mk_xe(ow, iw);
+                xo_n = mk_xo(ow, iw);
+            }
+            const uint32_t lim = lc - 16u * blk;  // steps left (wave-uniform): the last block may be partial
+            auto step = [&](uint32_t t) {
+                const uint32_t mhi = h.fhi < h.rhi ? h.fhi : h.rhi;
+                const bool cand = mhi <= bhi;  // high words only; the exact test runs in stage R
+                if (__ballot(cand)) {
+                    const uint64_t okm = __ballot(cand);
+                    if (cand) {
+                        const uint64_t F = ((uint64_t)h.fhi << 32) | h.flo, R = ((uint64_t)h.rhi << 32) | h.rlo;
+                        const uint64_t hv = F < R ? F : R;
+                        const uint32_t idx = wcount + mbcnt64(okm);
+                        const uint32_t tag = tagbase + jbase + t;
+                        if (idx < SD_CAND_CAP) {
+                            S.cand_hash[idx] = hv;
+                            S.cand_tag[idx] = tag;
+                        } else {
+                            spill[idx - SD_CAND_CAP] = make_uint4((uint32_t)hv, (uint32_t)(hv >> 32), tag, 0u);
+                        }
+                        tagbase += 1u << 22;
+                    }
+                    wcount += (uint32_t)__popcll(okm);
+                }
+                h.roll(tv[t & 3u]);
+                tv[t & 3u] = (t + 4u < 16u) ? T.roll[nib(xe, xo, t + 4u)] : T.roll[nib(xe_n, xo_n, t + 4u - 16u)];
+            };
+            if (lim >= 16u) {
+#pragma unroll
+                for (uint32_t t = 0; t < 16; ++t) step(t);
+            } else {
+#pragma unroll
+                for (uint32_t t = 0; t < 16; ++t) {
+                    if (t < lim) step(t);
+                }
+            }
+            xe = xe_n;
+            xo = xo_n;
+            jbase += 16u;
+        }
+    }
+    wcount_out = rdfirst(wcount);
+    return tagbase >> 22;
+}
+
+// ------------------------------------------------------------------ stage R
+// r-th run head (0-based) of a 64-base block with head mask m
+__device__ __forceinline__ uint32_t select_bit64(unsigned long long m, uint32_t r) {
+    uint32_t mw = (uint32_t)m, bit = 0;
+    const uint32_t c = (uint32_t)__popc(mw);
+    if (r >= c) {
+        r -= c;
+        mw = (uint32_t)(m >> 32);
+        bit = 32;
+    }
+#pragma unroll
+    for (uint32_t width = 16; width >= 1; width >>= 1) {
+        const uint32_t half = (uint32_t)__popc(mw & ((1u << width) - 1u));
+        if (r >= half) {
+            r -= half;
+            mw >>= width;
+            bit += width;
+        }
+    }
+    return bit;
+}
+
+// raw position of compressed base j of the current tile
+__device__ __forceinline__ uint32_t seed_rawpos(const SeedLds &S, uint32_t n_blocks, float scale, uint32_t raw_base, uint32_t carry_n, uint32_t j) {
+    if (j < carry_n) return S.carry_pos[j];  // a base of the previous tile's last l-1
+    uint32_t b = (uint32_t)((float)j * scale);  // interpolate, then walk to the block with cnt[b] <= j < cnt[b+1]
+    if (b >= n_blocks) b = n_blocks - 1u;
+    while ((uint32_t)S.cnt[b] > j) --b;
+    while ((uint32_t)S.cnt[b + 1u] <= j) ++b;
+    return raw_base + b * 64u + select_bit64(S.heads[b], j - (uint32_t)S.cnt[b]);
+}
+
+// Orders the tile's candidates, resolves their raw positions and appends them to the sequence's minimizer list.
+// Returns the number of minimizers appended; sets inexact when a candidate fails the exact 64-bit test (the sequence then
+// goes to the general path, whose test is exact by construction).
+__device__ __forceinline__ uint32_t seed_stage_r(SeedLds &S, const DevParams &P, uint32_t my_count, uint32_t total, const uint4 *__restrict__ spill,
+                                                 uint32_t w_eff, uint32_t n_blocks, uint32_t n_codes, uint32_t raw_base, uint32_t carry_n,
+                                                 unsigned long long *__restrict__ mz_hash, uint32_t *__restrict__ mz_pos, uint32_t out_base,
+                                                 uint32_t out_cap, bool &inexact) {
+    const uint32_t lane = lane_id();
+    const uint32_t incl = wave_incl_scan_u32(my_count);
+    S.lane_prefix[lane] = (uint16_t)(incl - my_count);
+    if (total > SD_CAND_CAP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's spill stores have reached L2
+    wave_sync();
+    const float scale = (float)n_blocks / (float)(n_codes ? n_codes : 1u);
+    uint32_t n_garbage = 0;
+    for (uint32_t i0 = 0; i0 < total; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        const bool act = i < total;
+        uint64_t hv = 0;
+        uint32_t tag = 0;
+        if (act) {
+            if (i < SD_CAND_CAP) {
+                hv = S.cand_hash[i];
+                tag = S.cand_tag[i];
+            } else {
+                const unsigned long long *rec = reinterpret_cast<const unsigned long long *>(spill + (i - SD_CAND_CAP));
+                hv = __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L2-served: never a stale L1 line
+                tag = (uint32_t)__hip_atomic_load(rec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        const uint32_t j = tag & 0xFFFFu;
+        const bool valid = act && j < w_eff;  // windows past the end belong to the last lane's last slots: they sort to the very end
+        n_garbage += (uint32_t)__popcll(__ballot(act && !valid));
+        if (valid) {
+            if (hv > P.bound) inexact = true;
+            const uint32_t dest = out_base + (uint32_t)S.lane_prefix[(tag >> 16) & 63u] + (tag >> 22);
+            const uint32_t pos = seed_rawpos(S, n_blocks, scale, raw_base, carry_n, j);
+            if (dest < out_cap) {
+                mz_hash[dest] = hv;
+                mz_pos[dest] = pos;
+            }
+        }
+    }
+    inexact = __ballot(inexact) != 0;
+    return total - n_garbage;
+}
+
+// Whole sequence through the fast path, tile by tile.  Returns the number of minimizers (may exceed out_cap: overflow, the
+// list is then incomplete) or 0xFFFFFFFF when the sequence does not qualify (non-ACGT byte / inexact candidate).
+// TIMING (diagnostic builds only): tacc[0..2] += cycles spent in stages A, B, R.
+constexpr uint32_t SD_NOT_FAST = 0xFFFFFFFFu;
+template <bool TIMING = false>
+__device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict__ seq, uint32_t len, const DevParams &P, const SeedTables &T,
+                                                       SeedLds &S, uint4 *__restrict__ spill, unsigned long long *__restrict__ mz_hash,
+                                                       uint32_t *__restrict__ mz_pos, uint32_t out_cap, unsigned long long *tacc = nullptr) {
+    const uint32_t lane = lane_id();
+    uint32_t raw0 = 0, carry_n = 0, carry_prev = 0, n_out = 0;
+    while (raw0 < len) {
+        uint32_t n_codes = 0, n_blocks = 0, raw_end = 0;
+        const unsigned long long t0 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
+        const bool ok = seed_stage_a(seq, len, raw0, carry_n, carry_prev, P.use_hpc != 0, T, S, n_codes, n_blocks, raw_end);
+        const unsigned long long t1 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
+        if (TIMING) tacc[0] += t1 - t0;
+        if (!ok) return SD_NOT_FAST;
+        const bool more = raw_end < len;
+        if (n_codes >= P.l) {
+            const uint32_t w_eff = n_codes - P.l + 1u;
+            uint32_t total = 0;
+            const uint32_t my = seed_stage_b(T, S, P, w_eff, spill, total);
+            const unsigned long long t2 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
+            if (TIMING) tacc[1] += t2 - t1;
+            bool inexact = false;
+            n_out += seed_stage_r(S, P, my, total, spill, w_eff, n_blocks, n_codes, raw0, carry_n, mz_hash, mz_pos, n_out, out_cap, inexact);
+            if (inexact) return SD_NOT_FAST;
+            if (TIMING) tacc[2] += __builtin_amdgcn_s_memtime() - t2;
+        }
+        if (more) {
+            // the last l-1 compressed bases (all of them when the tile has fewer: a very long homopolymer run) open the next
+            // tile's code stream; their raw positions stay available for windows that start in them
+            const uint32_t new_cn = n_codes < P.l - 1u ? n_codes : P.l - 1u;
+            const float scale = (float)n_blocks / (float)(n_codes ? n_codes : 1u);
+            uint32_t cpos = 0, ccode = 0;
+            if (lane < new_cn) cpos = seed_rawpos(S, n_blocks, scale, raw0, carry_n, n_codes - new_cn + lane);
+            if (lane < 4u) {
+                const uint32_t sb = 2u * (n_codes - new_cn) + 32u * lane;
+                ccode = __builtin_amdgcn_alignbit(S.codes[(sb >> 5) + 1u], S.codes[sb >> 5], sb & 31u);
+                const uint32_t keep = 2u * new_cn > 32u * lane ? 2u * new_cn - 32u * lane : 0u;
+                ccode = keep >= 32u ? ccode : (ccode & ((1u << keep) - 1u));
+            }
+            wave_sync();
+            if (lane < new_cn) S.carry_pos[lane] = cpos;
+            if (lane < 4u) S.carry_codes[lane] = ccode;
+            carry_n = new_cn;
+        }
+        wave_sync();
+        raw0 = raw_end;
+    }
+    return n_out;
+}
+
+}  // namespace mq

@@ -480,6 +480,11 @@ uint64_t mqo_index_build_mt(mqo_index *ix, const uint8_t *bases, const uint64_t 
     return total;
 }
 
+/* ------------------------------------------------------------------ branch counters (tests only)
+ * Set per thread by mqo_find_matches_diag: which of the reference's sharp edges did this read reach?  They let the GPU
+ * parity tests assert that their inputs really exercise the precedence quirk, ties, the `as i32` wrap and the clipping. */
+static __thread mqo_diag *g_diag = NULL;
+
 /* ------------------------------------------------------------------ Match (src/match.rs) */
 
 /* Match::new src/match.rs:20-29 */
@@ -510,6 +515,12 @@ int mqo_match_check(const mqo_match *m, const mqo_kminmer *q, const mqo_entry *r
     int B = ((((q->rev != 0) != (r->rc != 0)) ? 1 : 0) == (m->rc ? 1 : 0));
     int C = (m->rc && d_rc == 1);
     int D = (!m->rc && d_fw == 1);
+    if (g_diag) {
+        if (D && !(A && B)) g_diag->quirk_ext++;      /* forward run extended across references / strands (F8) */
+        if (D && !A) g_diag->quirk_cross_ref++;
+        if (A && B && C) g_diag->rc_ext++;
+        if (!((A && B && C) || D)) g_diag->check_fail++; /* a hit that fails check starts the next Match */
+    }
     return (A && B && C) || D;
 }
 
@@ -559,12 +570,14 @@ static inline uint64_t abs_as_usize(int32_t x) {
 }
 /* src/chain.rs:132-136 */
 static int fwd_gap_too_long(uint64_t u_q_e, uint64_t u_r_e, uint64_t v_q_s, uint64_t v_r_s, uint64_t g) {
+    if (g_diag && ((u_q_e | u_r_e | v_q_s | v_r_s) >> 31)) g_diag->i32_wrap++; /* a coordinate >= 2^31 went through `as i32` */
     int32_t g1 = wsub32(as_i32(v_q_s), as_i32(u_q_e));
     int32_t g2 = wsub32(as_i32(v_r_s), as_i32(u_r_e));
     return abs_as_usize(wsub32(g1, g2)) > g;
 }
 /* src/chain.rs:138-142 */
 static int rc_gap_too_long(uint64_t u_r_s, uint64_t u_q_e, uint64_t v_q_s, uint64_t v_r_e, uint64_t g) {
+    if (g_diag && ((u_r_s | u_q_e | v_q_s | v_r_e) >> 31)) g_diag->i32_wrap++;
     int32_t g1 = wsub32(as_i32(v_q_s), as_i32(u_q_e));
     int32_t g2 = wsub32(as_i32(u_r_s), as_i32(v_r_e));
     return abs_as_usize(wsub32(g1, g2)) > g;
@@ -602,8 +615,9 @@ int mqo_chain_get_match(const mqo_match *matches, size_t n, const mqo_params *p,
                 last = &matches[i];
                 len_f++;
                 score += matches[i].count;
-            }
+            } else if (g_diag) g_diag->filtered_out++;
         }
+        if (g_diag) g_diag->multi_match_refs++;
     } else {
         first = last = &matches[0];
         len_f = 1;
@@ -658,14 +672,14 @@ void mqo_find_coords(uint64_t q_len, uint64_t r_len, uint64_t ref_id, const mqo_
     uint64_t tail = q_len - q_end - 1;
     if (!c->rc) {
         if (r_start >= q_start) { final_r_start = r_start - q_start; exc_s = q_start; }
-        else { final_r_start = 0; exc_s = r_start; }
+        else { final_r_start = 0; exc_s = r_start; if (g_diag) g_diag->clip_start++; }
         if (r_end + tail <= r_len - 1) { final_r_end = r_end + tail; exc_e = tail; }
-        else { final_r_end = r_len - 1; exc_e = r_len - r_end - 1; }
+        else { final_r_end = r_len - 1; exc_e = r_len - r_end - 1; if (g_diag) g_diag->clip_end++; }
     } else {
         if (r_end + q_start <= r_len - 1) { final_r_end = r_end + q_start; exc_s = q_start; }
-        else { final_r_end = r_len - 1; exc_s = r_len - r_end - 1; }
+        else { final_r_end = r_len - 1; exc_s = r_len - r_end - 1; if (g_diag) g_diag->clip_end++; }
         if (r_start >= tail) { final_r_start = r_start - tail; exc_e = tail; }
-        else { final_r_start = 0; exc_e = r_start; }
+        else { final_r_start = 0; exc_e = r_start; if (g_diag) g_diag->clip_start++; }
     }
     out->mapped = 1;
     out->rc = c->rc;
@@ -727,10 +741,24 @@ void mqo_find_matches(const mqo_index *ix, const uint8_t *seq, size_t len, const
         }
     }
     int best = mqo_best_of(scores, ncand);
+    if (g_diag) {
+        g_diag->n_kminmers = n;
+        for (size_t i = 0; i < n; i++) g_diag->n_hits += hit[i];
+        g_diag->n_matches = nm;
+        g_diag->n_candidates = ncand;
+        g_diag->tie = (ncand > 1 && best < 0);
+    }
     if (best >= 0) {
         mqo_find_coords(len, mqo_index_ref_len(ix, ids[best]), ids[best], &coords[best], out);
     }
     free(km); free(ent); free(hit); free(ms); free(mref); free(done); free(grp); free(scores); free(ids); free(coords);
+}
+
+void mqo_find_matches_diag(const mqo_index *ix, const uint8_t *seq, size_t len, const mqo_params *p, mqo_paf *out, mqo_diag *diag) {
+    memset(diag, 0, sizeof(*diag));
+    g_diag = diag;
+    mqo_find_matches(ix, seq, len, p, out);
+    g_diag = NULL;
 }
 
 /* ------------------------------------------------------------------ batch driver (CPU baseline) */
@@ -742,6 +770,7 @@ typedef struct {
     const mqo_params *p;
     mqo_paf *out;
     volatile uint32_t *next;
+    mqo_diag *diag; /* NULL in the timed baseline */
 } map_job;
 
 static void *map_worker(void *arg) {
@@ -750,17 +779,26 @@ static void *map_worker(void *arg) {
         uint32_t lo = __sync_fetch_and_add(j->next, 16);
         if (lo >= j->n) break;
         uint32_t hi = lo + 16 < j->n ? lo + 16 : j->n;
-        for (uint32_t r = lo; r < hi; r++)
-            mqo_find_matches(j->ix, j->bases + j->offsets[r], (size_t)(j->offsets[r + 1] - j->offsets[r]), j->p, &j->out[r]);
+        for (uint32_t r = lo; r < hi; r++) {
+            const uint8_t *sq = j->bases + j->offsets[r];
+            const size_t ln = (size_t)(j->offsets[r + 1] - j->offsets[r]);
+            if (j->diag) mqo_find_matches_diag(j->ix, sq, ln, j->p, &j->out[r], &j->diag[r]);
+            else mqo_find_matches(j->ix, sq, ln, j->p, &j->out[r]);
+        }
     }
     return NULL;
 }
 
 void mqo_map_batch(const mqo_index *ix, const uint8_t *bases, const uint64_t *offsets, uint32_t n,
                    const mqo_params *p, int threads, mqo_paf *out) {
+    mqo_map_batch_diag(ix, bases, offsets, n, p, threads, out, NULL);
+}
+
+void mqo_map_batch_diag(const mqo_index *ix, const uint8_t *bases, const uint64_t *offsets, uint32_t n,
+                        const mqo_params *p, int threads, mqo_paf *out, mqo_diag *diag) {
     if (threads < 1) threads = 1;
     volatile uint32_t next = 0;
-    map_job job = {ix, bases, offsets, n, p, out, &next};
+    map_job job = {ix, bases, offsets, n, p, out, &next, diag};
     if (threads == 1) { map_worker(&job); return; }
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
     for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, map_worker, &job);

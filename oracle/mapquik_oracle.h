@@ -158,11 +158,33 @@ void mqo_find_coords(uint64_t q_len, uint64_t r_len, uint64_t ref_id, const mqo_
 /* PAF text, no trailing newline; returns length written (snprintf semantics) */
 int  mqo_format_paf(const char *q_id, const char *r_name, const mqo_paf *paf, char *buf, size_t cap);
 
+/* Per-read branch counters (tests only): which sharp edges of the reference did this read reach? */
+typedef struct {
+    uint64_t n_kminmers;
+    uint64_t n_hits;
+    uint64_t n_matches;
+    uint64_t n_candidates;     /* references with a Some(get_match) (src/mers.rs:81-86) */
+    uint64_t tie;              /* 1 => top two scores equal => None (src/mers.rs:104-108) */
+    uint64_t quirk_ext;        /* Match::check true through `|| D` although same-ref/same-strand is false (src/match.rs:39-43) */
+    uint64_t quirk_cross_ref;  /* ... of which the hit is on another reference */
+    uint64_t rc_ext;           /* extensions through (A && B && C) */
+    uint64_t check_fail;       /* hits that fail check and start the next Match */
+    uint64_t i32_wrap;         /* gap tests that saw a coordinate >= 2^31 (src/chain.rs:132-142) */
+    uint64_t multi_match_refs; /* references with more than one Match (filter_matches_max ran, src/chain.rs:123-129) */
+    uint64_t filtered_out;     /* Matches dropped by the co-linearity filter */
+    uint64_t clip_start;       /* find_coords clipped at the reference start (src/mers.rs:131-183) */
+    uint64_t clip_end;         /* ... at the reference end */
+} mqo_diag;
+
 /* ---- the hot path: src/mers.rs:77-102 ---- */
 void mqo_find_matches(const mqo_index *ix, const uint8_t *seq, size_t len, const mqo_params *p, mqo_paf *out);
 /* batch driver with a pthread pool (CPU baseline).  bases: concatenated reads, offsets: n+1 */
 void mqo_map_batch(const mqo_index *ix, const uint8_t *bases, const uint64_t *offsets, uint32_t n,
                    const mqo_params *p, int threads, mqo_paf *out);
+/* the same with per-read branch counters (diag: n records, or NULL) */
+void mqo_find_matches_diag(const mqo_index *ix, const uint8_t *seq, size_t len, const mqo_params *p, mqo_paf *out, mqo_diag *diag);
+void mqo_map_batch_diag(const mqo_index *ix, const uint8_t *bases, const uint64_t *offsets, uint32_t n,
+                        const mqo_params *p, int threads, mqo_paf *out, mqo_diag *diag);
 
 #ifdef __cplusplus
 }

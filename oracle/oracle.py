@@ -40,6 +40,9 @@ paf_dtype = np.dtype([("mapped", "<i4"), ("rc", "<i4"), ("ref_id", "<u8"), ("q_l
                       ("q_end", "<u8"), ("r_len", "<u8"), ("r_start", "<u8"), ("r_end", "<u8"), ("score", "<u8"),
                       ("mapq", "<u8")])
 
+diag_dtype = np.dtype([(n, "<u8") for n in ("n_kminmers", "n_hits", "n_matches", "n_candidates", "tie", "quirk_ext", "quirk_cross_ref",
+                                            "rc_ext", "check_fail", "i32_wrap", "multi_match_refs", "filtered_out", "clip_start", "clip_end")])
+
 _lib = None
 
 
@@ -101,6 +104,7 @@ def lib():
     L.mqo_format_paf.argtypes = [C.c_char_p, C.c_char_p, vp, C.c_char_p, sz]
     L.mqo_find_matches.argtypes = [vp, vp, sz, PP, vp]
     L.mqo_map_batch.argtypes = [vp, vp, vp, C.c_uint32, PP, C.c_int, vp]
+    L.mqo_map_batch_diag.argtypes = [vp, vp, vp, C.c_uint32, PP, C.c_int, vp, vp]
     _lib = L
     return L
 
@@ -202,6 +206,16 @@ class Index:
         out = np.zeros(n, dtype=paf_dtype)
         lib().mqo_map_batch(self.h, _ptr(bases), _ptr(offsets), n, C.byref(p), threads, _ptr(out))
         return out
+
+    def map_batch_diag(self, bases, offsets, p, threads=1):
+        """map_batch plus per-read branch counters (diag_dtype): which sharp edges of the reference each read reached."""
+        bases = _seq(bases)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        out = np.zeros(n, dtype=paf_dtype)
+        diag = np.zeros(n, dtype=diag_dtype)
+        lib().mqo_map_batch_diag(self.h, _ptr(bases), _ptr(offsets), n, C.byref(p), threads, _ptr(out), _ptr(diag))
+        return out, diag
 
 
 def format_paf(q_id, r_name, paf):

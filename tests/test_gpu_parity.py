@@ -229,6 +229,37 @@ def test_real_read_fixture(mq):
             assert hashlib.sha256(o.tobytes()).hexdigest() == e["sha256_of_tuples"]
 
 
+def test_real_read_fixture_100(mq):
+    """All 100 reads of the reference's example read file (tests/golden/nearperfect-ecoli.100.fa.gz) through the HIP seeder
+    vs the committed per-read digests (tests/golden/ecoli100_kminmers.json), three parameter sets."""
+    import gzip
+    import hashlib
+    import json
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    exp = json.load(open(os.path.join(gold, "ecoli100_kminmers.json")))
+    recs, name = [], None
+    for line in gzip.open(os.path.join(gold, "nearperfect-ecoli.100.fa.gz"), "rt"):
+        line = line.strip()
+        if line.startswith(">"):
+            name = line[1:].split()[0]
+        elif name is not None:
+            recs.append((name, line.encode()))
+            name = None
+    assert len(recs) == 100
+    bases = np.frombuffer(b"".join(s for _, s in recs), dtype=np.uint8)
+    offs = np.zeros(len(recs) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(s) for _, s in recs])
+    odt = np.dtype([("hash", "<u8"), ("start", "<u8"), ("end", "<u8"), ("offset", "<u8"), ("rev", "<i4"), ("_pad", "<i4")])
+    for case in exp["cases"]:
+        got = mq.Index(mq.Params(**case["params"])).kminmers_batch(bases, offs)
+        for km, e in zip(got, case["reads"]):
+            assert len(km) == e["n_kminmers"], e["id"]
+            o = np.zeros(len(km), dtype=odt)
+            for f in ("hash", "start", "end", "offset", "rev"):
+                o[f] = km[f]
+            assert hashlib.sha256(o.tobytes()).hexdigest() == e["sha256_of_tuples"], e["id"]
+
+
 def test_device_resident_entry_point_and_reuse(mq, oracle, simlib, ecoli):
     """mq_map_batch_device on caller-owned device buffers (plain hipMalloc through ctypes), launched twice on one index."""
     import ctypes as C

@@ -85,6 +85,33 @@ def test_real_read_fixture_matches_oracle(oracle):
             assert hashlib.sha256(km.tobytes()).hexdigest() == e["sha256_of_tuples"]
 
 
+def _fasta_gz(path):
+    import gzip
+    recs, name = [], None
+    for line in gzip.open(path, "rt"):
+        line = line.strip()
+        if line.startswith(">"):
+            name = line[1:].split()[0]
+        elif name is not None:
+            recs.append((name, line.encode()))
+            name = None
+    return recs
+
+
+def test_real_read_fixture_100_matches_oracle(oracle):
+    """All 100 reads of the reference's example/nearperfect-ecoli.100.fa (committed as data) vs the committed digests."""
+    exp = json.load(open(os.path.join(GOLD, "ecoli100_kminmers.json")))
+    recs = _fasta_gz(os.path.join(GOLD, "nearperfect-ecoli.100.fa.gz"))
+    assert len(recs) == 100 and sum(len(s) for _, s in recs) == 2289087  # SURVEY section 4
+    for case in exp["cases"]:
+        p = oracle.params(**case["params"])
+        for (name, seq), e in zip(recs, case["reads"]):
+            assert name == e["id"] and len(seq) == e["len"]
+            km = oracle.kminmers(seq, p)
+            assert len(km) == e["n_kminmers"]
+            assert hashlib.sha256(km.tobytes()).hexdigest() == e["sha256_of_tuples"]
+
+
 def test_end_to_end_mapeval_and_index_order_independence(oracle, simlib):
     g, off, names = simlib.make_genome([300000, 200000], seed=17, repeat_frac=0.2, tandem_frac=0.05)
     reads = simlib.make_reads(g, off, 120, seed=2, len_mean=9000, len_sd=3000)

@@ -93,6 +93,59 @@ void mqsim_plant_repeats(uint8_t *g, uint64_t len, uint64_t seed, uint64_t n_seg
     }
 }
 
+/* Transposon-like repeat families (maize-shaped genomes, experiments/simulate_maize.sh context): n_fam consensus
+ * sequences (length U[min_len,max_len], taken from the genome itself) are pasted until ~target_bases bases are covered;
+ * every copy gets its own divergence U[div_lo,div_hi] (substitutions), so copies of one family differ by 2x that.
+ * Sequential and deterministic. */
+void mqsim_plant_families(uint8_t *g, uint64_t len, uint64_t seed, uint64_t n_fam, uint64_t target_bases, uint64_t min_len,
+                          uint64_t max_len, double div_lo, double div_hi) {
+    uint64_t s = seed ^ 0x5EEDFA1117ULL;
+    if (len < 4 * max_len || n_fam == 0) return;
+    uint64_t *fl = (uint64_t *)malloc(n_fam * sizeof(uint64_t));
+    uint8_t **fs = (uint8_t **)malloc(n_fam * sizeof(uint8_t *));
+    for (uint64_t f = 0; f < n_fam; f++) {
+        fl[f] = min_len + splitmix64(&s) % (max_len - min_len + 1);
+        const uint64_t src = splitmix64(&s) % (len - fl[f]);
+        fs[f] = (uint8_t *)malloc(fl[f]);
+        memcpy(fs[f], g + src, fl[f]);
+    }
+    uint64_t done = 0;
+    while (done < target_bases) {
+        const uint64_t f = splitmix64(&s) % n_fam;
+        const uint64_t dst = splitmix64(&s) % (len - fl[f]);
+        const double div = div_lo + (div_hi - div_lo) * u01(&s);
+        /* geometric skipping: next substituted base */
+        uint64_t t = 0;
+        memcpy(g + dst, fs[f], fl[f]);
+        if (div > 0) {
+            const double lg = log(1.0 - div);
+            for (;;) {
+                double u = u01(&s);
+                if (u < 1e-300) u = 1e-300;
+                t += (uint64_t)(log(u) / lg);
+                if (t >= fl[f]) break;
+                g[dst + t] = (uint8_t)ACGT[splitmix64(&s) & 3];
+                t++;
+            }
+        }
+        done += fl[f];
+    }
+    for (uint64_t f = 0; f < n_fam; f++) free(fs[f]);
+    free(fs);
+    free(fl);
+}
+
+/* Runs of N (assembly gaps): n_runs runs of length U[min_len,max_len]. */
+void mqsim_plant_n(uint8_t *g, uint64_t len, uint64_t seed, uint64_t n_runs, uint64_t min_len, uint64_t max_len) {
+    uint64_t s = seed ^ 0x4E4E4E4EULL;
+    if (len < 4 * max_len) return;
+    for (uint64_t i = 0; i < n_runs; i++) {
+        const uint64_t L = min_len + splitmix64(&s) % (max_len - min_len + 1);
+        const uint64_t dst = splitmix64(&s) % (len - L);
+        memset(g + dst, 'N', L);
+    }
+}
+
 typedef struct {
     const uint8_t *genome;      /* concatenated contigs */
     const uint64_t *ctg_off;    /* n_ctg + 1 */

@@ -31,6 +31,8 @@ def lib():
         vp, u64, u32, dbl = C.c_void_p, C.c_uint64, C.c_uint32, C.c_double
         L.mqsim_genome.argtypes = [vp, u64, u64, C.c_int]
         L.mqsim_plant_repeats.argtypes = [vp, u64, u64, u64, u64, u64, u64, dbl]
+        L.mqsim_plant_families.argtypes = [vp, u64, u64, u64, u64, u64, u64, dbl, dbl]
+        L.mqsim_plant_n.argtypes = [vp, u64, u64, u64, u64, u64]
         L.mqsim_read_caps.argtypes = [vp, u32, u32, dbl, dbl, u64, u64, u64, vp]
         L.mqsim_reads.argtypes = [vp, vp, u32, u32, dbl, dbl, u64, u64, dbl, dbl, dbl, u64, C.c_int, vp, vp, vp, vp, vp, vp, vp]
         L.mqsim_compact.argtypes = [vp, vp, vp, u32, vp, vp]
@@ -49,9 +51,15 @@ CHM13_LIKE = [248387328, 242696752, 201105948, 193574945, 182045439, 172126628, 
 ECOLI_LEN = [4641652]  # example/ecoli.genome.fa.fai:1
 
 
-def make_genome(contig_lens, seed=913, threads=8, repeat_frac=0.0, tandem_frac=0.0, div=0.01, prefix="chr"):
+# 10 contigs shaped like maize B73 v5 chr1..10 (rounded; sum ~2.13 Gbp, longest 308 Mbp)
+MAIZE_LIKE = [308452471, 243675191, 238017767, 250330460, 226353449, 181357234, 185808916, 182411202, 163004744, 152435371]
+
+
+def make_genome(contig_lens, seed=913, threads=8, repeat_frac=0.0, tandem_frac=0.0, div=0.01, prefix="chr", family_frac=0.0,
+                n_families=200, family_div=(0.01, 0.05), n_runs=0):
     """Uniform ACGT contigs; optionally overwrite ~repeat_frac of the bases with copied segments
-    (1-20 kb, `div` divergence) and ~tandem_frac with tandem arrays."""
+    (1-20 kb, `div` divergence) and ~tandem_frac with tandem arrays; ~family_frac with copies of `n_families`
+    transposon-like families (1-12 kb, per-copy divergence U[family_div]); `n_runs` runs of N (100-50,000 bases)."""
     lens = np.asarray(contig_lens, dtype=np.uint64)
     offsets = np.zeros(lens.size + 1, dtype=np.uint64)
     offsets[1:] = np.cumsum(lens)
@@ -63,6 +71,10 @@ def make_genome(contig_lens, seed=913, threads=8, repeat_frac=0.0, tandem_frac=0
         n_seg = int(total * repeat_frac / mean_len)
         n_tan = int(total * tandem_frac / mean_len)
         lib().mqsim_plant_repeats(_p(g), total, seed, n_seg, n_tan, 1000, 20000, div)
+    if family_frac > 0:
+        lib().mqsim_plant_families(_p(g), total, seed, n_families, int(total * family_frac), 1000, 12000, family_div[0], family_div[1])
+    if n_runs > 0:
+        lib().mqsim_plant_n(_p(g), total, seed, n_runs, 100, 50000)
     names = ["%s%d" % (prefix, i + 1) for i in range(lens.size)]
     return g, offsets, names
 
