@@ -7,7 +7,7 @@ CSRC   := mapquik_amd/csrc
 
 all: $(LIBDIR)/libmapquik_hip.so $(LIBDIR)/mapquik
 
-$(LIBDIR)/libmapquik_hip.so: $(CSRC)/mq_capi.hip $(CSRC)/mq_device.hpp $(CSRC)/mq_fast.hpp include/mapquik_hip.h
+$(LIBDIR)/libmapquik_hip.so: $(CSRC)/mq_capi.hip $(CSRC)/mq_device.hpp $(CSRC)/mq_seed.hpp include/mapquik_hip.h
 	mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -Wno-align-mismatch -o $@ $(CSRC)/mq_capi.hip
 

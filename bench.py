@@ -115,11 +115,11 @@ def main():
     d_offs = torch.from_numpy(offs.astype(np.int64)).to(dev)
     d_out = torch.zeros(n * mq.hit_dtype.itemsize, dtype=torch.uint8, device=dev)
     t_reads = time.time() - t0
-    ix.reserve(max_len)
+    ix.reserve(n, total_bases)
     stream = torch.cuda.current_stream(dev)
 
     def step():
-        ix.map_batch_device(d_bases.data_ptr(), d_offs.data_ptr(), n, max_len, d_out.data_ptr(), stream.cuda_stream)
+        ix.map_batch_device(d_bases.data_ptr(), d_offs.data_ptr(), n, total_bases, d_out.data_ptr(), stream.cuda_stream)
 
     for _ in range(args.warmup):
         step()
@@ -160,7 +160,7 @@ def main():
     # HBM), S_slot = 32 B, p_bar = mean probes per lookup MEASURED on this batch by one instrumented launch outside the timed
     # region, S_out = 40 B (+ 8 B offset)
     d_out2 = torch.zeros_like(d_out)
-    lookups, extra = ix.probe_stats(d_bases.data_ptr(), d_offs.data_ptr(), n, max_len, d_out2.data_ptr())
+    lookups, extra = ix.probe_stats(d_bases.data_ptr(), d_offs.data_ptr(), n, total_bases, d_out2.data_ptr())
     torch.cuda.synchronize()
     assert torch.equal(d_out, d_out2), "instrumented launch disagrees with the timed one"
     p_bar = 1.0 + extra / max(lookups, 1)

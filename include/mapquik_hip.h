@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MQ_ABI_VERSION 1
+#define MQ_ABI_VERSION 2
 
 #define MQ_OK 0
 #define MQ_EINVAL (-1)
@@ -118,22 +118,49 @@ mq_index *mq_index_load(const char *path, int device);
 int mq_index_ref_info(const mq_index *idx, uint32_t ref_id, const char **name, uint64_t *len);
 
 /* find_matches (src/mers.rs:77-102) for n reads.  bases: concatenated reads; offsets: n+1 prefix offsets.
- * Host-buffer form: copies in, runs, copies out, synchronises.  Reads that overflow the per-wave Match scratch are mapped
- * again on the GPU with a worst-case scratch, so no MQ_HIT_OVERFLOW is returned from this entry point. */
+ * Host-buffer form: copies in, runs, copies out, synchronises.  Reads that overflow the per-wave Match scratch or whose
+ * minimizer list outgrows its region are mapped again on the GPU with worst-case scratch, so no MQ_HIT_OVERFLOW is returned
+ * from this entry point. */
 int mq_map_batch(mq_index *idx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out);
 /* Device-resident form: all pointers are device memory on the index's device; asynchronous on `stream`
- * (a hipStream_t, may be NULL).  max_len = longest read in the batch (0 => computed on the host is not possible:
- * must be given).  No allocation happens here unless the scratch has to grow for a larger max_len / n. */
-/* A read with more Match runs than the scratch holds (MQ_MATCH_CAP, default 2048) gets status MQ_HIT_OVERFLOW here. */
-int mq_map_batch_device(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint32_t max_len,
+ * (a hipStream_t, may be NULL).  total_bases = d_offsets[n] - d_offsets[0] (the host knows it: it built the offsets); it sizes
+ * the per-read minimizer lists.  No allocation happens here once the scratch has grown to the batch shape (mq_map_reserve).
+ * A read with more Match runs than the scratch holds (MQ_MATCH_CAP, default 2048) or with a minimizer list denser than
+ * 4*density + 1/512 per base gets status MQ_HIT_OVERFLOW here (loud, never a wrong line). */
+int mq_map_batch_device(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases,
                         mq_hit *d_out, void *stream);
+
+/* THREADING CONTRACT.  The reference maps on --threads workers over one read-only index (src/closures.rs:183,187,
+ * src/index.rs:108-116).  Here: every mq_index_* / mq_map_* entry point locks the index, so calls on ONE index from several
+ * threads are safe and run one after another (they share the index's default context: one set of work counters, scratch and
+ * staging buffers).  For launch sequences in flight TOGETHER on one finalized index, give every worker thread (or every
+ * stream slot of a pipelined feeder) its own mq_ctx: a context owns a stream, work counters, Match scratch, minimizer
+ * lists, staging buffers and events, and the finalized table is only read.  One context runs one launch sequence at a time
+ * (calls on one context must not overlap; successive device-form calls must be ordered by their streams).
+ * mq_index_add_ref / mq_index_finalize must have returned before any context maps. */
+typedef struct mq_ctx mq_ctx;
+mq_ctx *mq_ctx_new(mq_index *idx);
+void mq_ctx_free(mq_ctx *ctx);
+/* mq_map_batch on this context. */
+int mq_ctx_map_batch(mq_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out);
+/* The same in two halves, for double buffering: submit queues H2D copy, kernels and D2H copy on the context's stream and
+ * returns; `out` is filled (and overflow reads redone) by mq_ctx_wait.  bases/offsets/out must stay valid until then; bases
+ * in page-locked memory (mq_host_alloc) overlaps the copy with other contexts' kernels. */
+int mq_ctx_submit(mq_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out);
+int mq_ctx_wait(mq_ctx *ctx);
+/* mq_map_batch_device on this context. */
+int mq_ctx_map_batch_device(mq_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases,
+                            mq_hit *d_out, void *stream);
+int mq_ctx_last_map_ms(mq_ctx *ctx, float *ms);
+
 /* Page-locked host memory for the buffers handed to mq_map_batch / mq_index_add_ref (a feeder that parses FASTX straight
  * into such buffers gets the full PCIe rate on the copy in; pageable buffers work too, at roughly a quarter of it). */
 void *mq_host_alloc(size_t bytes);
 void mq_host_free(void *p);
 
-/* Pre-size the per-launch scratch so that mq_map_batch_device never allocates. */
-int mq_map_reserve(mq_index *idx, uint32_t max_len);
+/* Pre-size the default context's scratch for batches of up to n_reads reads / total_bases bases, so that mq_map_batch_device
+ * never allocates. */
+int mq_map_reserve(mq_index *idx, uint32_t n_reads, uint64_t total_bases);
 
 /* Parity/debug: the k-min-mers of each sequence as KminmersIterator yields them (src/mers.rs:41-54).
  * kmm_offsets (n+1, host) gives each sequence's capacity window in `out`; counts[i] receives the true count. */
@@ -147,19 +174,21 @@ int mq_index_lookup(mq_index *idx, const uint64_t *hashes, uint32_t n, uint8_t *
 /* The format! of src/mers.rs:181 (no newline).  Returns the length or <0. */
 int mq_format_paf(const mq_index *idx, const char *q_id, uint64_t q_len, const mq_hit *hit, char *buf, size_t cap);
 
-/* Diagnostic: how many reads of the last map launch took the fast seeding path (ACGT-only, one LDS tile) and how many
+/* Diagnostic: how many reads of the last map launch took the fast seeding path (ACGT-only) and how many
  * the general streaming path.  Both produce identical results.  Synchronises on the launch. */
 int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general);
 
-/* Diagnostic builds only (env MQ_STAGE_TIMING=1 selects an instrumented kernel; its run time is never a reported number):
- * shader-clock cycles summed over all waves of the last launch in {stage A, stage B, stage C + consume, finish, chain, whole wave},
- * then {index slots visited beyond the home slot, index lookups, 100-MHz real-time ticks summed over waves}: nine values. */
-int mq_last_stage_cycles(mq_index *idx, uint64_t *cycles9);
-
 /* Measurement aid: one instrumented (slower, never timed) launch of the same batch that counts index lookups and the slots
  * visited beyond each lookup's home slot: mean probes per lookup = 1 + extra_steps / lookups (SURVEY 8d's p-bar). */
-int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint32_t max_len, mq_hit *d_out,
+int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases, mq_hit *d_out,
                        uint64_t *lookups, uint64_t *extra_steps);
+
+/* Diagnostic (tools/probe_rate.py): blocks*256 threads each probe per_thread pseudo-random (absent) keys of the finalized table;
+ * returns the kernel time, the lookups made and the slots visited beyond the home slots.  Measures the random-access rate the
+ * memory system sustains on this table, detached from the map path.  bitmap_log2 != 0: test a stand-in bitmap of 2^bitmap_log2
+ * bits (one in eight set) first, and probe the table only for keys whose bit is set (table_too) or not at all. */
+int mq_probe_rate(mq_index *idx, uint32_t blocks, uint32_t per_thread, uint32_t bitmap_log2, uint32_t table_too, float *ms,
+                  uint64_t *lookups, uint64_t *extra_steps);
 
 /* Timing of the last mq_map_batch_device launch sequence on its stream, from HIP events recorded around the
  * kernels (milliseconds).  Synchronises on the end event. */

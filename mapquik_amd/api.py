@@ -22,7 +22,8 @@ assert hit_dtype.itemsize == 40 and kminmer_dtype.itemsize == 24
 EXPORTS = ["mq_last_error", "mq_abi_version", "mq_device_count", "mq_params_default", "mq_index_new", "mq_index_free",
            "mq_index_add_ref", "mq_index_add_ref_device", "mq_index_finalize", "mq_index_get_stats", "mq_index_ref_info",
            "mq_map_batch", "mq_map_batch_device", "mq_map_reserve", "mq_kminmers_batch", "mq_index_lookup", "mq_format_paf",
-           "mq_last_map_ms", "mq_last_map_path_counts", "mq_last_stage_cycles", "mq_host_alloc", "mq_host_free", "mq_index_save", "mq_index_load", "mq_map_probe_stats"]
+           "mq_last_map_ms", "mq_last_map_path_counts", "mq_host_alloc", "mq_host_free", "mq_index_save", "mq_index_load", "mq_map_probe_stats",
+           "mq_ctx_new", "mq_ctx_free", "mq_ctx_map_batch", "mq_ctx_submit", "mq_ctx_wait", "mq_ctx_map_batch_device", "mq_ctx_last_map_ms", "mq_probe_rate"]
 
 
 class MapquikError(RuntimeError):
@@ -79,14 +80,22 @@ def load_library(path=None):
     L.mq_index_get_stats.argtypes = [vp, C.POINTER(IndexStats)]
     L.mq_index_ref_info.argtypes = [vp, u32, C.POINTER(C.c_char_p), C.POINTER(u64)]
     L.mq_map_batch.argtypes = [vp, vp, vp, u32, vp]
-    L.mq_map_batch_device.argtypes = [vp, vp, vp, u32, u32, vp, vp]
-    L.mq_map_reserve.argtypes = [vp, u32]
+    L.mq_map_batch_device.argtypes = [vp, vp, vp, u32, u64, vp, vp]
+    L.mq_map_reserve.argtypes = [vp, u32, u64]
+    L.mq_ctx_new.restype = vp
+    L.mq_ctx_new.argtypes = [vp]
+    L.mq_ctx_free.argtypes = [vp]
+    L.mq_ctx_map_batch.argtypes = [vp, vp, vp, u32, vp]
+    L.mq_ctx_submit.argtypes = [vp, vp, vp, u32, vp]
+    L.mq_ctx_wait.argtypes = [vp]
+    L.mq_ctx_map_batch_device.argtypes = [vp, vp, vp, u32, u64, vp, vp]
+    L.mq_ctx_last_map_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.mq_probe_rate.argtypes = [vp, u32, u32, u32, u32, C.POINTER(C.c_float), C.POINTER(u64), C.POINTER(u64)]
     L.mq_kminmers_batch.argtypes = [vp, vp, vp, u32, vp, vp, vp]
     L.mq_index_lookup.argtypes = [vp, vp, u32, vp, vp, vp]
     L.mq_format_paf.argtypes = [vp, C.c_char_p, u64, vp, C.c_char_p, C.c_size_t]
     L.mq_last_map_ms.argtypes = [vp, C.POINTER(C.c_float)]
-    L.mq_last_stage_cycles.argtypes = [vp, vp]
-    L.mq_map_probe_stats.argtypes = [vp, vp, vp, u32, u32, vp, C.POINTER(u64), C.POINTER(u64)]
+    L.mq_map_probe_stats.argtypes = [vp, vp, vp, u32, u64, vp, C.POINTER(u64), C.POINTER(u64)]
     L.mq_index_save.argtypes = [vp, C.c_char_p]
     L.mq_index_load.restype = vp
     L.mq_index_load.argtypes = [C.c_char_p, C.c_int]
@@ -216,15 +225,20 @@ class Index:
             raise _err(self._L, "mq_map_batch")
         return out
 
-    def map_batch_device(self, d_bases, d_offsets, n, max_len, d_out, stream=0):
-        rc = self._L.mq_map_batch_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n, max_len, C.c_void_p(d_out),
+    def map_batch_device(self, d_bases, d_offsets, n, total_bases, d_out, stream=0):
+        """find_matches for n device-resident reads; total_bases = offsets[n] - offsets[0]."""
+        rc = self._L.mq_map_batch_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n, int(total_bases), C.c_void_p(d_out),
                                          C.c_void_p(stream))
         if rc != 0:
             raise _err(self._L, "mq_map_batch_device")
 
-    def reserve(self, max_len):
-        if self._L.mq_map_reserve(self._h, max_len) != 0:
+    def reserve(self, n_reads, total_bases):
+        if self._L.mq_map_reserve(self._h, n_reads, int(total_bases)) != 0:
             raise _err(self._L, "mq_map_reserve")
+
+    def context(self):
+        """A stream slot (mq_ctx): own stream, scratch and staging; contexts of one finalized index may map concurrently."""
+        return Context(self)
 
     def last_map_ms(self):
         ms = C.c_float()
@@ -232,20 +246,20 @@ class Index:
             raise _err(self._L, "mq_last_map_ms")
         return ms.value
 
-    def last_stage_cycles(self):
-        """Diagnostic (MQ_STAGE_TIMING=1): cycles summed over waves in [A, B, C+consume, finish, chain, total]."""
-        v = np.zeros(9, dtype=np.uint64)
-        if self._L.mq_last_stage_cycles(self._h, _p(v)) != 0:
-            raise _err(self._L, "mq_last_stage_cycles")
-        return v
-
-    def probe_stats(self, d_bases, d_offsets, n, max_len, d_out):
+    def probe_stats(self, d_bases, d_offsets, n, total_bases, d_out):
         """(index lookups, slots visited beyond the home slot) of one instrumented launch: p-bar = 1 + extra / lookups."""
         a, b = C.c_uint64(), C.c_uint64()
-        if self._L.mq_map_probe_stats(self._h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n, max_len, C.c_void_p(d_out),
+        if self._L.mq_map_probe_stats(self._h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n, int(total_bases), C.c_void_p(d_out),
                                       C.byref(a), C.byref(b)) != 0:
             raise _err(self._L, "mq_map_probe_stats")
         return a.value, b.value
+
+    def probe_rate(self, blocks, per_thread, bitmap_log2=0, table_too=1):
+        """Diagnostic: (ms, lookups, extra steps) of blocks*256 threads probing per_thread random absent keys each."""
+        ms, a, b = C.c_float(), C.c_uint64(), C.c_uint64()
+        if self._L.mq_probe_rate(self._h, blocks, per_thread, bitmap_log2, table_too, C.byref(ms), C.byref(a), C.byref(b)) != 0:
+            raise _err(self._L, "mq_probe_rate")
+        return ms.value, a.value, b.value
 
     def last_map_path_counts(self):
         """(reads through the fast seeding path, reads through the general path) of the last launch."""
@@ -309,6 +323,62 @@ class Index:
             if st == MQ_HIT_MAPPED:
                 out.append(self.format_paf(name, int(offsets[i + 1] - offsets[i]), hits[i]))
         return out
+
+
+class Context:
+    """mq_ctx: one stream slot of a finalized index (the reference's per-thread worker, src/closures.rs:183,187)."""
+
+    def __init__(self, index):
+        self._L = index._L
+        self._index = index  # keeps the index alive
+        self._h = self._L.mq_ctx_new(index.handle)
+        if not self._h:
+            raise _err(self._L, "mq_ctx_new")
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mq_ctx_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def map_batch(self, bases, offsets):
+        bases = _seq(bases)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        out = np.zeros(max(n, 0), dtype=hit_dtype)
+        if n > 0 and self._L.mq_ctx_map_batch(self._h, _p(bases), _p(offsets), n, _p(out)) != 0:
+            raise _err(self._L, "mq_ctx_map_batch")
+        return out
+
+    def submit(self, bases, offsets):
+        """Queue a batch on the context's stream; wait() returns its hits."""
+        bases = _seq(bases)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        out = np.zeros(max(n, 0), dtype=hit_dtype)
+        if n > 0 and self._L.mq_ctx_submit(self._h, _p(bases), _p(offsets), n, _p(out)) != 0:
+            raise _err(self._L, "mq_ctx_submit")
+        self._keep = (bases, offsets, out)
+
+    def wait(self):
+        if self._L.mq_ctx_wait(self._h) != 0:
+            raise _err(self._L, "mq_ctx_wait")
+        out = self._keep[2] if self._keep else np.zeros(0, dtype=hit_dtype)
+        self._keep = None
+        return out
+
+    def map_batch_device(self, d_bases, d_offsets, n, total_bases, d_out, stream=0):
+        if self._L.mq_ctx_map_batch_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n, int(total_bases), C.c_void_p(d_out),
+                                           C.c_void_p(stream)) != 0:
+            raise _err(self._L, "mq_ctx_map_batch_device")
+
+    def last_map_ms(self):
+        ms = C.c_float()
+        if self._L.mq_ctx_last_map_ms(self._h, C.byref(ms)) != 0:
+            raise _err(self._L, "mq_ctx_last_map_ms")
+        return ms.value
 
 
 def ref_extract(ref_idx, inp_seq_raw, params, mers_index, name=None):

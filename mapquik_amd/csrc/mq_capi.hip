@@ -7,124 +7,344 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
 #include "mq_device.hpp"
-#include "mq_fast.hpp"
+#include "mq_seed.hpp"
 
 using namespace mq;
 
 // =================================================================== kernels
 
-// Fused hot path: one wave per read; 4 waves per workgroup share the look-up tables; persistent waves pull read indices
-// from an atomic counter.  CH: lanes per chunk in the chain stage (64 in production).  FAST=false forces the general path.
-struct MapArgs {
+// The map path.  One wave per read, persistent waves pulling read indices from an atomic counter.  Two phases per read:
+//   seed   read -> ordered minimizer list {hash, raw position} in the read's HBM region     (mq_seed.hpp for ACGT-only reads,
+//          the general streaming seeder seed_segment of mq_device.hpp for the rest)
+//   map    list -> k-min-mers -> index probe -> Match runs -> chain -> mq_hit                (MapSink, chain_stage)
+// map_kernel runs both phases back to back in the same wave (default): while one wave waits for its index probes (random
+// 32-B slot reads: ~42 G lookups/s is all the memory system gives, tools/probe_rate.py) the other waves of the SIMD seed.
+// MQ_PIPELINE=split runs the phases as three launches (seed_reads_kernel, seed_general_kernel, map_lists_kernel) so that a
+// profiler prices each phase by itself; same device functions, same results.
+// Read r's list lives at entries [base_r, base_r + cap_r) of mz_hash[] / mz_pos[]:
+//   base_r = ((o0_r - o0_0) * f16 >> 16) + slack * r,   cap_r = (len_r * f16 >> 16) + slack
+// (regions never overlap; f16/65536 = list entries reserved per base).  A list that outgrows its region (a read inside a
+// short-period tandem array can be far denser than 2 d) is written again, at its now known size, into an exact-size region
+// taken from a shared pool behind the regular regions.  Only when the pool is exhausted too does the read come back as
+// MQ_HIT_OVERFLOW (the host-buffer entry points then redo it with f16 = 65536).
+struct SplitArgs {
     const uint8_t *bases;
     const uint64_t *offsets;
     uint32_t n;
     DevParams P;
+    unsigned long long *mz_hash;
+    uint32_t *mz_pos;
+    uint32_t *mz_count;    // split pipeline only: list length of read r (or NOT_FAST / LIST_OVERFLOW)
+    uint64_t *mz_base;     // split pipeline only: where read r's list starts (its regular region or a pool region)
+    uint64_t pool_base, pool_cap;  // the pool: entries [pool_base, pool_base + pool_cap)
+    uint32_t f16, slack;
+    uint32_t *queue;       // split pipeline only: reads for the general seeder
+    uint32_t *counters;    // [0] seed work, [1] map work, [2] queue length, [3] general work, [4] fast reads, [5] general reads,
+                           // [6] lists moved to the pool, [12..13] 64-bit pool cursor
+    uint32_t force_general;
     const Slot *table;
     uint64_t mask;
     const uint64_t *ref_lens;
-    MatchRec *scratch_all;   // per wave: cap_matches records
+    MatchRec *scratch_all;  // per mapping wave: cap_matches records
     uint32_t cap_matches;
-    uint8_t *fast_scratch;   // per wave: FAST_EM_BYTES + FAST_HM_WORDS*4
-    uint32_t *work_counter;
     mq_hit *out;
     mq_kminmer *dump;
     const uint64_t *dump_off;
     uint32_t *dump_counts;
-    uint32_t *stats;         // [0] reads through the fast path, [1] through the general path
-    uint32_t stop_after;     // diagnostic (MQ_STOP_AFTER): 0 = run everything; 1/2/3 = stop a read after stage A / B / gather
+    unsigned long long *stats64;  // instrumented launch only: [0] slots visited beyond the home slot, [1] lookups
 };
 
-constexpr int MAP_WAVES = 4;
+__device__ __forceinline__ void list_region(const SplitArgs &A, uint64_t o0_rel, uint64_t len, uint32_t r, uint64_t &base, uint32_t &cap) {
+    base = ((o0_rel * A.f16) >> 16) + (uint64_t)A.slack * r;
+    const uint64_t c = ((len * A.f16) >> 16) + A.slack;
+    cap = c > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)c;
+}
+constexpr uint32_t LIST_OVERFLOW = 0xFFFFFFFEu;  // list length value: the list fits neither its region nor the pool
+// an exact-size pool region for a list of cnt entries (wave-uniform); false when the pool is exhausted
+__device__ __forceinline__ bool pool_take(const SplitArgs &A, uint32_t cnt, uint64_t &base) {
+    unsigned long long at = 0;
+    if (lane_id() == 0) at = atomicAdd(reinterpret_cast<unsigned long long *>(A.counters + 12), (unsigned long long)cnt);
+    at = rdlane64(at, 0);
+    base = A.pool_base + at;
+    return at + cnt <= A.pool_cap;
+}
 
-#ifndef MQ_MIN_WAVES
-#define MQ_MIN_WAVES 4
+// seed phase, fast seeder: list length, SD_NOT_FAST (declined: non-ACGT byte, ...) or LIST_OVERFLOW; base moves with the list
+__device__ __forceinline__ uint32_t seed_read_fast(const SplitArgs &A, const SeedTables &T, SeedLds &S, const uint8_t *seq,
+                                                   uint32_t len, uint64_t &base, uint32_t cap, uint32_t &n_moved) {
+    uint32_t cnt = seed_sequence_fast(seq, len, A.P, T, S, A.mz_hash + base, A.mz_pos + base, cap);
+    if (cnt != SD_NOT_FAST && cnt > cap) {  // denser than its region: once more, into an exact-size pool region
+        if (pool_take(A, cnt, base)) {
+            seed_sequence_fast(seq, len, A.P, T, S, A.mz_hash + base, A.mz_pos + base, cnt);
+            n_moved++;
+        } else {
+            cnt = LIST_OVERFLOW;
+        }
+    }
+    return cnt;
+}
+
+// seed phase, general streaming seeder (any bytes, any length)
+__device__ __forceinline__ uint32_t seed_read_general(const SplitArgs &A, WaveLds &S, const uint8_t *seq, uint64_t len, uint64_t &base,
+                                                      uint32_t cap, uint32_t &n_moved) {
+    uint32_t cnt;
+    {
+        SoaListSink sink(A.mz_hash + base, A.mz_pos + base, cap);
+        uint32_t mz_count = 0;
+        seed_segment(seq, len, 0, len, A.P, S, sink, mz_count);
+        cnt = sink.written;
+    }
+    if (cnt > cap) {
+        if (pool_take(A, cnt, base)) {
+            SoaListSink sink(A.mz_hash + base, A.mz_pos + base, cnt);
+            uint32_t mz_count = 0;
+            seed_segment(seq, len, 0, len, A.P, S, sink, mz_count);
+            n_moved++;
+        } else {
+            cnt = LIST_OVERFLOW;
+        }
+    }
+    return cnt;
+}
+
+constexpr int ML_NB = 4;                               // lane-batches of 64 k-min-mers hashed and probed together
+constexpr uint32_t ML_LIST_CAP = 64 * ML_NB + MAX_K;   // minimizers staged in LDS at a time
+struct MapListLds {
+    unsigned long long h[ML_LIST_CAP];
+    uint32_t p[ML_LIST_CAP];
+};
+
+// map phase of read r: its list (cnt entries at base) -> mq_hit
+template <int CH, bool TIMING>
+__device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, MatchRec *scratch, uint32_t r, uint64_t len, uint32_t cnt,
+                                         uint64_t base, unsigned long long &t_steps, unsigned long long &t_lookups) {
+    const uint32_t lane = lane_id();
+    const DevParams &P = A.P;
+    mq_hit h;
+    h.status = MQ_HIT_UNMAPPED;
+    h.ref_id = h.rc = h.mapq = h.q_start = h.q_end = h.r_start = h.r_end = h.score = h.n_kminmers = 0;
+    uint32_t n_kmm = 0;
+    if (cnt == LIST_OVERFLOW) {
+        h.status = MQ_HIT_OVERFLOW;  // the list fits neither its region nor the pool: nothing was computed for this read
+    } else if (cnt >= P.k) {
+        mq_kminmer *d = nullptr;
+        uint32_t dcap = 0;
+        if (A.dump) {
+            d = A.dump + A.dump_off[r];
+            dcap = (uint32_t)(A.dump_off[r + 1] - A.dump_off[r]);
+        }
+        MapSink sink(A.table, A.mask, P, scratch, A.cap_matches, d, dcap);
+        const unsigned long long *lh = A.mz_hash + base;
+        const uint32_t *lp = A.mz_pos + base;
+        const uint32_t chunk = 64u * (uint32_t)ML_NB + P.k - 1u;
+        for (uint32_t g = 0; g + P.k <= cnt;) {
+            const uint32_t have = cnt - g < chunk ? cnt - g : chunk;
+            for (uint32_t i = lane; i < have; i += 64u) {  // L2-served loads: the list may have been written by this very wave
+                S.h[i] = ld_sc1_u64(lh + g + i);
+                S.p[i] = ld_sc1_u32(lp + g + i);
+            }
+            wave_sync();
+            sink.template consume_list<ML_NB>(S.h, S.p, have);
+            wave_sync();
+            g += have - (P.k - 1u);
+        }
+        sink.finish_runs();
+        n_kmm = sink.kmm_count;
+        if (sink.n_matches > A.cap_matches) {
+            h.status = MQ_HIT_OVERFLOW;
+        } else if (sink.n_matches > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Match records written by this wave are in L2
+            wave_sync();
+            chain_stage<CH>(scratch, sink.n_matches, P, len, A.ref_lens, h);
+        }
+        if (TIMING) {
+            t_steps += wave_sum_u32(sink.probe_steps);
+            t_lookups += n_kmm;
+        }
+    }
+    h.n_kminmers = n_kmm;
+    if (lane == 0) {
+        A.out[r] = h;
+        if (A.dump_counts) A.dump_counts[r] = n_kmm;
+    }
+}
+
+#ifndef MQ_MAP_WAVES
+#define MQ_MAP_WAVES 4
 #endif
-template <int CH, bool FAST, bool TIMING = false>
-__global__ __launch_bounds__(64 * MAP_WAVES, MQ_MIN_WAVES) void map_kernel(const MapArgs A) {
-    __shared__ WgTables T;
-    __shared__ WaveLds SS[MAP_WAVES];
-    build_tables(T, A.P.l);
+#ifndef MQ_MAP_MIN_WAVES
+#define MQ_MAP_MIN_WAVES 4
+#endif
+constexpr int MAP_WAVES = MQ_MAP_WAVES;
+
+// per-wave LDS of the fused kernel: the phases of one read follow each other, so they share the memory
+union MapWaveLds {
+    SeedLds seed;
+    WaveLds general;
+    MapListLds map;
+};
+
+// CH: lanes per chunk in the chain stage (64 in production; 4 only in tests so that ordinary reads take the multi-chunk path)
+template <int CH, bool TIMING = false>
+__global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(const SplitArgs A) {
+    __shared__ SeedTables T;
+    __shared__ MapWaveLds SS[MAP_WAVES];
+    build_seed_tables(T, A.P.l);
     __syncthreads();  // the only workgroup-wide rendezvous; waves are independent from here on
     const uint32_t lane = lane_id();
-    const uint32_t wv = threadIdx.x >> 6;
-    WaveLds &S = SS[wv];
+    const uint32_t wv = rdfirst(threadIdx.x >> 6);  // wave-uniform: per-wave bases stay in SGPRs
+    MapWaveLds &S = SS[wv];
     const size_t wave_gid = (size_t)blockIdx.x * MAP_WAVES + wv;
     MatchRec *scratch = A.scratch_all + wave_gid * A.cap_matches;
-    uint8_t *fs = A.fast_scratch + wave_gid * (size_t)(FAST_EM_BYTES + FAST_HM_WORDS * 4u);
-    uint4 *em = reinterpret_cast<uint4 *>(fs);
-    uint32_t *hm = reinterpret_cast<uint32_t *>(fs + FAST_EM_BYTES);
     const DevParams &P = A.P;
-    uint32_t n_fast = 0, n_general = 0;
-    unsigned long long tacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // diagnostic build only: cycles in A, B, C(+consume), finish, chain, total; extra probe steps; lookups
-    const unsigned long long t_begin = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
-    const unsigned long long r_begin = TIMING ? __builtin_amdgcn_s_memrealtime() : 0ull;  // 100 MHz
+    const uint64_t o_base = A.offsets[0];
+    uint32_t n_fast = 0, n_general = 0, n_moved = 0;
+    unsigned long long t_steps = 0, t_lookups = 0;
     for (;;) {
         uint32_t r = 0;
-        if (lane == 0) r = atomicAdd(A.work_counter, 1u);
+        if (lane == 0) r = atomicAdd(&A.counters[0], 1u);
         r = rdfirst(r);
         if (r >= A.n) break;
         const uint64_t o0 = A.offsets[r], o1 = A.offsets[r + 1];
         const uint64_t len = o1 - o0;
-        mq_hit h;
-        h.status = MQ_HIT_UNMAPPED;
-        h.ref_id = h.rc = h.mapq = h.q_start = h.q_end = h.r_start = h.r_end = h.score = h.n_kminmers = 0;
-        uint32_t n_kmm = 0;
+        uint32_t cnt = 0;
+        uint64_t base = 0;
         // extract(): len < l + k - 1 => None (src/mers.rs:44)
         if (len >= (uint64_t)P.l + P.k - 1u) {
-            mq_kminmer *d = nullptr;
-            uint32_t dcap = 0;
-            if (A.dump) {
-                d = A.dump + A.dump_off[r];
-                dcap = (uint32_t)(A.dump_off[r + 1] - A.dump_off[r]);
-            }
-            MapSink sink(A.table, A.mask, P, scratch, A.cap_matches, d, dcap);
-            uint32_t mz_count = 0;
-            bool done = false;
-            if (FAST) done = fast_seed_sequence<MapSink, TIMING>(A.bases + o0, (uint32_t)len, P, T, S, sink, mz_count, em, hm, tacc, A.stop_after);
-            if (done) n_fast++;
-            else {
+            uint32_t cap;
+            list_region(A, o0 - o_base, len, r, base, cap);
+            cnt = A.force_general ? SD_NOT_FAST : seed_read_fast(A, T, S.seed, A.bases + o0, (uint32_t)len, base, cap, n_moved);
+            if (cnt == SD_NOT_FAST) {
                 n_general++;
-                seed_segment(A.bases + o0, len, 0, len, P, S, sink, mz_count);
-            }
-            const unsigned long long t_f0 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
-            sink.finish(S, mz_count);
-            n_kmm = sink.kmm_count;
-            const unsigned long long t_f1 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
-            tacc[3] += t_f1 - t_f0;
-            if (sink.n_matches > A.cap_matches) {
-                h.status = MQ_HIT_OVERFLOW;
-            } else if (sink.n_matches > 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Match records written by this wave are in L2
                 wave_sync();
-                chain_stage<CH>(scratch, sink.n_matches, P, len, A.ref_lens, h);
+                cnt = seed_read_general(A, S.general, A.bases + o0, len, base, cap, n_moved);
+            } else {
+                n_fast++;
             }
-            if (TIMING) {
-                tacc[4] += __builtin_amdgcn_s_memtime() - t_f1;
-                tacc[6] += wave_sum_u32(sink.probe_steps);
-                tacc[7] += n_kmm;
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have reached L2
+            wave_sync();
         }
-        h.n_kminmers = n_kmm;
+        map_read<CH, TIMING>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups);
+        wave_sync();
+    }
+    if (lane == 0) {
+        if (n_fast) atomicAdd(&A.counters[4], n_fast);
+        if (n_general) atomicAdd(&A.counters[5], n_general);
+        if (n_moved) atomicAdd(&A.counters[6], n_moved);
+        if (TIMING) {
+            atomicAdd(&A.stats64[0], t_steps);
+            atomicAdd(&A.stats64[1], t_lookups);
+        }
+    }
+}
+
+// ------------------------------------------------------------------- the same phases as separate launches (MQ_PIPELINE=split)
+#ifndef MQ_SEED_MIN_WAVES
+#define MQ_SEED_MIN_WAVES 4
+#endif
+constexpr int SEED_WAVES = 4;
+
+__global__ __launch_bounds__(64 * SEED_WAVES, MQ_SEED_MIN_WAVES) void seed_reads_kernel(const SplitArgs A) {
+    __shared__ SeedTables T;
+    __shared__ SeedLds SS[SEED_WAVES];
+    build_seed_tables(T, A.P.l);
+    __syncthreads();
+    const uint32_t lane = lane_id();
+    const uint32_t wv = rdfirst(threadIdx.x >> 6);  // wave-uniform: per-wave bases stay in SGPRs
+    SeedLds &S = SS[wv];
+    const size_t wave_gid = (size_t)blockIdx.x * SEED_WAVES + wv;
+    const DevParams &P = A.P;
+    const uint64_t o_base = A.offsets[0];
+    uint32_t n_fast = 0, n_general = 0, n_moved = 0;
+    for (;;) {
+        uint32_t r = 0;
+        if (lane == 0) r = atomicAdd(&A.counters[0], 1u);
+        r = rdfirst(r);
+        if (r >= A.n) break;
+        const uint64_t o0 = A.offsets[r], o1 = A.offsets[r + 1];
+        const uint64_t len = o1 - o0;
+        uint32_t cnt = 0;
+        uint64_t base = 0;
+        if (len >= (uint64_t)P.l + P.k - 1u) {
+            uint32_t cap;
+            list_region(A, o0 - o_base, len, r, base, cap);
+            cnt = A.force_general ? SD_NOT_FAST : seed_read_fast(A, T, S, A.bases + o0, (uint32_t)len, base, cap, n_moved);
+            if (cnt == SD_NOT_FAST) n_general++;
+            else n_fast++;
+        }
         if (lane == 0) {
-            A.out[r] = h;
-            if (A.dump_counts) A.dump_counts[r] = n_kmm;
+            A.mz_count[r] = cnt;
+            A.mz_base[r] = base;
+            if (cnt == SD_NOT_FAST) A.queue[atomicAdd(&A.counters[2], 1u)] = r;
         }
         wave_sync();
     }
-    if (A.stats && lane == 0) {
-        if (n_fast) atomicAdd(&A.stats[0], n_fast);
-        if (n_general) atomicAdd(&A.stats[1], n_general);
-        if (TIMING) {
-            tacc[5] = __builtin_amdgcn_s_memtime() - t_begin;
-            tacc[8] = __builtin_amdgcn_s_memrealtime() - r_begin;
-            unsigned long long *ts = reinterpret_cast<unsigned long long *>(A.stats + 2);
-            for (int i = 0; i < 9; ++i) atomicAdd(&ts[i], tacc[i]);
+    if (lane == 0) {
+        if (n_fast) atomicAdd(&A.counters[4], n_fast);
+        if (n_general) atomicAdd(&A.counters[5], n_general);
+        if (n_moved) atomicAdd(&A.counters[6], n_moved);
+    }
+}
+
+// the reads queued by seed_reads_kernel, through the general streaming seeder
+__global__ __launch_bounds__(64) void seed_general_kernel(const SplitArgs A) {
+    __shared__ WaveLds S;
+    const uint32_t lane = lane_id();
+    const uint32_t nq = A.counters[2];
+    const uint64_t o_base = A.offsets[0];
+    uint32_t n_moved = 0;
+    for (;;) {
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(&A.counters[3], 1u);
+        i = rdfirst(i);
+        if (i >= nq) break;
+        const uint32_t r = A.queue[i];
+        const uint64_t o0 = A.offsets[r], o1 = A.offsets[r + 1];
+        const uint64_t len = o1 - o0;
+        uint64_t base;
+        uint32_t cap;
+        list_region(A, o0 - o_base, len, r, base, cap);
+        const uint32_t cnt = seed_read_general(A, S, A.bases + o0, len, base, cap, n_moved);
+        if (lane == 0) {
+            A.mz_count[r] = cnt;
+            A.mz_base[r] = base;
         }
+        wave_sync();
+    }
+    if (lane == 0 && n_moved) atomicAdd(&A.counters[6], n_moved);
+}
+
+#ifndef MQ_ML_MIN_WAVES
+#define MQ_ML_MIN_WAVES 8
+#endif
+constexpr int ML_WAVES = 4;
+
+template <int CH, bool TIMING = false>
+__global__ __launch_bounds__(64 * ML_WAVES, MQ_ML_MIN_WAVES) void map_lists_kernel(const SplitArgs A) {
+    __shared__ MapListLds SS[ML_WAVES];
+    const uint32_t lane = lane_id();
+    const uint32_t wv = rdfirst(threadIdx.x >> 6);  // wave-uniform: per-wave bases stay in SGPRs
+    const size_t wave_gid = (size_t)blockIdx.x * ML_WAVES + wv;
+    MatchRec *scratch = A.scratch_all + wave_gid * A.cap_matches;
+    unsigned long long t_steps = 0, t_lookups = 0;
+    for (;;) {
+        uint32_t r = 0;
+        if (lane == 0) r = atomicAdd(&A.counters[1], 1u);
+        r = rdfirst(r);
+        if (r >= A.n) break;
+        const uint64_t len = A.offsets[r + 1] - A.offsets[r];
+        map_read<CH, TIMING>(A, SS[wv], scratch, r, len, A.mz_count[r], A.mz_base[r], t_steps, t_lookups);
+        wave_sync();
+    }
+    if (TIMING && lane == 0) {
+        atomicAdd(&A.stats64[0], t_steps);
+        atomicAdd(&A.stats64[1], t_lookups);
     }
 }
 
@@ -238,6 +458,60 @@ __global__ void lookup_kernel(const Slot *__restrict__ table, uint64_t mask, con
     ref_ids[i] = hit ? (e.id_rc >> 1) : 0;
 }
 
+// Diagnostic (tools/probe_rate.py): how many random index probes per second the memory system sustains, detached from
+// everything else the map path does.  Every thread looks up `per_thread` pseudo-random keys (absent with probability ~1,
+// like ~85 % of a read's k-min-mers), `ilp` home-slot loads in flight per thread.
+__global__ void probe_rate_kernel(const Slot *__restrict__ table, uint64_t mask, uint32_t per_thread, uint64_t seed,
+                                  unsigned long long *__restrict__ acc, const uint32_t *__restrict__ bitmap, uint64_t bit_mask,
+                                  uint32_t table_too) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long found = 0, steps = 0;
+    auto mix = [](uint64_t z) {
+        z += 0x9e3779b97f4a7c15ULL;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+        return z ^ (z >> 31);
+    };
+    for (uint32_t j = 0; j < per_thread; j += 4) {
+        uint64_t key[4];
+        unsigned long long k0[4];
+        uint32_t bw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            key[u] = mix(seed + tid * per_thread + j + u) | 1ull;
+            if (bitmap) bw[u] = bitmap[(key[u] & bit_mask) >> 5];
+            else k0[u] = table[key[u] & mask].key;
+        }
+        if (bitmap) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool maybe = (bw[u] >> (key[u] & 31u)) & 1u;
+                found += maybe;
+                k0[u] = (maybe && table_too) ? table[key[u] & mask].key : 0ull;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint64_t sl = key[u] & mask;
+            unsigned long long k = k0[u];
+            while (k != 0 && k != key[u]) {
+                sl = (sl + 1) & mask;
+                k = table[sl].key;
+                steps++;
+            }
+            if (k == key[u]) found += table[sl].count;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        found += __shfl_xor(found, d, 64);
+        steps += __shfl_xor(steps, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&acc[0], found);
+        atomicAdd(&acc[1], steps);
+    }
+}
+
 // =================================================================== host side
 
 static thread_local std::string g_err;
@@ -255,6 +529,45 @@ static int set_err(int code, const std::string &msg) {
         }                                                                                                         \
     } while (0)
 
+struct mq_index;
+
+// One stream slot: everything a map launch sequence writes (work counters, Match scratch, minimizer lists, seeder spill,
+// events) plus the staging buffers of the host-buffer entry points.  Launch sequences of DIFFERENT contexts of one index
+// may be in flight together (the index itself is read-only once finalized); one context runs one sequence at a time.
+struct mq_ctx {
+    mq_index *idx = nullptr;
+    hipStream_t stream = nullptr;   // the context's own stream (host-buffer entry points)
+    uint32_t *d_counter = nullptr;  // 64 words: SplitArgs::counters; [8..11] two 64-bit probe statistics of an instrumented launch
+    MatchRec *scratch = nullptr;    // per mapping wave: cap_matches records
+    unsigned long long *mz_hash = nullptr;
+    uint32_t *mz_pos = nullptr;
+    uint64_t mz_cap = 0;            // list entries allocated
+    uint32_t *mz_count = nullptr;
+    uint64_t *mz_base = nullptr;
+    uint32_t *queue = nullptr;
+    uint64_t reads_cap = 0;
+    uint64_t pool_base = 0, pool_cap = 0;  // of the last ctx_ensure: the pool behind the regular list regions
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    // staging for the host-buffer entry points
+    uint8_t *st_bases = nullptr;
+    uint64_t st_bases_cap = 0;
+    uint64_t *st_off = nullptr;
+    uint64_t st_off_cap = 0;
+    mq_hit *st_out = nullptr;
+    uint64_t st_out_cap = 0;
+    uint64_t *h_off = nullptr;      // page-locked: relative offsets on their way to the device
+    uint64_t h_off_cap = 0;
+    mq_hit *h_out = nullptr;        // page-locked: hits on their way back
+    uint64_t h_out_cap = 0;
+    // a submitted, not yet waited-for batch
+    bool pending = false;
+    const uint8_t *p_bases = nullptr;
+    const uint64_t *p_offsets = nullptr;
+    uint32_t p_n = 0;
+    mq_hit *p_out = nullptr;
+};
+
 struct KmmChunk {
     RefKmm *d = nullptr;
     uint64_t n = 0;
@@ -265,6 +578,7 @@ struct mq_index {
     DevParams dp;
     int device = 0;
     int n_cu = 0;
+    std::mutex mu;  // serialises the index-level entry points (add_ref, finalize, and everything that uses the default context)
     std::map<uint32_t, std::pair<std::string, uint64_t>> refs;
     std::vector<KmmChunk> chunks;
     uint64_t n_kmm_total = 0;
@@ -273,26 +587,14 @@ struct mq_index {
     uint64_t nslots = 0;
     uint64_t *d_ref_lens = nullptr;
     uint64_t n_unique = 0, n_keys = 0;
-    // map scratch
-    MatchRec *scratch = nullptr;
+    // launch geometry (workgroups) and scratch sizes, fixed at the first map call
+    uint32_t grid_fused = 0, grid_seed = 0, grid_map = 0;  // map_kernel; seed_reads_kernel, map_lists_kernel (split)
     uint32_t cap_matches = 0;
-    uint32_t grid = 0;
-    uint32_t *d_counter = nullptr;  // [0] work counter, [1] fast-path reads, [2] general-path reads
-    uint8_t *fast_scratch = nullptr;
+    bool split = false;             // diagnostic MQ_PIPELINE=split: the two phases as separate launches (a profiler then prices each)
     bool force_general = false;     // test hook MQ_FORCE_GENERAL=1: never take the fast seeding path
-    uint32_t stop_after = 0;        // diagnostic MQ_STOP_AFTER (instruction-count attribution; results are NOT valid)
     bool timing_once = false;       // set by mq_map_probe_stats for one instrumented launch
-    bool stage_timing = false;      // diagnostic MQ_STAGE_TIMING=1: s_memtime stamps per stage (never for reported numbers)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_valid = false;
-    // staging for the host-buffer entry points
-    uint8_t *st_bases = nullptr;
-    uint64_t st_bases_cap = 0;
-    uint64_t *st_off = nullptr;
-    uint64_t st_off_cap = 0;
-    mq_hit *st_out = nullptr;
-    uint64_t st_out_cap = 0;
-    int chain_chunk = 64;  // test hook: MQ_CHAIN_CHUNK=4 exercises the multi-chunk chain path
+    int chain_chunk = 64;           // test hook: MQ_CHAIN_CHUNK=4 exercises the multi-chunk chain path
+    mq_ctx *def_ctx = nullptr;      // the context behind the index-level map entry points
 };
 
 extern "C" {
@@ -347,32 +649,148 @@ static int alloc_table(mq_index *idx, uint64_t nslots) {
     return MQ_OK;
 }
 
-static int ensure_scratch(mq_index *idx, uint32_t max_len) {
-    (void)max_len;
-    if (!idx->d_counter) HIPCHK(hipMalloc((void **)&idx->d_counter, 128));
-    if (!idx->ev0) {
-        HIPCHK(hipEventCreate(&idx->ev0));
-        HIPCHK(hipEventCreate(&idx->ev1));
-    }
-    if (!idx->grid) {
-        int occ = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, map_kernel<64, true>, 64 * MAP_WAVES, 0));
+template <class T>
+static int grow(T *&p, uint64_t &cap, uint64_t need) {
+    if (need <= cap) return MQ_OK;
+    if (p) HIPCHK(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    uint64_t nc = need + need / 4 + 64;
+    HIPCHK(hipMalloc((void **)&p, nc * sizeof(T)));
+    cap = nc;
+    return MQ_OK;
+}
+template <class T>
+static int grow_pinned(T *&p, uint64_t &cap, uint64_t need) {
+    if (need <= cap) return MQ_OK;
+    if (p) HIPCHK(hipHostFree(p));
+    p = nullptr;
+    cap = 0;
+    uint64_t nc = need + need / 4 + 64;
+    HIPCHK(hipHostMalloc((void **)&p, nc * sizeof(T), hipHostMallocDefault));
+    cap = nc;
+    return MQ_OK;
+}
+
+// launch geometry: persistent waves, as many workgroups as stay resident
+static int ensure_geometry(mq_index *idx) {
+    if (idx->grid_seed) return MQ_OK;
+    auto occ_of = [&](const void *fn, int threads, int &occ) -> int {
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, threads, 0));
         if (occ < 1) occ = 1;
         if (occ > 8) occ = 8;
         const char *oe = getenv("MQ_OCC");  // diagnostic: cap workgroups per CU
         if (oe && atoi(oe) >= 1 && atoi(oe) < occ) occ = atoi(oe);
-        idx->grid = (uint32_t)(occ * idx->n_cu);  // workgroups; MAP_WAVES persistent waves each
-    }
-    const size_t n_waves = (size_t)idx->grid * MAP_WAVES;
-    if (!idx->scratch) {
-        // Match runs per read held in HBM scratch; a read with more runs is reported MQ_HIT_OVERFLOW (never silently wrong)
-        const char *e = getenv("MQ_MATCH_CAP");
-        idx->cap_matches = e ? (uint32_t)strtoul(e, nullptr, 10) : 2048u;
-        if (idx->cap_matches < 1) idx->cap_matches = 1;
-        HIPCHK(hipMalloc((void **)&idx->scratch, n_waves * idx->cap_matches * sizeof(MatchRec)));
-    }
-    if (!idx->fast_scratch) HIPCHK(hipMalloc((void **)&idx->fast_scratch, n_waves * (size_t)(FAST_EM_BYTES + FAST_HM_WORDS * 4u)));
+        return MQ_OK;
+    };
+    int occ = 0, rc;
+    if ((rc = occ_of((const void *)map_kernel<64, false>, 64 * MAP_WAVES, occ))) return rc;
+    idx->grid_fused = (uint32_t)(occ * idx->n_cu);
+    if ((rc = occ_of((const void *)seed_reads_kernel, 64 * SEED_WAVES, occ))) return rc;
+    idx->grid_seed = (uint32_t)(occ * idx->n_cu);
+    if ((rc = occ_of((const void *)map_lists_kernel<64, false>, 64 * ML_WAVES, occ))) return rc;
+    idx->grid_map = (uint32_t)(occ * idx->n_cu);
+    // Match runs per read held in HBM scratch; a read with more runs is reported MQ_HIT_OVERFLOW (never silently wrong)
+    const char *e = getenv("MQ_MATCH_CAP");
+    idx->cap_matches = e ? (uint32_t)strtoul(e, nullptr, 10) : 2048u;
+    if (idx->cap_matches < 1) idx->cap_matches = 1;
     return MQ_OK;
+}
+
+// list entries reserved per base, in 1/65536: 4 d + 1/512 -- canonical selection keeps 1-(1-d)^2 ~ 2 d of the l-mers, so this
+// is at least twice the expected count (2.6 times under homopolymer compression); denser lists take the overflow redo
+static uint32_t list_f16(const mq_index *idx) {
+    double d = idx->params.density;
+    if (!(d > 0)) d = 0;
+    double f = 4.0 * d + 1.0 / 512.0;
+    if (f > 1.0) f = 1.0;
+    const char *e = getenv("MQ_LIST_F16");  // test hook: force list-region overflows
+    if (e && atoi(e) >= 0) return (uint32_t)std::min(65536, atoi(e));
+    return (uint32_t)std::ceil(f * 65536.0);
+}
+constexpr uint32_t LIST_SLACK = 64;
+
+static int ctx_ensure(mq_ctx *c, uint32_t n, uint64_t total_bases, uint32_t f16) {
+    mq_index *idx = c->idx;
+    int rc = ensure_geometry(idx);
+    if (rc) return rc;
+    if (!c->d_counter) HIPCHK(hipMalloc((void **)&c->d_counter, 256));
+    if (!c->ev0) {
+        HIPCHK(hipEventCreate(&c->ev0));
+        HIPCHK(hipEventCreate(&c->ev1));
+    }
+    if (!c->scratch) {
+        const size_t n_waves = std::max((size_t)idx->grid_fused * MAP_WAVES, (size_t)idx->grid_map * ML_WAVES);
+        HIPCHK(hipMalloc((void **)&c->scratch, n_waves * idx->cap_matches * sizeof(MatchRec)));
+    }
+    if (n > c->reads_cap) {
+        if (c->mz_count) HIPCHK(hipFree(c->mz_count));
+        if (c->mz_base) HIPCHK(hipFree(c->mz_base));
+        if (c->queue) HIPCHK(hipFree(c->queue));
+        c->mz_count = c->queue = nullptr;
+        c->mz_base = nullptr;
+        c->reads_cap = 0;
+        const uint64_t nc = (uint64_t)n + n / 4 + 64;
+        HIPCHK(hipMalloc((void **)&c->mz_count, nc * 4));
+        HIPCHK(hipMalloc((void **)&c->mz_base, nc * 8));
+        HIPCHK(hipMalloc((void **)&c->queue, nc * 4));
+        c->reads_cap = nc;
+    }
+    // regular regions, then the pool for lists denser than their region (an eighth of the regular space, at least 1 M entries)
+    const uint64_t regular = ((total_bases * f16) >> 16) + (uint64_t)LIST_SLACK * n + 64;
+    const uint64_t pool = f16 >= 65536u ? 0 : std::max<uint64_t>(regular / 8, 1ull << 20);
+    const uint64_t need = regular + pool;
+    c->pool_base = regular;
+    c->pool_cap = pool;
+    if (need > c->mz_cap) {
+        if (c->mz_hash) HIPCHK(hipFree(c->mz_hash));
+        if (c->mz_pos) HIPCHK(hipFree(c->mz_pos));
+        c->mz_hash = nullptr;
+        c->mz_pos = nullptr;
+        c->mz_cap = 0;
+        const uint64_t nc = need + need / 8;
+        HIPCHK(hipMalloc((void **)&c->mz_hash, nc * 8));
+        HIPCHK(hipMalloc((void **)&c->mz_pos, nc * 4));
+        c->mz_cap = nc;
+    }
+    return MQ_OK;
+}
+
+static void ctx_release(mq_ctx *c) {
+    if (!c) return;
+    if (c->stream) hipStreamSynchronize(c->stream);
+    hipFree(c->d_counter);
+    hipFree(c->scratch);
+    hipFree(c->mz_hash);
+    hipFree(c->mz_pos);
+    hipFree(c->mz_count);
+    hipFree(c->mz_base);
+    hipFree(c->queue);
+    hipFree(c->st_bases);
+    hipFree(c->st_off);
+    hipFree(c->st_out);
+    if (c->h_off) hipHostFree(c->h_off);
+    if (c->h_out) hipHostFree(c->h_out);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static mq_ctx *ctx_create(mq_index *idx) {
+    mq_ctx *c = new (std::nothrow) mq_ctx();
+    if (!c) {
+        set_err(MQ_ENOMEM, "out of host memory");
+        return nullptr;
+    }
+    c->idx = idx;
+    if (hipSetDevice(idx->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_err(MQ_EHIP, "hipStreamCreate failed");
+        c->stream = nullptr;
+        ctx_release(c);
+        return nullptr;
+    }
+    return c;
 }
 
 extern "C" {
@@ -410,10 +828,8 @@ mq_index *mq_index_new(const mq_params *params, int device) {
     if (cc && atoi(cc) == 4) idx->chain_chunk = 4;
     const char *fg = getenv("MQ_FORCE_GENERAL");
     idx->force_general = fg && atoi(fg) != 0;
-    const char *stt = getenv("MQ_STAGE_TIMING");
-    idx->stage_timing = stt && atoi(stt) != 0;
-    const char *sa = getenv("MQ_STOP_AFTER");
-    idx->stop_after = sa ? (uint32_t)atoi(sa) : 0u;
+    const char *pl = getenv("MQ_PIPELINE");
+    idx->split = pl && strcmp(pl, "split") == 0;
     hipDeviceProp_t prop;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
         set_err(MQ_EHIP, "hipSetDevice/hipGetDeviceProperties failed");
@@ -423,6 +839,12 @@ mq_index *mq_index_new(const mq_params *params, int device) {
     idx->n_cu = prop.multiProcessorCount;
     // a 1-slot empty table so that seeding-only calls work before finalize
     if (alloc_table(idx, 1) != MQ_OK) {
+        delete idx;
+        return nullptr;
+    }
+    idx->def_ctx = ctx_create(idx);
+    if (!idx->def_ctx) {
+        hipFree(idx->table);
         delete idx;
         return nullptr;
     }
@@ -436,18 +858,11 @@ void mq_index_free(mq_index *idx) {
         if (c.d) hipFree(c.d);
     if (idx->table) hipFree(idx->table);
     if (idx->d_ref_lens) hipFree(idx->d_ref_lens);
-    if (idx->scratch) hipFree(idx->scratch);
-    if (idx->d_counter) hipFree(idx->d_counter);
-    if (idx->fast_scratch) hipFree(idx->fast_scratch);
-    if (idx->st_bases) hipFree(idx->st_bases);
-    if (idx->st_off) hipFree(idx->st_off);
-    if (idx->st_out) hipFree(idx->st_out);
-    if (idx->ev0) hipEventDestroy(idx->ev0);
-    if (idx->ev1) hipEventDestroy(idx->ev1);
+    ctx_release(idx->def_ctx);
     delete idx;
 }
 
-int64_t mq_index_add_ref_device(mq_index *idx, uint32_t ref_id, const char *name, const uint8_t *d_seq, uint64_t len) {
+static int64_t add_ref_device_locked(mq_index *idx, uint32_t ref_id, const char *name, const uint8_t *d_seq, uint64_t len) {
     if (!idx || (!d_seq && len)) return set_err(MQ_EINVAL, "bad arguments");
     if (idx->finalized) return set_err(MQ_ESTATE, "index already finalized");
     if (len >= (1ull << 32)) return set_err(MQ_EINVAL, "sequence length must be < 2^32");
@@ -537,8 +952,15 @@ int64_t mq_index_add_ref_device(mq_index *idx, uint32_t ref_id, const char *name
     return n_kmm;
 }
 
+int64_t mq_index_add_ref_device(mq_index *idx, uint32_t ref_id, const char *name, const uint8_t *d_seq, uint64_t len) {
+    if (!idx) return set_err(MQ_EINVAL, "idx is NULL");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    return add_ref_device_locked(idx, ref_id, name, d_seq, len);
+}
+
 int64_t mq_index_add_ref(mq_index *idx, uint32_t ref_id, const char *name, const uint8_t *seq, uint64_t len) {
     if (!idx || (!seq && len)) return set_err(MQ_EINVAL, "bad arguments");
+    std::lock_guard<std::mutex> lk(idx->mu);
     int rc = use_device(idx);
     if (rc) return rc;
     uint8_t *d = nullptr;
@@ -550,20 +972,21 @@ int64_t mq_index_add_ref(mq_index *idx, uint32_t ref_id, const char *name, const
             return set_err(MQ_EHIP, std::string("hipMemcpy H2D: ") + hipGetErrorString(e));
         }
     }
-    int64_t r = mq_index_add_ref_device(idx, ref_id, name, d, len);
+    int64_t r = add_ref_device_locked(idx, ref_id, name, d, len);
     if (d) hipFree(d);
     return r;
 }
 
 int64_t mq_index_finalize(mq_index *idx) {
     if (!idx) return set_err(MQ_EINVAL, "idx is NULL");
+    std::lock_guard<std::mutex> lk(idx->mu);
     if (idx->finalized) return (int64_t)idx->n_unique;
     int rc = use_device(idx);
     if (rc) return rc;
     uint64_t nslots = 1024;
     const char *lf = getenv("MQ_TABLE_FACTOR");  // slots per inserted k-min-mer (power-of-two rounding on top); default 4 => load <= 0.25:
     // ~85 % of a read's lookups miss, a miss walks to the first empty slot, and every extra step is a dependent 128-B line fill
-    const uint64_t factor = lf && atoi(lf) >= 1 ? (uint64_t)atoi(lf) : 4ull;
+    const uint64_t factor = lf && atoi(lf) >= 2 ? (uint64_t)atoi(lf) : 4ull;  // >= 2: a full table would make a miss walk forever
     while (nslots < factor * idx->n_kmm_total) nslots <<= 1;
     rc = alloc_table(idx, nslots);
     if (rc) return rc;
@@ -713,154 +1136,269 @@ int mq_index_ref_info(const mq_index *idx, uint32_t ref_id, const char **name, u
     return MQ_OK;
 }
 
-int mq_map_reserve(mq_index *idx, uint32_t max_len) {
+int mq_map_reserve(mq_index *idx, uint32_t n_reads, uint64_t total_bases) {
     if (!idx) return set_err(MQ_EINVAL, "idx is NULL");
+    std::lock_guard<std::mutex> lk(idx->mu);
     int rc = use_device(idx);
     if (rc) return rc;
-    return ensure_scratch(idx, max_len);
+    return ctx_ensure(idx->def_ctx, n_reads, total_bases, list_f16(idx));
 }
 
 }  // extern "C"
 
-static int launch_map(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, mq_hit *d_out,
-                      mq_kminmer *d_dump, const uint64_t *d_dump_off, uint32_t *d_dump_counts, hipStream_t st,
-                      MatchRec *scratch_override = nullptr, uint32_t cap_override = 0, uint32_t grid_override = 0) {
+struct LaunchOpt {
+    mq_kminmer *d_dump = nullptr;
+    const uint64_t *d_dump_off = nullptr;
+    uint32_t *d_dump_counts = nullptr;
+    MatchRec *scratch_override = nullptr;  // overflow redo: worst-case Match scratch on a small grid
+    uint32_t cap_override = 0;
+    uint32_t grid_override = 0;
+    uint32_t f16 = 0;                      // 0 => list_f16(idx)
+};
+
+// One launch sequence on stream `st` using the context's scratch.  ctx_ensure(c, n, total_bases, f16) must have succeeded.
+static int launch_map(mq_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, mq_hit *d_out, hipStream_t st,
+                      const LaunchOpt &o = LaunchOpt()) {
+    mq_index *idx = c->idx;
     if (n == 0) return MQ_OK;
-    HIPCHK(hipMemsetAsync(idx->d_counter, 0, 128, st));
-    HIPCHK(hipEventRecord(idx->ev0, st));
-    MapArgs A;
+    HIPCHK(hipMemsetAsync(c->d_counter, 0, 256, st));
+    HIPCHK(hipEventRecord(c->ev0, st));
+    SplitArgs A;
     A.bases = d_bases;
     A.offsets = d_offsets;
     A.n = n;
     A.P = idx->dp;
+    A.mz_hash = c->mz_hash;
+    A.mz_pos = c->mz_pos;
+    A.mz_count = c->mz_count;
+    A.mz_base = c->mz_base;
+    A.pool_base = c->pool_base;
+    A.pool_cap = c->pool_cap;
+    A.f16 = o.f16 ? o.f16 : list_f16(idx);
+    A.slack = LIST_SLACK;
+    A.queue = c->queue;
+    A.counters = c->d_counter;
+    A.force_general = idx->force_general ? 1u : 0u;
     A.table = idx->table;
     A.mask = idx->nslots - 1;
     A.ref_lens = idx->d_ref_lens;
-    A.scratch_all = scratch_override ? scratch_override : idx->scratch;
-    A.cap_matches = scratch_override ? cap_override : idx->cap_matches;
-    A.fast_scratch = idx->fast_scratch;
-    A.work_counter = idx->d_counter;
+    A.scratch_all = o.scratch_override ? o.scratch_override : c->scratch;
+    A.cap_matches = o.scratch_override ? o.cap_override : idx->cap_matches;
     A.out = d_out;
-    A.dump = d_dump;
-    A.dump_off = d_dump_off;
-    A.dump_counts = d_dump_counts;
-    A.stats = idx->d_counter + 2;
-    A.stop_after = idx->stop_after;  // [2] fast reads, [3] general reads, [4..15] six 64-bit stage cycle sums
-    uint32_t grid = std::min<uint32_t>(idx->grid, (n + MAP_WAVES - 1) / MAP_WAVES);
-    if (grid_override) grid = std::min(grid, grid_override);
-    const dim3 blk(64 * MAP_WAVES);
-    if (idx->stage_timing || idx->timing_once) hipLaunchKernelGGL((map_kernel<64, true, true>), dim3(grid), blk, 0, st, A);
-    else if (idx->chain_chunk == 4 && idx->force_general) hipLaunchKernelGGL((map_kernel<4, false>), dim3(grid), blk, 0, st, A);
-    else if (idx->chain_chunk == 4) hipLaunchKernelGGL((map_kernel<4, true>), dim3(grid), blk, 0, st, A);
-    else if (idx->force_general) hipLaunchKernelGGL((map_kernel<64, false>), dim3(grid), blk, 0, st, A);
-    else hipLaunchKernelGGL((map_kernel<64, true>), dim3(grid), blk, 0, st, A);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(idx->ev1, st));
-    idx->ev_valid = true;
+    A.dump = o.d_dump;
+    A.dump_off = o.d_dump_off;
+    A.dump_counts = o.d_dump_counts;
+    A.stats64 = reinterpret_cast<unsigned long long *>(c->d_counter + 8);
+    if (!idx->split) {
+        uint32_t grid = std::min<uint32_t>(idx->grid_fused, (n + MAP_WAVES - 1) / MAP_WAVES);
+        if (o.grid_override) grid = std::min(grid, o.grid_override);
+        const dim3 blk(64 * MAP_WAVES);
+        if (idx->timing_once) hipLaunchKernelGGL((map_kernel<64, true>), dim3(grid), blk, 0, st, A);
+        else if (idx->chain_chunk == 4) hipLaunchKernelGGL((map_kernel<4, false>), dim3(grid), blk, 0, st, A);
+        else hipLaunchKernelGGL((map_kernel<64, false>), dim3(grid), blk, 0, st, A);
+        HIPCHK(hipGetLastError());
+    } else {
+        const uint32_t gs = std::min<uint32_t>(idx->grid_seed, (n + SEED_WAVES - 1) / SEED_WAVES);
+        hipLaunchKernelGGL(seed_reads_kernel, dim3(gs), dim3(64 * SEED_WAVES), 0, st, A);
+        HIPCHK(hipGetLastError());
+        // the reads the fast seeder declined: the queue length lives on the device, so the grid is fixed and waves that find
+        // the queue empty leave at once
+        const uint32_t gg = std::min<uint32_t>((uint32_t)idx->n_cu * 8u, n);
+        hipLaunchKernelGGL(seed_general_kernel, dim3(gg), dim3(64), 0, st, A);
+        HIPCHK(hipGetLastError());
+        uint32_t gm = std::min<uint32_t>(idx->grid_map, (n + ML_WAVES - 1) / ML_WAVES);
+        if (o.grid_override) gm = std::min(gm, o.grid_override);
+        const dim3 blk(64 * ML_WAVES);
+        if (idx->timing_once) hipLaunchKernelGGL((map_lists_kernel<64, true>), dim3(gm), blk, 0, st, A);
+        else if (idx->chain_chunk == 4) hipLaunchKernelGGL((map_lists_kernel<4, false>), dim3(gm), blk, 0, st, A);
+        else hipLaunchKernelGGL((map_lists_kernel<64, false>), dim3(gm), blk, 0, st, A);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(c->ev1, st));
+    c->ev_valid = true;
     return MQ_OK;
 }
 
-template <class T>
-static int grow(T *&p, uint64_t &cap, uint64_t need) {
-    if (need <= cap) return MQ_OK;
-    if (p) HIPCHK(hipFree(p));
-    p = nullptr;
-    cap = 0;
-    uint64_t nc = need + need / 4 + 64;
-    HIPCHK(hipMalloc((void **)&p, nc * sizeof(T)));
-    cap = nc;
+// Reads that came back MQ_HIT_OVERFLOW (more Match runs than the per-wave scratch holds, or a minimizer list denser than its
+// region): map those again on the GPU with worst-case scratch and list regions on a small grid.  Never a CPU path.
+static int redo_overflow(mq_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out) {
+    mq_index *idx = c->idx;
+    std::vector<uint32_t> redo;
+    for (uint32_t i = 0; i < n; ++i)
+        if (out[i].status == MQ_HIT_OVERFLOW) redo.push_back(i);
+    if (redo.empty()) return MQ_OK;
+    uint64_t sub_max = 0;
+    std::vector<uint64_t> so(redo.size() + 1, 0);
+    for (size_t j = 0; j < redo.size(); ++j) {
+        const uint64_t L = offsets[redo[j] + 1] - offsets[redo[j]];
+        so[j + 1] = so[j] + L;
+        sub_max = std::max(sub_max, L);
+    }
+    const uint64_t sub_total = so.back();
+    std::vector<uint8_t> sb(sub_total ? sub_total : 1);
+    for (size_t j = 0; j < redo.size(); ++j) memcpy(sb.data() + so[j], bases + offsets[redo[j]], (size_t)(so[j + 1] - so[j]));
+    const uint32_t cap = (uint32_t)std::max<uint64_t>(sub_max, 1);  // a read cannot have more runs than bases
+    const uint32_t waves = std::max(MAP_WAVES, ML_WAVES);
+    const uint32_t rgrid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min(idx->grid_fused, idx->grid_map), (1ull << 30) / ((uint64_t)cap * sizeof(MatchRec) * waves)));
+    int rc = ctx_ensure(c, (uint32_t)redo.size(), sub_total, 65536u);
+    if (rc) return rc;
+    MatchRec *big = nullptr;
+    uint8_t *d_sb = nullptr;
+    uint64_t *d_so = nullptr;
+    mq_hit *d_sh = nullptr;
+    hipError_t e = hipMalloc((void **)&big, (size_t)rgrid * waves * cap * sizeof(MatchRec));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_sb, sub_total + 1);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_so, so.size() * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_sh, redo.size() * sizeof(mq_hit));
+    if (e == hipSuccess && sub_total) e = hipMemcpyAsync(d_sb, sb.data(), sub_total, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_so, so.data(), so.size() * 8, hipMemcpyHostToDevice, c->stream);
+    int rrc = MQ_OK;
+    std::vector<mq_hit> sh(redo.size());
+    if (e == hipSuccess) {
+        LaunchOpt o;
+        o.scratch_override = big;
+        o.cap_override = cap;
+        o.grid_override = rgrid;
+        o.f16 = 65536u;
+        rrc = launch_map(c, d_sb, d_so, (uint32_t)redo.size(), d_sh, c->stream, o);
+    }
+    if (e == hipSuccess && rrc == MQ_OK) e = hipMemcpyAsync(sh.data(), d_sh, redo.size() * sizeof(mq_hit), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    else hipStreamSynchronize(c->stream);
+    hipFree(big);
+    hipFree(d_sb);
+    hipFree(d_so);
+    hipFree(d_sh);
+    if (e != hipSuccess) return set_err(e == hipErrorOutOfMemory ? MQ_ENOMEM : MQ_EHIP, std::string("overflow retry: ") + hipGetErrorString(e));
+    if (rrc) return rrc;
+    for (size_t j = 0; j < redo.size(); ++j) out[redo[j]] = sh[j];
     return MQ_OK;
 }
 
-extern "C" {
-
-int mq_map_batch_device(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint32_t max_len,
-                        mq_hit *d_out, void *stream) {
-    if (!idx || (n && (!d_offsets || !d_out))) return set_err(MQ_EINVAL, "bad arguments");
-    if (!idx->finalized) return set_err(MQ_ESTATE, "index not finalized");
-    int rc = use_device(idx);
-    if (rc) return rc;
-    rc = ensure_scratch(idx, max_len);
-    if (rc) return rc;
-    return launch_map(idx, d_bases, d_offsets, n, d_out, nullptr, nullptr, nullptr, (hipStream_t)stream);
-}
-
-int mq_map_batch(mq_index *idx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out) {
-    if (!idx || (n && (!offsets || !out))) return set_err(MQ_EINVAL, "bad arguments");
+// host buffers -> device staging -> launch sequence -> page-locked hits, all asynchronous on the context's stream
+static int ctx_submit(mq_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out) {
+    mq_index *idx = c->idx;
+    if (c->pending) return set_err(MQ_ESTATE, "context has a submitted batch: call mq_ctx_wait first");
     if (!idx->finalized) return set_err(MQ_ESTATE, "index not finalized");
     if (n == 0) return MQ_OK;
     int rc = use_device(idx);
     if (rc) return rc;
+    if ((rc = grow_pinned(c->h_off, c->h_off_cap, (uint64_t)n + 1))) return rc;
+    if ((rc = grow_pinned(c->h_out, c->h_out_cap, (uint64_t)n))) return rc;
     const uint64_t total = offsets[n] - offsets[0];
-    uint64_t max_len = 0;
     for (uint32_t i = 0; i < n; ++i) {
         if (offsets[i + 1] < offsets[i]) return set_err(MQ_EINVAL, "offsets must be non-decreasing");
-        max_len = std::max(max_len, offsets[i + 1] - offsets[i]);
+        if (offsets[i + 1] - offsets[i] >= (1ull << 32)) return set_err(MQ_EINVAL, "sequence length must be < 2^32");
+        c->h_off[i] = offsets[i] - offsets[0];
     }
-    if (max_len >= (1ull << 32)) return set_err(MQ_EINVAL, "sequence length must be < 2^32");
-    rc = ensure_scratch(idx, (uint32_t)max_len);
+    c->h_off[n] = total;
+    if ((rc = ctx_ensure(c, n, total, list_f16(idx)))) return rc;
+    if ((rc = grow(c->st_bases, c->st_bases_cap, total + 64))) return rc;
+    if ((rc = grow(c->st_off, c->st_off_cap, (uint64_t)n + 1))) return rc;
+    if ((rc = grow(c->st_out, c->st_out_cap, (uint64_t)n))) return rc;
+    if (total) HIPCHK(hipMemcpyAsync(c->st_bases, bases + offsets[0], total, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->st_off, c->h_off, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    rc = launch_map(c, c->st_bases, c->st_off, n, c->st_out, c->stream);
     if (rc) return rc;
-    if ((rc = grow(idx->st_bases, idx->st_bases_cap, total + 1))) return rc;
-    if ((rc = grow(idx->st_off, idx->st_off_cap, (uint64_t)n + 1))) return rc;
-    if ((rc = grow(idx->st_out, idx->st_out_cap, (uint64_t)n))) return rc;
-    std::vector<uint64_t> rel((size_t)n + 1);
-    for (uint32_t i = 0; i <= n; ++i) rel[i] = offsets[i] - offsets[0];
-    if (total) HIPCHK(hipMemcpy(idx->st_bases, bases + offsets[0], total, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(idx->st_off, rel.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-    rc = launch_map(idx, idx->st_bases, idx->st_off, n, idx->st_out, nullptr, nullptr, nullptr, 0);
-    if (rc) return rc;
-    HIPCHK(hipMemcpy(out, idx->st_out, (size_t)n * sizeof(mq_hit), hipMemcpyDeviceToHost));
-    // Reads whose Match runs did not fit the per-wave scratch come back as MQ_HIT_OVERFLOW: map those again on the GPU
-    // with a worst-case scratch (a read cannot have more runs than bases) on a small grid.  Never a CPU path.
-    std::vector<uint32_t> redo;
-    for (uint32_t i = 0; i < n; ++i)
-        if (out[i].status == MQ_HIT_OVERFLOW) redo.push_back(i);
-    if (!redo.empty()) {
-        uint64_t sub_total = 0, sub_max = 0;
-        std::vector<uint64_t> so(redo.size() + 1, 0);
-        for (size_t j = 0; j < redo.size(); ++j) {
-            const uint64_t L = offsets[redo[j] + 1] - offsets[redo[j]];
-            so[j + 1] = so[j] + L;
-            sub_max = std::max(sub_max, L);
-        }
-        sub_total = so.back();
-        std::vector<uint8_t> sb(sub_total ? sub_total : 1);
-        for (size_t j = 0; j < redo.size(); ++j)
-            memcpy(sb.data() + so[j], bases + offsets[redo[j]], (size_t)(so[j + 1] - so[j]));
-        const uint32_t cap = (uint32_t)std::max<uint64_t>(sub_max, 1);
-        const uint32_t rgrid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(idx->grid, (1ull << 30) / ((uint64_t)cap * sizeof(MatchRec) * MAP_WAVES)));
-        MatchRec *big = nullptr;
-        uint8_t *d_sb = nullptr;
-        uint64_t *d_so = nullptr;
-        mq_hit *d_sh = nullptr;
-        hipError_t e = hipMalloc((void **)&big, (size_t)rgrid * MAP_WAVES * cap * sizeof(MatchRec));
-        if (e == hipSuccess) e = hipMalloc((void **)&d_sb, sub_total + 1);
-        if (e == hipSuccess) e = hipMalloc((void **)&d_so, so.size() * 8);
-        if (e == hipSuccess) e = hipMalloc((void **)&d_sh, redo.size() * sizeof(mq_hit));
-        if (e == hipSuccess && sub_total) e = hipMemcpy(d_sb, sb.data(), sub_total, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d_so, so.data(), so.size() * 8, hipMemcpyHostToDevice);
-        int rrc = MQ_OK;
-        std::vector<mq_hit> sh(redo.size());
-        if (e == hipSuccess) rrc = launch_map(idx, d_sb, d_so, (uint32_t)redo.size(), d_sh, nullptr, nullptr, nullptr, 0, big, cap, rgrid);
-        if (e == hipSuccess && rrc == MQ_OK) e = hipMemcpy(sh.data(), d_sh, redo.size() * sizeof(mq_hit), hipMemcpyDeviceToHost);
-        hipFree(big); hipFree(d_sb); hipFree(d_so); hipFree(d_sh);
-        if (e != hipSuccess) return set_err(e == hipErrorOutOfMemory ? MQ_ENOMEM : MQ_EHIP, std::string("overflow retry: ") + hipGetErrorString(e));
-        if (rrc) return rrc;
-        for (size_t j = 0; j < redo.size(); ++j) out[redo[j]] = sh[j];
-    }
+    HIPCHK(hipMemcpyAsync(c->h_out, c->st_out, (size_t)n * sizeof(mq_hit), hipMemcpyDeviceToHost, c->stream));
+    c->pending = true;
+    c->p_bases = bases;
+    c->p_offsets = offsets;
+    c->p_n = n;
+    c->p_out = out;
     return MQ_OK;
+}
+
+static int ctx_wait(mq_ctx *c) {
+    if (!c->pending) return MQ_OK;
+    c->pending = false;
+    int rc = use_device(c->idx);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(c->p_out, c->h_out, (size_t)c->p_n * sizeof(mq_hit));
+    return redo_overflow(c, c->p_bases, c->p_offsets, c->p_n, c->p_out);
+}
+
+static int ctx_map_device(mq_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases, mq_hit *d_out,
+                          hipStream_t st) {
+    mq_index *idx = c->idx;
+    if (n && (!d_offsets || !d_out)) return set_err(MQ_EINVAL, "bad arguments");
+    if (!idx->finalized) return set_err(MQ_ESTATE, "index not finalized");
+    if (c->pending) return set_err(MQ_ESTATE, "context has a submitted batch: call mq_ctx_wait first");
+    int rc = use_device(idx);
+    if (rc) return rc;
+    if ((rc = ctx_ensure(c, n, total_bases, list_f16(idx)))) return rc;
+    return launch_map(c, d_bases, d_offsets, n, d_out, st);
+}
+
+extern "C" {
+
+mq_ctx *mq_ctx_new(mq_index *idx) {
+    if (!idx) {
+        set_err(MQ_EINVAL, "idx is NULL");
+        return nullptr;
+    }
+    return ctx_create(idx);
+}
+
+void mq_ctx_free(mq_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->idx->device);
+    ctx_release(ctx);
+}
+
+int mq_ctx_submit(mq_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out) {
+    if (!ctx || (n && (!offsets || !out))) return set_err(MQ_EINVAL, "bad arguments");
+    return ctx_submit(ctx, bases, offsets, n, out);
+}
+
+int mq_ctx_wait(mq_ctx *ctx) {
+    if (!ctx) return set_err(MQ_EINVAL, "ctx is NULL");
+    return ctx_wait(ctx);
+}
+
+int mq_ctx_map_batch(mq_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out) {
+    if (!ctx || (n && (!offsets || !out))) return set_err(MQ_EINVAL, "bad arguments");
+    int rc = ctx_submit(ctx, bases, offsets, n, out);
+    if (rc) return rc;
+    return ctx_wait(ctx);
+}
+
+int mq_ctx_map_batch_device(mq_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases,
+                            mq_hit *d_out, void *stream) {
+    if (!ctx) return set_err(MQ_EINVAL, "ctx is NULL");
+    return ctx_map_device(ctx, d_bases, d_offsets, n, total_bases, d_out, (hipStream_t)stream);
+}
+
+int mq_map_batch_device(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases,
+                        mq_hit *d_out, void *stream) {
+    if (!idx) return set_err(MQ_EINVAL, "idx is NULL");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    return ctx_map_device(idx->def_ctx, d_bases, d_offsets, n, total_bases, d_out, (hipStream_t)stream);
+}
+
+int mq_map_batch(mq_index *idx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out) {
+    if (!idx || (n && (!offsets || !out))) return set_err(MQ_EINVAL, "bad arguments");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    int rc = ctx_submit(idx->def_ctx, bases, offsets, n, out);
+    if (rc) return rc;
+    return ctx_wait(idx->def_ctx);
 }
 
 int mq_kminmers_batch(mq_index *idx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, const uint64_t *kmm_offsets,
                       mq_kminmer *out, uint32_t *counts) {
     if (!idx || (n && (!offsets || !kmm_offsets || !counts))) return set_err(MQ_EINVAL, "bad arguments");
     if (n == 0) return MQ_OK;
+    std::lock_guard<std::mutex> lk(idx->mu);
     int rc = use_device(idx);
-    if (rc) return rc;
-    rc = ensure_scratch(idx, 0);
     if (rc) return rc;
     const uint64_t total = offsets[n] - offsets[0];
     const uint64_t ktotal = kmm_offsets[n] - kmm_offsets[0];
+    for (uint32_t i = 0; i < n; ++i)
+        if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] >= (1ull << 32)) return set_err(MQ_EINVAL, "bad offsets / sequence length must be < 2^32");
+    // parity/debug entry point: list regions sized for the worst case (one minimizer per base), so no sequence overflows
+    rc = ctx_ensure(idx->def_ctx, n, total, 65536u);
+    if (rc) return rc;
     uint8_t *d_b = nullptr;
     uint64_t *d_o = nullptr, *d_ko = nullptr;
     mq_kminmer *d_k = nullptr;
@@ -891,7 +1429,14 @@ int mq_kminmers_batch(mq_index *idx, const uint8_t *bases, const uint64_t *offse
         return set_err(MQ_EHIP, std::string("mq_kminmers_batch setup: ") + hipGetErrorString(e));
     }
     // before finalize there is no ref table: the 1-slot empty table never hits, so ref_lens is never read
-    rc = launch_map(idx, d_b, d_o, n, d_h, d_k, d_ko, d_c, 0);
+    {
+        LaunchOpt o;
+        o.d_dump = d_k;
+        o.d_dump_off = d_ko;
+        o.d_dump_counts = d_c;
+        o.f16 = 65536u;
+        rc = launch_map(idx->def_ctx, d_b, d_o, n, d_h, 0, o);
+    }
     if (rc) {
         cleanup();
         return rc;
@@ -907,6 +1452,7 @@ int mq_index_lookup(mq_index *idx, const uint64_t *hashes, uint32_t n, uint8_t *
     if (!idx || (n && (!hashes || !found || !entries || !ref_ids))) return set_err(MQ_EINVAL, "bad arguments");
     if (!idx->finalized) return set_err(MQ_ESTATE, "index not finalized");
     if (n == 0) return MQ_OK;
+    std::lock_guard<std::mutex> lk(idx->mu);
     int rc = use_device(idx);
     if (rc) return rc;
     uint64_t *d_k = nullptr;
@@ -961,47 +1507,89 @@ void mq_host_free(void *p) {
 
 int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general) {
     if (!idx || !n_fast || !n_general) return set_err(MQ_EINVAL, "bad arguments");
-    if (!idx->ev_valid) return set_err(MQ_ESTATE, "no map launch recorded");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    mq_ctx *c = idx->def_ctx;
+    if (!c->ev_valid) return set_err(MQ_ESTATE, "no map launch recorded");
     int rc = use_device(idx);
     if (rc) return rc;
-    HIPCHK(hipEventSynchronize(idx->ev1));
+    HIPCHK(hipEventSynchronize(c->ev1));
     uint32_t v[2] = {0, 0};
-    HIPCHK(hipMemcpy(v, idx->d_counter + 2, 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(v, c->d_counter + 4, 8, hipMemcpyDeviceToHost));
     *n_fast = v[0];
     *n_general = v[1];
     return MQ_OK;
 }
 
-int mq_last_stage_cycles(mq_index *idx, uint64_t *cycles9) {
-    if (!idx || !cycles9) return set_err(MQ_EINVAL, "bad arguments");
-    if (!idx->ev_valid) return set_err(MQ_ESTATE, "no map launch recorded");
-    int rc = use_device(idx);
-    if (rc) return rc;
-    HIPCHK(hipEventSynchronize(idx->ev1));
-    HIPCHK(hipMemcpy(cycles9, idx->d_counter + 4, 72, hipMemcpyDeviceToHost));
-    return MQ_OK;
-}
-
-int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint32_t max_len, mq_hit *d_out,
+int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases, mq_hit *d_out,
                        uint64_t *lookups, uint64_t *extra_steps) {
     if (!idx || !lookups || !extra_steps) return set_err(MQ_EINVAL, "bad arguments");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    mq_ctx *c = idx->def_ctx;
     idx->timing_once = true;
-    int rc = mq_map_batch_device(idx, d_bases, d_offsets, n, max_len, d_out, nullptr);
+    int rc = ctx_map_device(c, d_bases, d_offsets, n, total_bases, d_out, nullptr);
     idx->timing_once = false;
     if (rc) return rc;
-    uint64_t v[9];
-    rc = mq_last_stage_cycles(idx, v);
-    if (rc) return rc;
-    *extra_steps = v[6];
-    *lookups = v[7];
+    HIPCHK(hipEventSynchronize(c->ev1));
+    uint64_t v[2];
+    HIPCHK(hipMemcpy(v, c->d_counter + 8, 16, hipMemcpyDeviceToHost));
+    *extra_steps = v[0];
+    *lookups = v[1];
     return MQ_OK;
 }
 
 int mq_last_map_ms(mq_index *idx, float *ms) {
     if (!idx || !ms) return set_err(MQ_EINVAL, "bad arguments");
-    if (!idx->ev_valid) return set_err(MQ_ESTATE, "no map launch recorded");
-    HIPCHK(hipEventSynchronize(idx->ev1));
-    HIPCHK(hipEventElapsedTime(ms, idx->ev0, idx->ev1));
+    std::lock_guard<std::mutex> lk(idx->mu);
+    mq_ctx *c = idx->def_ctx;
+    if (!c->ev_valid) return set_err(MQ_ESTATE, "no map launch recorded");
+    HIPCHK(hipEventSynchronize(c->ev1));
+    HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return MQ_OK;
+}
+
+int mq_probe_rate(mq_index *idx, uint32_t blocks, uint32_t per_thread, uint32_t bitmap_log2, uint32_t table_too, float *ms,
+                  uint64_t *lookups, uint64_t *extra_steps) {
+    if (!idx || !ms || !lookups || !extra_steps) return set_err(MQ_EINVAL, "bad arguments");
+    if (!idx->finalized) return set_err(MQ_ESTATE, "index not finalized");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    int rc = use_device(idx);
+    if (rc) return rc;
+    unsigned long long *d_acc = nullptr;
+    uint32_t *bm = nullptr;
+    uint64_t bit_mask = 0;
+    HIPCHK(hipMalloc((void **)&d_acc, 16));
+    HIPCHK(hipMemset(d_acc, 0, 16));
+    if (bitmap_log2) {  // a stand-in bitmap with one bit in eight set
+        bit_mask = (1ull << bitmap_log2) - 1;
+        HIPCHK(hipMalloc((void **)&bm, (size_t)1 << (bitmap_log2 - 3)));
+        HIPCHK(hipMemset(bm, 0x10, (size_t)1 << (bitmap_log2 - 3)));
+    }
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    per_thread = (per_thread + 3u) & ~3u;
+    hipLaunchKernelGGL(probe_rate_kernel, dim3(blocks), dim3(256), 0, 0, idx->table, idx->nslots - 1, per_thread, 1ull, d_acc, bm, bit_mask, table_too);  // warm-up
+    HIPCHK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(probe_rate_kernel, dim3(blocks), dim3(256), 0, 0, idx->table, idx->nslots - 1, per_thread, 0x1234567ull, d_acc, bm, bit_mask, table_too);
+    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipEventElapsedTime(ms, e0, e1));
+    unsigned long long acc[2];
+    HIPCHK(hipMemcpy(acc, d_acc, 16, hipMemcpyDeviceToHost));
+    hipFree(d_acc);
+    hipFree(bm);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *lookups = (uint64_t)blocks * 256ull * per_thread;
+    *extra_steps = acc[1] / 2;  // two launches accumulated
+    return MQ_OK;
+}
+
+int mq_ctx_last_map_ms(mq_ctx *ctx, float *ms) {
+    if (!ctx || !ms) return set_err(MQ_EINVAL, "bad arguments");
+    if (!ctx->ev_valid) return set_err(MQ_ESTATE, "no map launch recorded");
+    HIPCHK(hipEventSynchronize(ctx->ev1));
+    HIPCHK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
     return MQ_OK;
 }
 

@@ -1,8 +1,8 @@
 // mq_device.hpp -- gfx950 device code for mapquik's hot path (seeding, index probe, Match runs, pseudo-chain).
 //
 // One wavefront (64 lanes) owns one sequence (or one segment of a long reference).  Everything is
-// integer / byte work: no MFMA.  This header holds the GENERAL streaming seeder (any length, any bytes; the fast path for
-// ACGT-only sequences is mq_fast.hpp), the index probe, the Match-run builder and the chain stage.
+// integer / byte work: no MFMA.  This header holds the GENERAL streaming seeder (any length, any bytes; the fast seeder for
+// ACGT-only sequences is mq_seed.hpp), the index probe, the Match-run builder and the chain stage.
 // Structure of the streaming seeder (lanes = consecutive positions):
 //   raw bytes --(head flags, ballot/mbcnt compaction)--> HPC ring in LDS --(64-wide XOR prefix scan of
 //   rotated ntHash seeds)--> canonical l-mer hashes --(density predicate, ballot compaction)--> ordered
@@ -13,7 +13,7 @@
 // (all rotation amounts mod 64; blocks of 64 HPC positions are 64-aligned so amounts are lane constants).
 //
 // Reference semantics restated here (citations relative to the reference tree):
-//   KminmersIterator (rust-seq2kminmers, call sites src/mers.rs:27,53)   -> seed_segment / fast_seed_sequence + kminmer_hash
+//   KminmersIterator (rust-seq2kminmers, call sites src/mers.rs:27,53)   -> seed_segment / seed_sequence_fast + kminmer_hash
 //   ReadOnlyIndex::get (src/index.rs:118-126)                           -> probe_table
 //   Match::new/update/check/extend (src/match.rs:20-58), chain_matches (src/mers.rs:57-73) -> MapSink::batch_runs
 //   Chain::get_match (src/chain.rs:147-169) and helpers                  -> chain_stage
@@ -65,28 +65,12 @@ struct alignas(16) MatchRec {
     uint32_t q_start, q_end, r_start, r_end, count, ref, rc, done;
 };
 
-constexpr uint32_t FAST_CODES_DW = 1312;  // packed 2-bit HPC codes of one tile (+ read-ahead padding), see mq_fast.hpp
-constexpr uint32_t FAST_CNT_N = 516;      // HPC count at every 64-base block (+ sentinel)
-
-// Per-wave LDS.  The general streaming path uses the ring, the fast path the packed tile: never at the same time.
+// Per-wave LDS of the general streaming seeder
 struct WaveLds {
-    union {
-        struct {  // general streaming path
-            unsigned long long mz_hash[MZ_CAP];
-            uint32_t mz_pos[MZ_CAP];
-            uint32_t ring_pos[RING];
-            uint8_t ring_code[RING];
-        };
-        struct {  // fast path
-            uint32_t codes[FAST_CODES_DW];
-            unsigned long long stash_hash[MAX_K];  // the last k-1 minimizers, carried into the next tile
-            uint32_t stash_pos[MAX_K];
-            uint32_t lane_prefix[68];
-            uint32_t carry_pos[64];    // raw positions of the compressed bases carried into the next tile
-            uint32_t carry_codes[4];   // their 2-bit codes (<= 63)
-            uint16_t cnt64[FAST_CNT_N];
-        } f;
-    };
+    unsigned long long mz_hash[MZ_CAP];
+    uint32_t mz_pos[MZ_CAP];
+    uint32_t ring_pos[RING];
+    uint8_t ring_code[RING];
 };
 
 // ------------------------------------------------------------------ wave helpers
@@ -473,7 +457,7 @@ __device__ __forceinline__ void chain_stage(MatchRec *__restrict__ scratch, uint
     out.score = b_score;
 }
 
-// ------------------------------------------------------------------ sink of the fused map path
+// ------------------------------------------------------------------ the map stage's consumer of an ordered minimizer list
 struct MapSink {
     const Slot *__restrict__ table;
     uint64_t mask;
@@ -528,18 +512,6 @@ struct MapSink {
             k0 = table[s].key;
             probe_steps++;
         }
-    }
-
-    // k-min-mers [0, n) of the small LDS minimizer list (general streaming path)
-    __device__ __forceinline__ void consume(WaveLds &S, uint32_t n) {
-        uint64_t key;
-        bool rev;
-        uint32_t q_start, q_end;
-        const bool act = lane_id() < n;
-        batch_keys(S.mz_hash, S.mz_pos, 0, act, key, rev, q_start, q_end);
-        Slot e = {};
-        const bool hit = act && probe_table(table, mask, key, e);
-        batch_runs(n, key, rev, q_start, q_end, hit, e);
     }
 
     // one batch of n <= 64 consecutive k-min-mers (lane = k-min-mer) with their index entries: dump + Match runs
@@ -703,43 +675,15 @@ struct MapSink {
         }
     }
 
-    __device__ __forceinline__ void shift(WaveLds &S, uint32_t &mz_count) {
-        const uint32_t lane = lane_id();
-        const uint32_t rem = mz_count - 64u;
-        for (uint32_t base = 0; base < rem; base += 64u) {
-            const bool mv = base + lane < rem;
-            uint64_t h = 0;
-            uint32_t p = 0;
-            if (mv) {
-                h = S.mz_hash[64u + base + lane];
-                p = S.mz_pos[64u + base + lane];
-            }
-            wave_sync();
-            if (mv) {
-                S.mz_hash[base + lane] = h;
-                S.mz_pos[base + lane] = p;
-            }
-            wave_sync();
-        }
-        mz_count = rem;
-    }
-
-    __device__ __forceinline__ void on_minimizers(WaveLds &S, uint32_t &mz_count) {
-        if (mz_count >= 64u + P.k - 1u) {
-            consume(S, 64u);
-            shift(S, mz_count);
-        }
-    }
-
-    __device__ __forceinline__ void finish(WaveLds &S, uint32_t &mz_count) {
-        if (mz_count >= P.k) consume(S, mz_count - P.k + 1u);
+    // the run still open after the last k-min-mer of the read ends there
+    __device__ __forceinline__ void finish_runs() {
         if (c_open) {
             if (n_matches < cap_matches && lane_id() == 0) scratch[n_matches] = M;
             n_matches++;
             c_open = false;
         }
-        mz_count = 0;
     }
+
 };
 
 // ------------------------------------------------------------------ sink of the reference path: ordered minimizers to HBM
@@ -748,10 +692,6 @@ struct ListSink {
     uint32_t cap;
     uint32_t written = 0;  // may exceed cap (overflow detected by the host)
     __device__ ListSink(Minimizer *o, uint32_t c) : out(o), cap(c) {}
-    template <int NB>
-    __device__ __forceinline__ void consume_list(const unsigned long long *mzh, const uint32_t *mzp, uint32_t have) {
-        (void)mzh; (void)mzp; (void)have;  // the reference path streams through on_minimizers only
-    }
     __device__ __forceinline__ void on_minimizers(WaveLds &S, uint32_t &mz_count) {
         const uint32_t lane = lane_id();
         for (uint32_t base = 0; base < mz_count; base += 64u) {
@@ -762,6 +702,28 @@ struct ListSink {
                 m.pos = S.mz_pos[i];
                 m.pad = 0;
                 out[written + i] = m;
+            }
+        }
+        written += mz_count;
+        mz_count = 0;
+        wave_sync();
+    }
+};
+
+// sink of the split pipeline's general seeder: ordered minimizers to the read's SoA list region (hash[], pos[])
+struct SoaListSink {
+    unsigned long long *__restrict__ out_hash;
+    uint32_t *__restrict__ out_pos;
+    uint32_t cap;
+    uint32_t written = 0;  // may exceed cap (the map stage then reports the read as overflowed)
+    __device__ SoaListSink(unsigned long long *h, uint32_t *p, uint32_t c) : out_hash(h), out_pos(p), cap(c) {}
+    __device__ __forceinline__ void on_minimizers(WaveLds &S, uint32_t &mz_count) {
+        const uint32_t lane = lane_id();
+        for (uint32_t base = 0; base < mz_count; base += 64u) {
+            const uint32_t i = base + lane;
+            if (i < mz_count && written + i < cap) {
+                out_hash[written + i] = S.mz_hash[i];
+                out_pos[written + i] = S.mz_pos[i];
             }
         }
         written += mz_count;

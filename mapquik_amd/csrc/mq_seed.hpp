@@ -1,4 +1,4 @@
-// mq_seed.hpp -- the seed kernel's fast path: an ACGT-only sequence -> its ordered minimizer list (hash, raw position) in HBM.
+// mq_seed.hpp -- the fast seeder: an ACGT-only sequence -> its ordered minimizer list (hash, raw position) in HBM.
 //
 // One wave per sequence, tile by tile (8192 raw bases = two super-rows of 64 bases per lane); per-wave LDS 5.9 KB so that 24
 // waves (6 per SIMD) share a CU.  Everything lives in LDS between the stages; nothing but the final list goes to HBM.
@@ -9,11 +9,12 @@
 //   stage B  lanes own contiguous chunks of ceil(windows / 64) compressed positions and ROLL ntHash over them:
 //            fh' = rol(fh,1) ^ rol(h(out),l) ^ h(in),  rh' = ror(rh,1) ^ ror(hc(out),1) ^ rol(hc(in),l-1)
 //            with one 16-entry LDS table indexed by (out,in) -> one ds_read_b128 per step, four look-ups in flight.
-//            The per-step test is min(fh.hi, rh.hi) <= hi(bound); candidates are appended (ballot + mbcnt) to a dense LDS
-//            list {hash, j | lane | slot}; a list that outgrows LDS continues in a per-wave HBM spill area.
-//   stage R  lane = candidate: exact 64-bit test, its place in position order (lane_prefix[lane] + slot), raw position =
-//            block search in the per-block counts + select on the 64-bit head mask, then {hash, pos} go to the
-//            sequence's region of the minimizer buffer.
+//            The per-step test is min(fh.hi, rh.hi) <= hi(bound); its outcome is shifted into a per-lane flag word (three
+//            VALU instructions, no branch, no scalar work, nothing stored); the flag words go to LDS once per 16 steps.
+//   stage R  lane = candidate, in position order: the owning lane by binary search in the lanes' count prefix, the step by
+//            bit select in that lane's flags; the window's two hashes computed again from the code stream, four bases per
+//            look-up (256-entry table); exact 64-bit test; raw position = block search in the per-block counts + select on
+//            the 64-bit head mask; then {hash, pos} go to the sequence's region of the minimizer buffer.
 // A sequence with a byte other than A C G T (or a candidate that passes the high-word test but not the exact one) is
 // handed to the general streaming seeder (mq_device.hpp) through a queue; both produce the same list.
 #pragma once
@@ -28,15 +29,16 @@ constexpr uint32_t SD_BLOCKS = SD_TILE_RAW / 64;           // 64-base blocks per
 constexpr uint32_t SD_CODES_MAX = SD_TILE_RAW + MAX_L - 1; // codes of one tile incl. the carried l-1 (no compression at all)
 constexpr uint32_t SD_LC_MAX = (SD_CODES_MAX + 63) / 64;   // windows per lane
 constexpr uint32_t SD_CODES_DW = 528;                      // packed 2-bit codes + zero read-ahead padding
-constexpr uint32_t SD_CAND_CAP = 176;                      // candidates of one tile kept in LDS (expected ~125); the rest spill
-constexpr uint32_t SD_SPILL_CAP = SD_CODES_MAX;            // per-wave HBM spill records (16 B each): every window a candidate
+constexpr uint32_t SD_FLAG_BLKS = 12;                      // 16-step blocks per lane (flag words of 16 bits), padded to 3 x 64 bits
 static_assert((63 * SD_LC_MAX + 16 * ((SD_LC_MAX + 15) / 16) + MAX_L + 32) / 16 < SD_CODES_DW, "code stream read-ahead padding");
-static_assert(SD_CODES_MAX < (1u << 16) && SD_LC_MAX < 256, "tag packing: j 16 bits | lane 6 bits | slot 8 bits");
+static_assert((SD_LC_MAX + 15) / 16 <= SD_FLAG_BLKS && SD_FLAG_BLKS % 4 == 0, "flag words");
 
 // workgroup-shared look-up tables (built once per workgroup)
 struct SeedTables {
     uint4 roll[16];      // index out | in<<2 : {rol(h(out),l)^h(in) lo,hi ; ror(hc(out),1)^rol(hc(in),l-1) lo,hi}
     uint4 warm[4];       // index code        : {h(c) lo,hi ; rol(hc(c),l-1) lo,hi}
+    uint4 quad[256];     // index c0 | c1<<2 | c2<<4 | c3<<6 : four Horner steps at once, {F4 lo,hi ; R4 lo,hi} with
+                         //   F4 = rol(h(c0),3)^rol(h(c1),2)^rol(h(c2),1)^h(c3),  R4 = ror(X0,3)^ror(X1,2)^ror(X2,1)^X3,  X = rol(hc(c),l-1)
     uint16_t lut[1024];  // index prev | c0<<2 | c1<<4 | c2<<6 | c3<<8 : compacted codes (8 bits) | 2*count << 8 | head bits << 12
 };
 
@@ -45,8 +47,7 @@ struct SeedLds {
     uint32_t codes[SD_CODES_DW];                 // the tile's 2-bit code stream (carried l-1 codes first)
     unsigned long long heads[SD_BLOCKS];         // bit b of heads[k]: raw base 64k + b of the tile is a run head
     uint16_t cnt[SD_BLOCKS + 4];                 // index in the code stream of block k's first run head; cnt[n_blocks] = n_codes
-    unsigned long long cand_hash[SD_CAND_CAP];   // stage B's dense candidate list (emission order)
-    uint32_t cand_tag[SD_CAND_CAP];              // j | lane << 16 | slot << 22
+    unsigned long long flags[64 * SD_FLAG_BLKS / 4];  // lane L, 16-step block b: bit t of the uint16 at [L * SD_FLAG_BLKS + b] <=> step 16 b + t is a candidate
     uint32_t carry_codes[4];                     // codes carried into the next tile (<= 63)
     uint32_t carry_pos[64];                      // their raw positions
     uint16_t lane_prefix[66];                    // exclusive prefix of the lanes' candidate counts
@@ -82,9 +83,48 @@ __device__ __forceinline__ void build_seed_tables(SeedTables &T, uint32_t l) {
         const uint64_t r = rotl64(seed_of(threadIdx.x ^ 2u), l - 1u);
         T.warm[threadIdx.x] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
     }
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+        uint64_t f = 0, r = 0;
+        for (uint32_t m = 0; m < 4; ++m) {
+            const uint32_t c = (i >> (2 * m)) & 3u;
+            f = rotl64(f, 1) ^ seed_of(c);
+            r = rotr64(r, 1) ^ rotl64(seed_of(c ^ 2u), l - 1u);
+        }
+        T.quad[i] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
+    }
 }
 
+
 typedef uint4 __attribute__((aligned(1))) uint4_unaligned;
+
+__device__ __forceinline__ uint64_t ld_sc1_u64(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L2-served: never a stale L1 line
+}
+__device__ __forceinline__ uint32_t ld_sc1_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// 16 ASCII bases (four dwords masked with 0x06060606: code<<1 in every byte) -> 32 bits, code j at bits 2j..2j+1.
+// Merge the dwords so that byte b holds bases b, 4+b, 8+b, 12+b, then transpose the 4x4 matrix of 2-bit elements.
+__device__ __forceinline__ uint32_t pack16(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
+    uint32_t v = (t0 >> 1) | (t1 << 1) | (t2 << 3) | (t3 << 5);
+    uint32_t x = ((v >> 6) ^ v) & 0x00CC00CCu;
+    v ^= x ^ (x << 6);
+    x = ((v >> 12) ^ v) & 0x0000F0F0u;
+    v ^= x ^ (x << 12);
+    return v;
+}
+
+// both strands' rolling ntHash of one window, as four dwords; roll() = one step with the table value of (out, in)
+struct Hash2 {
+    uint32_t flo, fhi, rlo, rhi;
+    __device__ __forceinline__ void roll(const uint4 tv) {
+        const uint32_t nfhi = __builtin_amdgcn_alignbit(fhi, flo, 31), nflo = __builtin_amdgcn_alignbit(flo, fhi, 31);  // rol 1
+        const uint32_t nrlo = __builtin_amdgcn_alignbit(rhi, rlo, 1), nrhi = __builtin_amdgcn_alignbit(rlo, rhi, 1);    // ror 1
+        flo = nflo ^ tv.x;
+        fhi = nfhi ^ tv.y;
+        rlo = nrlo ^ tv.z;
+        rhi = nrhi ^ tv.w;
+    }
+};
 
 // ------------------------------------------------------------------ DPP wave scan (no LDS crossbar: ds_bpermute costs ~24 cycles)
 // inclusive prefix sum over the 64 lanes: 4 row_shr steps inside each row of 16, then row_bcast:15 / row_bcast:31
@@ -96,17 +136,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
     return x;
-}
-
-// 16 ASCII bases (four dwords masked with 0x06060606: code<<1 in every byte) -> 32 bits, code j at bits 2j..2j+1.
-// Merge the dwords so that byte b holds bases b, 4+b, 8+b, 12+b, then transpose the 4x4 matrix of 2-bit elements.
-__device__ __forceinline__ uint32_t pack16(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
-    uint32_t v = (t0 >> 1) | (t1 << 1) | (t2 << 3) | (t3 << 5);
-    uint32_t x = ((v >> 6) ^ v) & 0x00CC00CCu;
-    v ^= x ^ (x << 6);
-    x = ((v >> 12) ^ v) & 0x0000F0F0u;
-    v ^= x ^ (x << 12);
-    return v;
 }
 
 // ------------------------------------------------------------------ stage A
@@ -141,6 +170,8 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
         nx3 = load_piece(pos + 48u);
     }
     for (uint32_t i = lane * 4u; i < SD_CODES_DW; i += 256u) *reinterpret_cast<uint4 *>(&S.codes[i]) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (uint32_t w = 0; w < SD_FLAG_BLKS / 4u; ++w) S.flags[lane * (SD_FLAG_BLKS / 4u) + w] = 0ull;  // stage B sets bits in its own blocks only
     wave_sync();
     if (lane < 4u && carry_n) S.codes[lane] = S.carry_codes[lane];  // the carried codes open the stream
     uint32_t b2 = 2u * carry_n;  // bits written so far = 2 * codes
@@ -227,43 +258,41 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
 }
 
 // ------------------------------------------------------------------ stage B
-struct Hash2 {
-    uint32_t flo, fhi, rlo, rhi;
-    __device__ __forceinline__ void roll(const uint4 tv) {
-        const uint32_t nfhi = __builtin_amdgcn_alignbit(fhi, flo, 31), nflo = __builtin_amdgcn_alignbit(flo, fhi, 31);  // rol 1
-        const uint32_t nrlo = __builtin_amdgcn_alignbit(rhi, rlo, 1), nrhi = __builtin_amdgcn_alignbit(rlo, rhi, 1);    // ror 1
-        flo = nflo ^ tv.x;
-        fhi = nfhi ^ tv.y;
-        rlo = nrlo ^ tv.z;
-        rhi = nrhi ^ tv.w;
+// Both strands' ntHash of the l-mer that starts at code index a of the tile's code stream, from scratch: Horner form
+// (fh = rol(fh,1)^h(c), rh = ror(rh,1)^rol(hc(c),l-1)), four bases per table look-up, the last l mod 4 one by one.
+__device__ __forceinline__ Hash2 window_hash(const SeedTables &T, const SeedLds &S, uint32_t l, uint32_t a) {
+    Hash2 h = {0, 0, 0, 0};
+    for (uint32_t m0 = 0; m0 < l; m0 += 16u) {
+        const uint32_t d = (a + m0) >> 4;
+        const uint32_t dw = __builtin_amdgcn_alignbit(S.codes[d + 1u], S.codes[d], 2u * ((a + m0) & 15u));  // 16 codes from a + m0
+        const uint32_t cnt = l - m0 < 16u ? l - m0 : 16u;
+        const uint32_t nq = cnt >> 2;
+        for (uint32_t q = 0; q < nq; ++q) {
+            const uint4 tv = T.quad[(dw >> (8u * q)) & 0xFFu];
+            const uint32_t nfhi = __builtin_amdgcn_alignbit(h.fhi, h.flo, 28), nflo = __builtin_amdgcn_alignbit(h.flo, h.fhi, 28);  // rol 4
+            const uint32_t nrlo = __builtin_amdgcn_alignbit(h.rhi, h.rlo, 4), nrhi = __builtin_amdgcn_alignbit(h.rlo, h.rhi, 4);    // ror 4
+            h.flo = nflo ^ tv.x;
+            h.fhi = nfhi ^ tv.y;
+            h.rlo = nrlo ^ tv.z;
+            h.rhi = nrhi ^ tv.w;
+        }
+        for (uint32_t m = 4u * nq; m < cnt; ++m) h.roll(T.warm[(dw >> (2u * m)) & 3u]);
     }
-};
+    return h;
+}
 
 // Rolls ntHash over windows [0, w_eff) of the tile's code stream; lane L owns windows [L*lc, (L+1)*lc), lc = ceil(w_eff/64).
-// Candidates (high-word test) go to the dense list in emission order; lane L's records, in slot order, are its windows in
-// position order.  Returns this lane's record count; wcount = records of the whole wave.
-__device__ __forceinline__ uint32_t seed_stage_b(const SeedTables &T, SeedLds &S, const DevParams &P, uint32_t w_eff,
-                                                 uint4 *__restrict__ spill, uint32_t &wcount_out) {
+// The outcome of every step's high-word test goes into the lane's flag word; nothing else is kept (stage R computes a
+// candidate's hashes again).  Steps past the last window (only the last active lane has them) may set bits too: stage R
+// masks them.  S.flags must be zero on entry for the blocks this lane does not write.
+__device__ __forceinline__ void seed_stage_b(const SeedTables &T, SeedLds &S, const DevParams &P, uint32_t w_eff) {
     const uint32_t lane = lane_id();
     const uint32_t l = P.l;
     const uint32_t lc = (w_eff + 63u) >> 6;
     const uint32_t s0 = lane * lc;
     const uint32_t bhi = (uint32_t)(P.bound >> 32);
-    uint32_t tagbase = lane << 16;  // | slot << 22
-    uint32_t wcount = 0;            // records written by the wave so far (wave-uniform)
     if (s0 < w_eff) {  // lanes beyond the last window sit out (exec-masked)
-        Hash2 h = {0, 0, 0, 0};
-        // 16 codes starting at code index a (any alignment)
-        auto codes16 = [&](uint32_t a) -> uint32_t {
-            const uint32_t d = a >> 4;
-            return __builtin_amdgcn_alignbit(S.codes[d + 1u], S.codes[d], 2u * (a & 15u));
-        };
-        // warm-up: the lane's first window, Horner form (fh = rol(fh,1)^h(c), rh = ror(rh,1)^rol(hc(c),l-1))
-        for (uint32_t m0 = 0; m0 < l; m0 += 16u) {
-            const uint32_t dw = codes16(s0 + m0);
-            const uint32_t cnt = l - m0 < 16u ? l - m0 : 16u;
-            for (uint32_t m = 0; m < cnt; ++m) h.roll(T.warm[(dw >> (2u * m)) & 3u]);
-        }
+        Hash2 h = window_hash(T, S, l, s0);  // the lane's first window
         // nibble m of xe / xo = out | in<<2 for step 2m / 2m+1 of a 16-step block
         auto mk_xe = [](uint32_t ow, uint32_t iw) { return (ow & 0x33333333u) | ((iw & 0x33333333u) << 2); };
         auto mk_xo = [](uint32_t ow, uint32_t iw) { return ((ow >> 2) & 0x33333333u) | (iw & 0xCCCCCCCCu); };
@@ -280,12 +309,12 @@ __device__ __forceinline__ uint32_t seed_stage_b(const SeedTables &T, SeedLds &S
             xe = mk_xe(ow, iw);
             xo = mk_xo(ow, iw);
         }
-        // ring of table values for the next four steps: their LDS reads are in flight while a step tests / emits
+        // ring of table values for the next four steps: their LDS reads are in flight while a step tests and rolls
         uint4 tv[4];
 #pragma unroll
         for (uint32_t s = 0; s < 4; ++s) tv[s] = T.roll[nib(xe, xo, s)];
         const uint32_t nb = (lc + 15u) >> 4;
-        uint32_t jbase = s0;  // j of step 0 of the current block
+        uint16_t *fl = reinterpret_cast<uint16_t *>(S.flags) + lane * SD_FLAG_BLKS;
         for (uint32_t blk = 0; blk < nb; ++blk) {
             uint32_t xe_n, xo_n;
             {
@@ -297,26 +326,11 @@ __device__ __forceinline__ uint32_t seed_stage_b(const SeedTables &T, SeedLds &S
                 xo_n = mk_xo(ow, iw);
             }
             const uint32_t lim = lc - 16u * blk;  // steps left (wave-uniform): the last block may be partial
+            uint32_t fbits = 0;                   // step t of the block ends up at bit 15 - t
             auto step = [&](uint32_t t) {
                 const uint32_t mhi = h.fhi < h.rhi ? h.fhi : h.rhi;
-                const bool cand = mhi <= bhi;  // high words only; the exact test runs in stage R
-                if (__ballot(cand)) {
-                    const uint64_t okm = __ballot(cand);
-                    if (cand) {
-                        const uint64_t F = ((uint64_t)h.fhi << 32) | h.flo, R = ((uint64_t)h.rhi << 32) | h.rlo;
-                        const uint64_t hv = F < R ? F : R;
-                        const uint32_t idx = wcount + mbcnt64(okm);
-                        const uint32_t tag = tagbase + jbase + t;
-                        if (idx < SD_CAND_CAP) {
-                            S.cand_hash[idx] = hv;
-                            S.cand_tag[idx] = tag;
-                        } else {
-                            spill[idx - SD_CAND_CAP] = make_uint4((uint32_t)hv, (uint32_t)(hv >> 32), tag, 0u);
-                        }
-                        tagbase += 1u << 22;
-                    }
-                    wcount += (uint32_t)__popcll(okm);
-                }
+                // fbits = 2 * fbits + (mhi <= bhi): v_cmp into vcc, v_addc with vcc as carry-in (high words only; the exact test runs in stage R)
+                asm("v_cmp_ge_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(fbits) : "v"(mhi), "s"(bhi) : "vcc");
                 h.roll(tv[t & 3u]);
                 tv[t & 3u] = (t + 4u < 16u) ? T.roll[nib(xe, xo, t + 4u)] : T.roll[nib(xe_n, xo_n, t + 4u - 16u)];
             };
@@ -328,14 +342,13 @@ __device__ __forceinline__ uint32_t seed_stage_b(const SeedTables &T, SeedLds &S
                 for (uint32_t t = 0; t < 16; ++t) {
                     if (t < lim) step(t);
                 }
+                fbits <<= 16u - lim;
             }
+            fl[blk] = (uint16_t)(__brev(fbits) >> 16);  // bit t <=> step t
             xe = xe_n;
             xo = xo_n;
-            jbase += 16u;
         }
     }
-    wcount_out = rdfirst(wcount);
-    return tagbase >> 22;
 }
 
 // ------------------------------------------------------------------ stage R
@@ -370,41 +383,60 @@ __device__ __forceinline__ uint32_t seed_rawpos(const SeedLds &S, uint32_t n_blo
     return raw_base + b * 64u + select_bit64(S.heads[b], j - (uint32_t)S.cnt[b]);
 }
 
-// Orders the tile's candidates, resolves their raw positions and appends them to the sequence's minimizer list.
-// Returns the number of minimizers appended; sets inexact when a candidate fails the exact 64-bit test (the sequence then
-// goes to the general path, whose test is exact by construction).
-__device__ __forceinline__ uint32_t seed_stage_r(SeedLds &S, const DevParams &P, uint32_t my_count, uint32_t total, const uint4 *__restrict__ spill,
-                                                 uint32_t w_eff, uint32_t n_blocks, uint32_t n_codes, uint32_t raw_base, uint32_t carry_n,
+// Lists the tile's candidates in position order (lane = candidate), resolves their raw positions and appends them to the
+// sequence's minimizer list.  Returns the number of minimizers appended; sets inexact when a candidate fails the exact
+// 64-bit test (the sequence then goes to the general path, whose test is exact by construction).
+__device__ __forceinline__ uint32_t seed_stage_r(const SeedTables &T, SeedLds &S, const DevParams &P, uint32_t w_eff,
+                                                 uint32_t n_blocks, uint32_t n_codes, uint32_t raw_base, uint32_t carry_n,
                                                  unsigned long long *__restrict__ mz_hash, uint32_t *__restrict__ mz_pos, uint32_t out_base,
                                                  uint32_t out_cap, bool &inexact) {
     const uint32_t lane = lane_id();
+    const uint32_t lc = (w_eff + 63u) >> 6;
+    // this lane's flags, masked to its real windows (steps [0, nv)); the masked words go back for the other lanes to read
+    unsigned long long *fw = &S.flags[lane * (SD_FLAG_BLKS / 4u)];
+    const uint32_t s0 = lane * lc;
+    const uint32_t nv = s0 < w_eff ? (w_eff - s0 < lc ? w_eff - s0 : lc) : 0u;
+    uint32_t my_count = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < SD_FLAG_BLKS / 4u; ++w) {
+        const uint32_t k = nv > 64u * w ? nv - 64u * w : 0u;
+        const unsigned long long f = fw[w] & (k >= 64u ? ~0ull : ((1ull << k) - 1ull));
+        fw[w] = f;
+        my_count += (uint32_t)__popcll(f);
+    }
     const uint32_t incl = wave_incl_scan_u32(my_count);
+    const uint32_t total = rdlane(incl, 63);
     S.lane_prefix[lane] = (uint16_t)(incl - my_count);
-    if (total > SD_CAND_CAP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's spill stores have reached L2
     wave_sync();
     const float scale = (float)n_blocks / (float)(n_codes ? n_codes : 1u);
-    uint32_t n_garbage = 0;
     for (uint32_t i0 = 0; i0 < total; i0 += 64u) {
         const uint32_t i = i0 + lane;
-        const bool act = i < total;
-        uint64_t hv = 0;
-        uint32_t tag = 0;
-        if (act) {
-            if (i < SD_CAND_CAP) {
-                hv = S.cand_hash[i];
-                tag = S.cand_tag[i];
-            } else {
-                const unsigned long long *rec = reinterpret_cast<const unsigned long long *>(spill + (i - SD_CAND_CAP));
-                hv = __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L2-served: never a stale L1 line
-                tag = (uint32_t)__hip_atomic_load(rec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i < total) {
+            // owner = the largest lane L with prefix[L] <= i (its count is then > 0)
+            uint32_t L = 0;
+#pragma unroll
+            for (uint32_t st = 32; st >= 1; st >>= 1)
+                if ((uint32_t)S.lane_prefix[L + st] <= i) L += st;
+            uint32_t e = i - (uint32_t)S.lane_prefix[L];  // rank of the step among L's candidate steps
+            const unsigned long long *lf = &S.flags[L * (SD_FLAG_BLKS / 4u)];
+            uint32_t t = 0;
+            unsigned long long word = lf[0];
+#pragma unroll
+            for (uint32_t w = 1; w < SD_FLAG_BLKS / 4u; ++w) {
+                const uint32_t c = (uint32_t)__popcll(word);
+                if (e >= c) {
+                    e -= c;
+                    word = lf[w];
+                    t = 64u * w;
+                }
             }
-        }
-        const uint32_t j = tag & 0xFFFFu;
-        const bool valid = act && j < w_eff;  // windows past the end belong to the last lane's last slots: they sort to the very end
-        n_garbage += (uint32_t)__popcll(__ballot(act && !valid));
-        if (valid) {
+            t += select_bit64(word, e);
+            const uint32_t j = L * lc + t;
+            const Hash2 wh = window_hash(T, S, P.l, j);
+            const uint64_t F = ((uint64_t)wh.fhi << 32) | wh.flo, R = ((uint64_t)wh.rhi << 32) | wh.rlo;
+            const uint64_t hv = F < R ? F : R;
             if (hv > P.bound) inexact = true;
-            const uint32_t dest = out_base + (uint32_t)S.lane_prefix[(tag >> 16) & 63u] + (tag >> 22);
+            const uint32_t dest = out_base + i;
             const uint32_t pos = seed_rawpos(S, n_blocks, scale, raw_base, carry_n, j);
             if (dest < out_cap) {
                 mz_hash[dest] = hv;
@@ -413,7 +445,7 @@ __device__ __forceinline__ uint32_t seed_stage_r(SeedLds &S, const DevParams &P,
         }
     }
     inexact = __ballot(inexact) != 0;
-    return total - n_garbage;
+    return total;
 }
 
 // Whole sequence through the fast path, tile by tile.  Returns the number of minimizers (may exceed out_cap: overflow, the
@@ -422,7 +454,7 @@ __device__ __forceinline__ uint32_t seed_stage_r(SeedLds &S, const DevParams &P,
 constexpr uint32_t SD_NOT_FAST = 0xFFFFFFFFu;
 template <bool TIMING = false>
 __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict__ seq, uint32_t len, const DevParams &P, const SeedTables &T,
-                                                       SeedLds &S, uint4 *__restrict__ spill, unsigned long long *__restrict__ mz_hash,
+                                                       SeedLds &S, unsigned long long *__restrict__ mz_hash,
                                                        uint32_t *__restrict__ mz_pos, uint32_t out_cap, unsigned long long *tacc = nullptr) {
     const uint32_t lane = lane_id();
     uint32_t raw0 = 0, carry_n = 0, carry_prev = 0, n_out = 0;
@@ -436,12 +468,11 @@ __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict
         const bool more = raw_end < len;
         if (n_codes >= P.l) {
             const uint32_t w_eff = n_codes - P.l + 1u;
-            uint32_t total = 0;
-            const uint32_t my = seed_stage_b(T, S, P, w_eff, spill, total);
+            seed_stage_b(T, S, P, w_eff);
             const unsigned long long t2 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
             if (TIMING) tacc[1] += t2 - t1;
             bool inexact = false;
-            n_out += seed_stage_r(S, P, my, total, spill, w_eff, n_blocks, n_codes, raw0, carry_n, mz_hash, mz_pos, n_out, out_cap, inexact);
+            n_out += seed_stage_r(T, S, P, w_eff, n_blocks, n_codes, raw0, carry_n, mz_hash, mz_pos, n_out, out_cap, inexact);
             if (inexact) return SD_NOT_FAST;
             if (TIMING) tacc[2] += __builtin_amdgcn_s_memtime() - t2;
         }

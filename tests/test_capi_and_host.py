@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_abi_version_and_defaults(lib):
     import mapquik_amd
-    assert lib.mq_abi_version() == 1
+    assert lib.mq_abi_version() == 2
     p = mapquik_amd.Params()
     q = mapquik_amd.Params(0, 0, 0.0, False, 0, 0, 0)
     lib.mq_params_default(C.byref(q))

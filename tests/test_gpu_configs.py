@@ -76,7 +76,7 @@ def test_config3_chm13_like_full_scale(mq, oracle, simlib):
     want, diag = ox.map_batch_diag(sb, so, po, threads=T)
     # the full batch through the device-resident entry point (what bench.py times)
     d_b, d_o, d_h = DevBuf.from_numpy(bases), DevBuf.from_numpy(offs), DevBuf(n * 40)
-    ml = int((offs[1:] - offs[:-1]).max())
+    ml = int(offs[-1] - offs[0])  # total bases of the batch
     ix.map_batch_device(d_b.ptr, d_o.ptr, n, ml, d_h.ptr, 0)
     hits = d_h.to_numpy(mq.hit_dtype, n)
     assert (hits["status"] == 2).sum() == 0
