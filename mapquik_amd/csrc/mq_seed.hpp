@@ -1,7 +1,9 @@
 // mq_seed.hpp -- the fast seeder: an ACGT-only sequence -> its ordered minimizer list (hash, raw position) in HBM.
 //
-// One wave per sequence, tile by tile (8192 raw bases = two super-rows of 64 bases per lane); per-wave LDS 5.9 KB so that 24
-// waves (6 per SIMD) share a CU.  Everything lives in LDS between the stages; nothing but the final list goes to HBM.
+// One wave per sequence, tile by tile (12,288 raw bases = three super-rows of 64 bases per lane); per-wave LDS 7.5 KB, so that
+// workgroups of 4 waves (36 KB with the shared tables) run 4 to a CU.  Everything lives in LDS between the stages; nothing but
+// the final list goes to HBM.  (Measured on MI355X: 2 super-rows 920, 3 super-rows 950 Gbases/s; 5 or 6 waves per SIMD at
+// 2 super-rows bought nothing, the fused kernel needs 128 VGPRs for its map phase.)
 //   stage A  decode + homopolymer compression: SWAR ASCII -> 2-bit codes (OR-merge + 4x4 transpose of 2-bit elements),
 //            validity by v_perm_b32 reconstruction, a 1024-entry LDS look-up (previous code + 4 codes -> compacted codes,
 //            count, run-head bits), one DPP prefix sum per super-row, ds_or of the packed codes into the tile's code stream.
@@ -23,13 +25,16 @@
 namespace mq {
 
 constexpr uint32_t SD_SR_RAW = 4096;                       // raw bases per super-row: 64 per lane
-constexpr uint32_t SD_MAX_SR = 2;                          // super-rows per tile
-constexpr uint32_t SD_TILE_RAW = SD_SR_RAW * SD_MAX_SR;    // 8192
+#ifndef MQ_SD_MAX_SR
+#define MQ_SD_MAX_SR 3
+#endif
+constexpr uint32_t SD_MAX_SR = MQ_SD_MAX_SR;               // super-rows per tile
+constexpr uint32_t SD_TILE_RAW = SD_SR_RAW * SD_MAX_SR;    // 12288
 constexpr uint32_t SD_BLOCKS = SD_TILE_RAW / 64;           // 64-base blocks per tile
 constexpr uint32_t SD_CODES_MAX = SD_TILE_RAW + MAX_L - 1; // codes of one tile incl. the carried l-1 (no compression at all)
 constexpr uint32_t SD_LC_MAX = (SD_CODES_MAX + 63) / 64;   // windows per lane
-constexpr uint32_t SD_CODES_DW = 528;                      // packed 2-bit codes + zero read-ahead padding
-constexpr uint32_t SD_FLAG_BLKS = 12;                      // 16-step blocks per lane (flag words of 16 bits), padded to 3 x 64 bits
+constexpr uint32_t SD_FLAG_BLKS = 4 * ((SD_LC_MAX + 63) / 64);  // 16-step blocks per lane (flag words of 16 bits), padded to whole 64-bit words
+constexpr uint32_t SD_CODES_DW = 4 * ((63 * SD_LC_MAX + 16 * ((SD_LC_MAX + 15) / 16) + MAX_L + 32) / 64 + 1);  // packed 2-bit codes + zero read-ahead padding (whole uint4s)
 static_assert((63 * SD_LC_MAX + 16 * ((SD_LC_MAX + 15) / 16) + MAX_L + 32) / 16 < SD_CODES_DW, "code stream read-ahead padding");
 static_assert((SD_LC_MAX + 15) / 16 <= SD_FLAG_BLKS && SD_FLAG_BLKS % 4 == 0, "flag words");
 
