@@ -49,8 +49,11 @@ typedef struct mq_params {
     uint32_t c;       /* minimum chain length, default 4 */
     uint32_t s;       /* minimum matching seeds, default 11 */
     uint32_t g;       /* maximum gap difference, default 2000 */
-    uint32_t reserved;
+    uint32_t flags;   /* MQ_FLAG_*; default 0 */
 } mq_params;
+/* The reference upper-cases every sequence before the seam (to_ascii_uppercase, src/closures.rs:63,106).  With this flag the
+ * kernels treat a-z as A-Z themselves, so a feeder can hand over raw FASTX bytes without touching them. */
+#define MQ_FLAG_FOLD_CASE 1u
 
 /* One k-min-mer as the reference's KminmerHash exposes it (fields used at src/index.rs:57-58,101). 24 bytes. */
 typedef struct mq_kminmer {
@@ -148,6 +151,11 @@ int mq_ctx_map_batch(mq_ctx *ctx, const uint8_t *bases, const uint64_t *offsets,
  * in page-locked memory (mq_host_alloc) overlaps the copy with other contexts' kernels. */
 int mq_ctx_submit(mq_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out);
 int mq_ctx_wait(mq_ctx *ctx);
+/* Spans form of mq_ctx_submit for raw FASTX buffers: the whole buffer buf[0, buf_bytes) goes to the device as it is (headers,
+ * line ends, quality lines and all) and read i is buf[starts[i], starts[i] + lens[i]); spans in order and disjoint.  With
+ * MQ_FLAG_FOLD_CASE the host never has to touch a base.  starts/lens/buf/out must stay valid until mq_ctx_wait. */
+int mq_ctx_submit_spans(mq_ctx *ctx, const uint8_t *buf, uint64_t buf_bytes, const uint64_t *starts, const uint32_t *lens, uint32_t n,
+                        mq_hit *out);
 /* mq_map_batch_device on this context. */
 int mq_ctx_map_batch_device(mq_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases,
                             mq_hit *d_out, void *stream);

@@ -12,6 +12,7 @@ import numpy as np
 from . import build as _build
 
 MQ_HIT_UNMAPPED, MQ_HIT_MAPPED, MQ_HIT_OVERFLOW = 0, 1, 2
+MQ_FLAG_FOLD_CASE = 1
 
 hit_dtype = np.dtype([("status", "<u4"), ("ref_id", "<u4"), ("rc", "<u4"), ("mapq", "<u4"), ("q_start", "<u4"), ("q_end", "<u4"),
                       ("r_start", "<u4"), ("r_end", "<u4"), ("score", "<u4"), ("n_kminmers", "<u4")])
@@ -23,7 +24,7 @@ EXPORTS = ["mq_last_error", "mq_abi_version", "mq_device_count", "mq_params_defa
            "mq_index_add_ref", "mq_index_add_ref_device", "mq_index_finalize", "mq_index_get_stats", "mq_index_ref_info",
            "mq_map_batch", "mq_map_batch_device", "mq_map_reserve", "mq_kminmers_batch", "mq_index_lookup", "mq_format_paf",
            "mq_last_map_ms", "mq_last_map_path_counts", "mq_host_alloc", "mq_host_free", "mq_index_save", "mq_index_load", "mq_map_probe_stats",
-           "mq_ctx_new", "mq_ctx_free", "mq_ctx_map_batch", "mq_ctx_submit", "mq_ctx_wait", "mq_ctx_map_batch_device", "mq_ctx_last_map_ms", "mq_probe_rate"]
+           "mq_ctx_new", "mq_ctx_free", "mq_ctx_map_batch", "mq_ctx_submit", "mq_ctx_submit_spans", "mq_ctx_wait", "mq_ctx_map_batch_device", "mq_ctx_last_map_ms", "mq_probe_rate"]
 
 
 class MapquikError(RuntimeError):
@@ -33,10 +34,10 @@ class MapquikError(RuntimeError):
 class Params(C.Structure):
     """src/main.rs:33-47; defaults src/main.rs:174-188."""
     _fields_ = [("k", C.c_uint32), ("l", C.c_uint32), ("density", C.c_double), ("use_hpc", C.c_uint32), ("c", C.c_uint32),
-                ("s", C.c_uint32), ("g", C.c_uint32), ("reserved", C.c_uint32)]
+                ("s", C.c_uint32), ("g", C.c_uint32), ("flags", C.c_uint32)]
 
-    def __init__(self, k=5, l=31, density=0.01, use_hpc=True, c=4, s=11, g=2000):
-        super().__init__(k, l, density, 1 if use_hpc else 0, c, s, g, 0)
+    def __init__(self, k=5, l=31, density=0.01, use_hpc=True, c=4, s=11, g=2000, fold_case=False):
+        super().__init__(k, l, density, 1 if use_hpc else 0, c, s, g, MQ_FLAG_FOLD_CASE if fold_case else 0)
 
 
 class IndexStats(C.Structure):
@@ -87,6 +88,7 @@ def load_library(path=None):
     L.mq_ctx_free.argtypes = [vp]
     L.mq_ctx_map_batch.argtypes = [vp, vp, vp, u32, vp]
     L.mq_ctx_submit.argtypes = [vp, vp, vp, u32, vp]
+    L.mq_ctx_submit_spans.argtypes = [vp, vp, u64, vp, vp, u32, vp]
     L.mq_ctx_wait.argtypes = [vp]
     L.mq_ctx_map_batch_device.argtypes = [vp, vp, vp, u32, u64, vp, vp]
     L.mq_ctx_last_map_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -361,6 +363,17 @@ class Context:
         if n > 0 and self._L.mq_ctx_submit(self._h, _p(bases), _p(offsets), n, _p(out)) != 0:
             raise _err(self._L, "mq_ctx_submit")
         self._keep = (bases, offsets, out)
+
+    def submit_spans(self, buf, starts, lens):
+        """Queue reads given as spans of a raw buffer (FASTX bytes as they are): read i = buf[starts[i] : starts[i] + lens[i]]."""
+        buf = _seq(buf)
+        starts = np.ascontiguousarray(starts, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        n = starts.size
+        out = np.zeros(max(n, 0), dtype=hit_dtype)
+        if n > 0 and self._L.mq_ctx_submit_spans(self._h, _p(buf), buf.size, _p(starts), _p(lens), n, _p(out)) != 0:
+            raise _err(self._L, "mq_ctx_submit_spans")
+        self._keep = (buf, starts, out, lens)
 
     def wait(self):
         if self._L.mq_ctx_wait(self._h) != 0:

@@ -43,12 +43,26 @@ def build_cli(force=False, verbose=False):
     build(force=False, verbose=verbose)
     if not force and os.path.exists(CLI) and all(os.path.getmtime(CLI) >= os.path.getmtime(d) for d in _cli_deps() + [LIB]):
         return CLI
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI, CLI_SRC, "-L" + LIBDIR, "-lmapquik_hip", "-lz", "-lpthread",
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", CLI, CLI_SRC, "-L" + LIBDIR, "-lmapquik_hip", "-lz", "-lpthread", "-ldl",
            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + "/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return CLI
+
+
+FEEDER_DUMP = os.path.join(LIBDIR, "feeder_dump")
+
+
+def build_feeder_dump(force=False):
+    """Test tool for the FASTX feeder (host only, no GPU): lib/feeder_dump."""
+    src = os.path.join(HOST_DIR, "feeder_dump.cc")
+    deps = [src, os.path.join(HOST_DIR, "fastx_feeder.hpp")]
+    if not force and os.path.exists(FEEDER_DUMP) and all(os.path.getmtime(FEEDER_DUMP) >= os.path.getmtime(d) for d in deps):
+        return FEEDER_DUMP
+    os.makedirs(LIBDIR, exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", FEEDER_DUMP, src, "-lz", "-lpthread", "-ldl"])
+    return FEEDER_DUMP
 
 
 def is_fresh():

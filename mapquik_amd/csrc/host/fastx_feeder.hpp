@@ -1,0 +1,495 @@
+// fastx_feeder.hpp -- the read feeder of the native driver: FASTA/FASTQ (raw, gzip, lz4) -> page-locked chunks of raw file
+// bytes + per-read spans, ready for mq_ctx_submit_spans.  Replaces what the reference gets from seq_io's worker pool and
+// get_reader (src/main.rs:60-75, src/closures.rs:177-187).
+//
+// Design: a base is copied ONCE on the host (file / inflate output -> page-locked chunk) and never touched again: the
+// chunk goes to the GPU as it is (headers, line ends, quality lines), reads are (start, length) spans of it, and the
+// kernels fold a-z to A-Z themselves (MQ_FLAG_FOLD_CASE).  Raw files are cut into chunks at record boundaries and read
+// with pread by N threads in parallel; compressed input is inflated by one thread straight into chunks (gzip and lz4
+// streams are sequential by nature) and parsed by the others.  Multi-line FASTA records are compacted in place.
+#pragma once
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/mapquik_hip.h"
+
+namespace mapquik {
+namespace feeder {
+
+struct IdSpan {
+    uint64_t off;
+    uint32_t len;
+};
+
+// one unit of work through the pipeline: raw bytes + the reads found in them
+struct Chunk {
+    size_t seq_no = 0;
+    uint8_t *buf = nullptr;  // page-locked (mq_host_alloc)
+    uint64_t cap = 0, begin = 0, bytes = 0;  // whole records occupy buf[begin, bytes)
+    std::vector<uint64_t> starts;
+    std::vector<uint32_t> lens;
+    std::vector<IdSpan> ids;
+    std::vector<mq_hit> hits;
+    std::string paf, unmapped;  // formatted output of this chunk
+    void clear() {
+        begin = bytes = 0;
+        starts.clear();
+        lens.clear();
+        ids.clear();
+        hits.clear();
+        paf.clear();
+        unmapped.clear();
+    }
+};
+
+struct FeederError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// ---------------------------------------------------------------- record boundaries
+constexpr uint64_t NEED_MORE = ~0ull;
+
+// 1: a FASTQ record starts at p; 0: it does not; 2: cannot tell without bytes beyond `end` (never when at_eof)
+inline int fastq_record_at(const uint8_t *b, uint64_t p, uint64_t end, bool at_eof) {
+    // '@' at a line start whose line after next starts with '+' and whose quality line is as long as its sequence line:
+    // tells a header from a quality line that happens to begin with '@'
+    if (p >= end) return at_eof ? 0 : 2;
+    if (b[p] != '@') return 0;
+    const int unknown = at_eof ? 1 : 2;
+    const uint8_t *e1 = (const uint8_t *)memchr(b + p, '\n', end - p);
+    if (!e1) return unknown;
+    const uint8_t *e2 = (const uint8_t *)memchr(e1 + 1, '\n', b + end - (e1 + 1));
+    if (!e2 || e2 + 1 >= b + end) return unknown;
+    if (e2[1] != '+') return 0;
+    const uint8_t *e3 = (const uint8_t *)memchr(e2 + 1, '\n', b + end - (e2 + 1));
+    if (!e3) return unknown;
+    const uint8_t *e4 = (const uint8_t *)memchr(e3 + 1, '\n', b + end - (e3 + 1));
+    if (!e4) return at_eof ? ((b + end - e3) == (e2 - e1) ? 1 : 0) : 2;  // last record of a file without a final newline
+    return (e4 - e3) == (e2 - e1) ? 1 : 0;
+}
+
+// first record start at or after `from`; `end` if there is none; NEED_MORE if that cannot be decided inside [.., end)
+inline uint64_t next_record_start(const uint8_t *b, uint64_t from, uint64_t end, bool fastq, bool at_eof) {
+    uint64_t p = from;
+    if (p > 0 && b[p - 1] != '\n') {  // move to the next line start
+        const uint8_t *e = (const uint8_t *)memchr(b + p, '\n', end - p);
+        if (!e) return at_eof ? end : NEED_MORE;
+        p = (uint64_t)(e - b) + 1;
+    }
+    while (p < end) {
+        if (fastq) {
+            const int r = fastq_record_at(b, p, end, at_eof);
+            if (r == 1) return p;
+            if (r == 2) return NEED_MORE;
+        } else if (b[p] == '>') {
+            return p;
+        }
+        const uint8_t *e = (const uint8_t *)memchr(b + p, '\n', end - p);
+        if (!e) return at_eof ? end : NEED_MORE;
+        p = (uint64_t)(e - b) + 1;
+    }
+    return at_eof ? end : NEED_MORE;
+}
+
+// ---------------------------------------------------------------- parser: whole records in c.buf[0, c.bytes) -> spans
+inline void parse_chunk(Chunk &c, bool fastq) {
+    uint8_t *b = c.buf;
+    const uint64_t end = c.bytes;
+    uint64_t p = c.begin;
+    auto line_end = [&](uint64_t from) -> uint64_t {
+        const uint8_t *e = (const uint8_t *)memchr(b + from, '\n', end - from);
+        return e ? (uint64_t)(e - b) : end;
+    };
+    auto add_id = [&](uint64_t h0, uint64_t h1) {  // first word after the marker (seq_io's id())
+        uint64_t s = h0 + 1, e = s;
+        while (e < h1 && b[e] != ' ' && b[e] != '\t' && b[e] != '\r') ++e;
+        c.ids.push_back({s, (uint32_t)(e - s)});
+    };
+    while (p < end) {
+        if (b[p] == '\n' || b[p] == '\r') { ++p; continue; }
+        if (fastq) {
+            if (b[p] != '@') throw FeederError("malformed FASTQ record");
+            const uint64_t e1 = line_end(p);
+            add_id(p, e1);
+            const uint64_t s = e1 + 1 < end ? e1 + 1 : end;
+            const uint64_t e2 = line_end(s);
+            uint64_t sl = e2 - s;
+            if (sl && b[s + sl - 1] == '\r') --sl;
+            c.starts.push_back(s);
+            c.lens.push_back((uint32_t)sl);
+            const uint64_t e3 = e2 < end ? line_end(e2 + 1) : end;                 // '+' line
+            uint64_t e4 = e3 < end ? e3 + 1 + (e2 - s) : end;                       // quality: as long as the sequence line
+            if (e4 > end || (e4 < end && b[e4] != '\n')) e4 = e3 < end ? line_end(e3 + 1) : end;
+            p = e4 < end ? e4 + 1 : end;
+        } else {
+            if (b[p] != '>') throw FeederError("malformed FASTA record");
+            const uint64_t e1 = line_end(p);
+            add_id(p, e1);
+            uint64_t s = e1 + 1 < end ? e1 + 1 : end;
+            uint64_t e2 = line_end(s);
+            uint64_t dst = e2;
+            if (dst > s && b[dst - 1] == '\r') --dst;
+            uint64_t q = e2 < end ? e2 + 1 : end;
+            while (q < end && b[q] != '>') {  // further sequence lines: compact them onto the first one
+                const uint64_t e = line_end(q);
+                uint64_t n = e - q;
+                if (n && b[q + n - 1] == '\r') --n;
+                if (n) memmove(b + dst, b + q, n);
+                dst += n;
+                q = e < end ? e + 1 : end;
+            }
+            if (dst - s >= (1ull << 32)) throw FeederError("sequence length must be < 2^32");
+            c.starts.push_back(s);
+            c.lens.push_back((uint32_t)(dst - s));
+            p = q;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- lz4 frame decoder through liblz4.so.1 (no headers in the image)
+struct Lz4 {
+    void *lib = nullptr;
+    void *ctx = nullptr;
+    size_t (*create)(void **, unsigned) = nullptr;
+    size_t (*free_)(void *) = nullptr;
+    size_t (*decompress)(void *, void *, size_t *, const void *, size_t *, const void *) = nullptr;
+    unsigned (*is_error)(size_t) = nullptr;
+    Lz4() {
+        lib = dlopen("liblz4.so.1", RTLD_NOW);
+        if (!lib) throw FeederError("Error opening compressed file: liblz4.so.1 not found");
+        create = (size_t(*)(void **, unsigned))dlsym(lib, "LZ4F_createDecompressionContext");
+        free_ = (size_t(*)(void *))dlsym(lib, "LZ4F_freeDecompressionContext");
+        decompress = (size_t(*)(void *, void *, size_t *, const void *, size_t *, const void *))dlsym(lib, "LZ4F_decompress");
+        is_error = (unsigned (*)(size_t))dlsym(lib, "LZ4F_isError");
+        if (!create || !free_ || !decompress || !is_error || is_error(create(&ctx, 100))) throw FeederError("liblz4: LZ4F API not usable");
+    }
+    ~Lz4() {
+        if (ctx) free_(ctx);
+        if (lib) dlclose(lib);
+    }
+};
+
+// ---------------------------------------------------------------- the feeder
+class Feeder {
+  public:
+    // chunk_bytes: target raw bytes per chunk; n_threads: reader/parser threads
+    // alloc/release: where chunk buffers come from (page-locked memory through mq_host_alloc unless a test says otherwise)
+    Feeder(const std::string &path, bool fastq, uint64_t chunk_bytes, int n_threads, int max_chunks,
+           std::function<void *(size_t)> alloc = mq_host_alloc, std::function<void(void *)> release = mq_host_free)
+        : path_(path), fastq_(fastq), chunk_bytes_(chunk_bytes < 64 ? 64 : chunk_bytes), n_threads_(n_threads < 1 ? 1 : n_threads),
+          max_chunks_(max_chunks), alloc_(alloc), release_(release) {
+        auto ends = [&](const char *t) {
+            const size_t n = strlen(t);
+            return path.size() >= n && path.compare(path.size() - n, n, t) == 0;
+        };
+        kind_ = ends(".gz") ? 1 : ends(".lz4") ? 2 : 0;
+        fd_ = open(path.c_str(), O_RDONLY);
+        if (fd_ < 0) throw FeederError("Error opening compressed file: " + path);  // get_reader's message (src/main.rs:62)
+        struct stat st;
+        fstat(fd_, &st);
+        file_size_ = (uint64_t)st.st_size;
+        if (kind_ == 0) {
+            if (chunk_bytes_ > file_size_ + 1) chunk_bytes_ = file_size_ + 1;
+            n_raw_chunks_ = (size_t)((file_size_ + chunk_bytes_ - 1) / chunk_bytes_);
+        }
+    }
+    ~Feeder() {
+        stop();
+        for (auto &c : all_) release_(c->buf);
+        if (fd_ >= 0) close(fd_);
+    }
+
+    void start() {
+        if (kind_ == 0) {
+            for (int t = 0; t < n_threads_; ++t) threads_.emplace_back([this] { raw_worker(); });
+        } else {
+            threads_.emplace_back([this] { inflate_worker(); });
+            for (int t = 0; t < n_threads_; ++t) threads_.emplace_back([this] { parse_worker(); });
+        }
+    }
+
+    // next parsed chunk (any order; seq_no says where it belongs) or nullptr at the end of the input
+    Chunk *next() {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return !ready_.empty() || finished_locked() || !error_.empty(); });
+        if (!error_.empty()) throw FeederError(error_);
+        if (ready_.empty()) return nullptr;
+        Chunk *c = ready_.front();
+        ready_.pop_front();
+        return c;
+    }
+    // hand a chunk back for re-use
+    void recycle(Chunk *c) {
+        c->clear();
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            free_.push_back(c);
+        }
+        cv_.notify_all();
+    }
+    size_t chunks_total() const { return produced_.load(); }
+    uint64_t bytes_in() const { return file_size_; }
+
+  private:
+    bool finished_locked() const { return done_workers_ == (int)threads_.size(); }
+
+    Chunk *get_buffer(uint64_t need, bool force = false) {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            for (auto it = free_.begin(); it != free_.end(); ++it)
+                if ((*it)->cap >= need) {
+                    Chunk *c = *it;
+                    free_.erase(it);
+                    return c;
+                }
+            if (force || (int)all_.size() < max_chunks_ || free_.size() == all_.size()) {  // grow the pool (or replace a too-small buffer when nothing is in flight)
+                lk.unlock();
+                std::unique_ptr<Chunk> c(new Chunk());
+                const uint64_t cap = std::max<uint64_t>(need, std::min<uint64_t>(chunk_bytes_ + chunk_bytes_ / 8 + (1u << 20), file_size_ + 64));
+                c->buf = (uint8_t *)alloc_(cap);
+                if (!c->buf) throw FeederError("cannot allocate a chunk buffer");
+                c->cap = cap;
+                lk.lock();
+                all_.push_back(std::move(c));
+                return all_.back().get();
+            }
+            if (stopping_) throw FeederError("stopped");
+            cv_.wait(lk);
+        }
+    }
+
+    void publish(Chunk *c) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            ready_.push_back(c);
+        }
+        produced_++;
+        cv_.notify_all();
+    }
+    void worker_done(const std::string &err) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (!err.empty() && error_.empty()) error_ = err;
+            done_workers_++;
+        }
+        cv_.notify_all();
+    }
+
+    // raw file: chunk i owns the records whose first byte lies in [i*CH, (i+1)*CH)
+    void raw_worker() {
+        std::string err;
+        try {
+            for (;;) {
+                // buffer first, chunk number second: every numbered chunk then owns a buffer, so the consumer (which may hold
+                // later chunks while it waits for an earlier one) can never starve the earliest chunk of memory
+                Chunk *c = get_buffer(std::min<uint64_t>(chunk_bytes_ + (1u << 20) + 2, file_size_ + 2));
+                const size_t i = next_raw_.fetch_add(1);
+                if (i >= n_raw_chunks_) {
+                    recycle(c);
+                    break;
+                }
+                const uint64_t lo = (uint64_t)i * chunk_bytes_, hi = std::min<uint64_t>(lo + chunk_bytes_, file_size_);
+                // read [lo - 1, hi + tail): one byte before to know whether lo is a line start; the tail until the owning
+                // record of hi's successor is complete (grown as needed)
+                uint64_t tail = std::min<uint64_t>(1u << 20, file_size_ - hi);
+                for (;;) {
+                    const uint64_t from = lo ? lo - 1 : 0, want = hi + tail - from;
+                    if (c->cap < want) {  // a record longer than the tail: a private, larger buffer (beyond the pool limit if need be)
+                        recycle(c);
+                        c = get_buffer(want, true);
+                    }
+                    uint64_t got = 0;
+                    while (got < want) {
+                        const ssize_t r = pread(fd_, c->buf + got, want - got, (off_t)(from + got));
+                        if (r <= 0) throw FeederError("read error: " + path_);
+                        got += (uint64_t)r;
+                    }
+                    const uint64_t skip = lo ? 1 : 0;  // index of byte `lo` in the buffer
+                    const bool at_eof = hi + tail >= file_size_;
+                    const uint64_t first = lo ? next_record_start(c->buf, skip, got, fastq_, at_eof) : 0;
+                    uint64_t last = got;
+                    if (first != NEED_MORE && hi < file_size_) last = next_record_start(c->buf, skip + (hi - lo), got, fastq_, at_eof);
+                    if (first == NEED_MORE || last == NEED_MORE) {  // the record that straddles hi is longer than the tail
+                        tail = std::min<uint64_t>(tail * 4, file_size_ - hi);
+                        continue;
+                    }
+                    if (first >= last || first >= skip + (hi - lo)) {
+                        c->begin = c->bytes = 0;  // no record starts in this chunk (inside a long record)
+                    } else {
+                        c->begin = first;
+                        c->bytes = last;
+                    }
+                    break;
+                }
+                c->seq_no = i;
+                parse_chunk(*c, fastq_);
+                publish(c);
+            }
+        } catch (const std::exception &e) { err = e.what(); }
+        worker_done(err);
+    }
+
+    // compressed input: one thread inflates into chunks cut at record boundaries; parse_worker threads parse them
+    void inflate_worker() {
+        std::string err;
+        try {
+            std::vector<uint8_t> in(4u << 20);
+            z_stream zs;
+            memset(&zs, 0, sizeof(zs));
+            std::unique_ptr<Lz4> lz;
+            if (kind_ == 1) {
+                if (inflateInit2(&zs, 15 + 32) != Z_OK) throw FeederError("inflateInit2 failed");
+            } else {
+                lz.reset(new Lz4());
+            }
+            const uint64_t cap_need = chunk_bytes_ + chunk_bytes_ / 8 + (1u << 20);
+            Chunk *c = get_buffer(cap_need);
+            size_t seq = 0;
+            uint64_t file_pos = 0;
+            size_t in_have = 0, in_pos = 0;
+            bool eof = false;
+            auto cut_and_publish = [&](bool final) {
+                // keep whole records in c, carry the incomplete last one to a fresh chunk
+                Chunk *nxt = nullptr;
+                uint64_t keep = c->bytes;
+                if (!final) {
+                    // last record start in the second half of the buffer
+                    uint64_t p = c->bytes / 2, lastrec = 0;
+                    for (;;) {  // candidates too close to the end to be validated are not taken: the cut lands on a sure record start
+                        const uint64_t q = next_record_start(c->buf, p, c->bytes, fastq_, false);
+                        if (q == NEED_MORE || q >= c->bytes) break;
+                        lastrec = q;
+                        p = q + 1;
+                    }
+                    if (lastrec == 0) throw FeederError("a single record does not fit a chunk: raise --batch-bases");
+                    keep = lastrec;
+                    nxt = get_buffer(cap_need);
+                    memcpy(nxt->buf, c->buf + keep, c->bytes - keep);
+                    nxt->bytes = c->bytes - keep;
+                }
+                c->bytes = keep;
+                c->seq_no = seq++;
+                {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    to_parse_.push_back(c);
+                }
+                cv_.notify_all();
+                c = nxt;
+            };
+            while (!eof) {
+                if (in_pos == in_have) {
+                    const ssize_t r = pread(fd_, in.data(), in.size(), (off_t)file_pos);
+                    if (r < 0) throw FeederError("read error: " + path_);
+                    if (r == 0) break;
+                    file_pos += (uint64_t)r;
+                    in_have = (size_t)r;
+                    in_pos = 0;
+                }
+                while (in_pos < in_have) {
+                    if (c->bytes + (1u << 16) > c->cap - 64 || c->bytes >= chunk_bytes_) cut_and_publish(false);
+                    size_t produced = 0, consumed = 0;
+                    if (kind_ == 1) {
+                        zs.next_in = in.data() + in_pos;
+                        zs.avail_in = (uInt)(in_have - in_pos);
+                        zs.next_out = c->buf + c->bytes;
+                        zs.avail_out = (uInt)std::min<uint64_t>(c->cap - 64 - c->bytes, 1u << 30);
+                        const uInt out0 = zs.avail_out;
+                        const int rc = inflate(&zs, Z_NO_FLUSH);
+                        consumed = (in_have - in_pos) - zs.avail_in;
+                        produced = out0 - zs.avail_out;
+                        if (rc == Z_STREAM_END) {
+                            if (zs.avail_in > 0 || file_pos < file_size_) inflateReset(&zs);  // concatenated gzip members
+                        } else if (rc != Z_OK && rc != Z_BUF_ERROR) {
+                            throw FeederError("gzip stream corrupt: " + path_);
+                        }
+                    } else {
+                        size_t dst = (size_t)(c->cap - 64 - c->bytes), src = in_have - in_pos;
+                        const size_t rc = lz->decompress(lz->ctx, c->buf + c->bytes, &dst, in.data() + in_pos, &src, nullptr);
+                        if (lz->is_error(rc)) throw FeederError("lz4 stream corrupt: " + path_);
+                        consumed = src;
+                        produced = dst;
+                    }
+                    in_pos += consumed;
+                    c->bytes += produced;
+                    if (!consumed && !produced) break;
+                }
+            }
+            if (kind_ == 1) inflateEnd(&zs);
+            cut_and_publish(true);
+        } catch (const std::exception &e) { err = e.what(); }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            inflate_done_ = true;
+        }
+        worker_done(err);
+    }
+
+    void parse_worker() {
+        std::string err;
+        try {
+            for (;;) {
+                Chunk *c = nullptr;
+                {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [&] { return !to_parse_.empty() || inflate_done_ || stopping_; });
+                    if (to_parse_.empty()) break;
+                    c = to_parse_.front();
+                    to_parse_.pop_front();
+                }
+                parse_chunk(*c, fastq_);
+                publish(c);
+            }
+        } catch (const std::exception &e) { err = e.what(); }
+        worker_done(err);
+    }
+
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stopping_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_)
+            if (t.joinable()) t.join();
+        threads_.clear();
+    }
+
+    std::string path_;
+    bool fastq_;
+    uint64_t chunk_bytes_;
+    int n_threads_, max_chunks_;
+    std::function<void *(size_t)> alloc_;
+    std::function<void(void *)> release_;
+    int kind_ = 0;  // 0 raw, 1 gzip, 2 lz4
+    int fd_ = -1;
+    uint64_t file_size_ = 0;
+    size_t n_raw_chunks_ = 0;
+    std::atomic<size_t> next_raw_{0}, produced_{0};
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<std::unique_ptr<Chunk>> all_;
+    std::deque<Chunk *> free_, ready_, to_parse_;
+    std::vector<std::thread> threads_;
+    int done_workers_ = 0;
+    bool inflate_done_ = false, stopping_ = false;
+    std::string error_;
+};
+
+}  // namespace feeder
+}  // namespace mapquik

@@ -1,0 +1,46 @@
+// feeder_dump -- test tool for fastx_feeder.hpp (no GPU needed: chunk buffers come from malloc).
+// usage: feeder_dump <file> <fasta|fastq> <chunk_bytes> <threads>   -> one line per read, in input order: id TAB length TAB sequence
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+
+#include "fastx_feeder.hpp"
+
+int main(int argc, char **argv) {
+    if (argc < 5) return 2;
+    using namespace mapquik::feeder;
+    try {
+        Feeder f(argv[1], std::string(argv[2]) == "fastq", strtoull(argv[3], nullptr, 10), atoi(argv[4]), atoi(argv[4]) + 4,
+                 [](size_t n) { return malloc(n); }, [](void *p) { free(p); });
+        f.start();
+        std::map<size_t, Chunk *> held;
+        size_t next = 0;
+        auto flush = [&]() {
+            for (auto it = held.find(next); it != held.end(); it = held.find(next)) {
+                Chunk *c = it->second;
+                for (size_t i = 0; i < c->starts.size(); ++i) {
+                    fwrite(c->buf + c->ids[i].off, 1, c->ids[i].len, stdout);
+                    printf("\t%u\t", c->lens[i]);
+                    fwrite(c->buf + c->starts[i], 1, c->lens[i], stdout);
+                    putchar('\n');
+                }
+                held.erase(it);
+                f.recycle(c);
+                ++next;
+            }
+        };
+        while (Chunk *c = f.next()) {
+            held[c->seq_no] = c;
+            flush();
+        }
+        flush();
+        if (!held.empty()) {
+            fprintf(stderr, "missing chunk %zu\n", next);
+            return 1;
+        }
+    } catch (const std::exception &e) {
+        fprintf(stderr, "feeder_dump: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -29,6 +29,7 @@ struct Params {
     bool use_pfx = false;
     bool debug = false;
     bool a = false;
+    bool fold_case = false;  // extension: the kernels treat a-z as A-Z (the reference upper-cases on the host, src/closures.rs:63,106)
     size_t c = 4;
     size_t s = 11;
     size_t g = 2000;
@@ -43,7 +44,7 @@ struct Params {
         p.c = (uint32_t)c;
         p.s = (uint32_t)s;
         p.g = (uint32_t)g;
-        p.reserved = 0;
+        p.flags = fold_case ? MQ_FLAG_FOLD_CASE : 0u;
         return p;
     }
 };

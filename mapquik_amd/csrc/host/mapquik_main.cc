@@ -1,6 +1,10 @@
 // mapquik (HIP backend) -- command-line driver with the reference's surface: src/main.rs:77-272 (flags, defaults, log
 // lines) and src/closures.rs:22-212 (index the reference, map the reads, write <prefix>.paf in input order).
-// The hot path runs on the GPU through mapquik_host.hpp / the C ABI.  Single-threaded FASTX reader (raw or gzip).
+// The hot path runs on the GPU through mapquik_host.hpp / the C ABI.  Reads come through fastx_feeder.hpp (parallel chunk
+// reader for raw files, one inflate thread + parser threads for .gz / .lz4), go to the GPU as raw FASTX bytes + spans
+// (mq_ctx_submit_spans, three stream slots per GPU so that copy-in, kernels and copy-out of consecutive chunks overlap),
+// and the PAF is formatted by a small thread pool and written in input order.  The reference FASTA still goes through the
+// simple line reader below (it is read once).
 #include <zlib.h>
 
 #include <algorithm>
@@ -19,6 +23,7 @@
 
 #include <sys/resource.h>
 
+#include "fastx_feeder.hpp"
 #include "mapquik_host.hpp"
 
 using namespace mapquik;
@@ -155,7 +160,7 @@ struct Opt {
     double density = -1;
     int device = 0;
     int gpus = 1;
-    unsigned long long batch_bases = 1ull << 30;
+    unsigned long long batch_bases = 1ull << 28;  // raw input bytes per chunk
 };
 
 static void usage() {
@@ -223,7 +228,7 @@ int main(int argc, char **argv) {
     P.use_hpc = !o.nohpc;
     P.use_simd = !o.nosimd;
     P.use_pfx = o.parallelfastx;
-    (void)threads;
+    P.fold_case = true;  // raw FASTX bytes go to the GPU: the kernels do the reference's to_ascii_uppercase
     if (P.use_hpc) puts(P.use_simd ? "Using HPC ntHash, with SIMD" : "Using HPC ntHash, scalar");
     else puts(P.use_simd ? "Using regular ntHash (not HPC), with SIMD" : "Using regular ntHash (not HPC), scalar");
 
@@ -269,95 +274,138 @@ int main(int argc, char **argv) {
 
         t0 = Clock::now();
         if (P.use_pfx && !ends_with(o.reads, ".gz") && !ends_with(o.reads, ".lz4")) puts("Warning: using experimental rust-parallelfastx (exciting!)");
-        struct Batch {
-            size_t seq_no = 0;
-            std::vector<std::string> ids;
-            std::string bases;
-            std::vector<uint64_t> offs{0};
-            std::vector<std::optional<std::string>> res;
-        };
+        using feeder::Chunk;
+        const int n_parse = (int)std::max<size_t>(1, threads);
+        const int n_slots = 3;  // stream slots per GPU: copy-in, kernels and copy-out of consecutive chunks overlap
+        const int n_format = std::max(1, std::min(4, n_parse / 2));
+        feeder::Feeder feed(o.reads, !reads_fasta, o.batch_bases, n_parse, n_parse + o.gpus * (n_slots + 1) + n_format + 2);
+        feed.start();
         std::mutex mu;
         std::condition_variable cv;
-        std::deque<std::unique_ptr<Batch>> todo;            // parsed, waiting for a GPU
-        std::map<size_t, std::unique_ptr<Batch>> done;      // mapped, waiting for their turn in the output
-        bool eof = false;
+        std::deque<Chunk *> to_format;               // mapped, waiting for a formatter
+        std::map<size_t, Chunk *> done;              // formatted, waiting for their turn in the output
+        int gpu_workers_left = o.gpus;
+        int formatting = 0;                          // chunks a formatter is working on right now
         std::string werr;
+        auto fail = [&](const std::string &m) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (werr.empty()) werr = m;
+        };
         std::vector<std::thread> workers;
         for (int g = 0; g < o.gpus; ++g)
             workers.emplace_back([&, g]() {
+                std::vector<mq_ctx *> ctx((size_t)n_slots, nullptr);
+                std::vector<Chunk *> inflight((size_t)n_slots, nullptr);
+                auto finish_slot = [&](int sl) {
+                    if (!inflight[sl]) return;
+                    if (mq_ctx_wait(ctx[sl]) != MQ_OK) fail(std::string("mq_ctx_wait: ") + last_error());
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        to_format.push_back(inflight[sl]);
+                    }
+                    inflight[sl] = nullptr;
+                    cv.notify_all();
+                };
+                try {
+                    for (int sl = 0; sl < n_slots; ++sl) {
+                        ctx[sl] = mq_ctx_new(ro[g]->handle());
+                        if (!ctx[sl]) throw Error(std::string("mq_ctx_new: ") + last_error());
+                    }
+                    for (size_t k = 0;; ++k) {
+                        Chunk *c = feed.next();
+                        if (!c) break;
+                        const int sl = (int)(k % (size_t)n_slots);
+                        finish_slot(sl);
+                        c->hits.resize(c->starts.size());
+                        if (c->starts.empty()) {  // nothing to map in this chunk (the middle of a very long record)
+                            std::lock_guard<std::mutex> lk(mu);
+                            to_format.push_back(c);
+                            cv.notify_all();
+                            continue;
+                        }
+                        if (mq_ctx_submit_spans(ctx[sl], c->buf, c->bytes, c->starts.data(), c->lens.data(), (uint32_t)c->starts.size(),
+                                                c->hits.data()) != MQ_OK)
+                            throw Error(std::string("mq_ctx_submit_spans: ") + last_error());
+                        inflight[sl] = c;
+                    }
+                    for (int sl = 0; sl < n_slots; ++sl) finish_slot(sl);
+                } catch (const std::exception &e) { fail(e.what()); }
+                for (auto c : ctx) mq_ctx_free(c);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    gpu_workers_left--;
+                }
+                cv.notify_all();
+            });
+        std::vector<std::thread> formatters;
+        for (int f = 0; f < n_format; ++f)
+            formatters.emplace_back([&]() {
+                std::string id;
+                std::vector<char> buf(4096);
                 for (;;) {
-                    std::unique_ptr<Batch> bt;
+                    Chunk *c = nullptr;
                     {
                         std::unique_lock<std::mutex> lk(mu);
-                        cv.wait(lk, [&] { return !todo.empty() || eof; });
-                        if (todo.empty()) return;
-                        bt = std::move(todo.front());
-                        todo.pop_front();
+                        cv.wait(lk, [&] { return !to_format.empty() || gpu_workers_left == 0; });
+                        if (to_format.empty()) return;
+                        c = to_format.front();
+                        to_format.pop_front();
+                        formatting++;
                     }
-                    cv.notify_all();
-                    try {
-                        bt->res = mers::find_matches_batch(bt->ids, (const uint8_t *)bt->bases.data(), bt->offs, *ro[g], P);
-                    } catch (const Error &e) {
-                        std::lock_guard<std::mutex> lk(mu);
-                        werr = e.what();
+                    for (size_t i = 0; i < c->starts.size(); ++i) {
+                        const mq_hit &h = c->hits[i];
+                        id.assign((const char *)c->buf + c->ids[i].off, c->ids[i].len);
+                        if (h.status == MQ_HIT_MAPPED) {
+                            int w = mq_format_paf(ro[0]->handle(), id.c_str(), c->lens[i], &h, buf.data(), buf.size());
+                            if (w >= (int)buf.size()) {
+                                buf.resize((size_t)w + 1);
+                                w = mq_format_paf(ro[0]->handle(), id.c_str(), c->lens[i], &h, buf.data(), buf.size());
+                            }
+                            if (w < 0) { fail(std::string("find_coords: ") + last_error()); break; }
+                            c->paf.append(buf.data(), (size_t)w);
+                            c->paf.push_back('\n');
+                        } else if (h.status == MQ_HIT_UNMAPPED) {
+                            if (unm) { c->unmapped += id; c->unmapped.push_back('\n'); }
+                        } else {
+                            fail("find_matches: read " + id + " could not be processed");
+                            break;
+                        }
                     }
                     {
                         std::lock_guard<std::mutex> lk(mu);
-                        const size_t k = bt->seq_no;
-                        done[k] = std::move(bt);
+                        done[c->seq_no] = c;
+                        formatting--;
                     }
                     cv.notify_all();
                 }
             });
-        size_t next_out = 0, n_batches = 0;
-        auto drain = [&](bool all) {  // main thread writes in input order (main_thread_mer, src/closures.rs:117-123)
-            std::unique_lock<std::mutex> lk(mu);
-            for (;;) {
-                auto it = done.find(next_out);
-                if (it == done.end()) {
-                    if (!all || next_out >= n_batches) return;
-                    cv.wait(lk, [&] { return done.count(next_out) != 0; });
-                    continue;
-                }
-                std::unique_ptr<Batch> bt = std::move(it->second);
-                done.erase(it);
-                lk.unlock();
-                for (size_t i = 0; i < bt->res.size(); ++i) {
-                    if (bt->res[i]) fprintf(paf, "%s\n", bt->res[i]->c_str());
-                    else if (unm) fprintf(unm, "%s\n", bt->ids[i].c_str());
-                }
-                ++next_out;
-                lk.lock();
-            }
-        };
-        std::unique_ptr<Batch> cur(new Batch());
-        auto submit = [&]() {
-            if (cur->ids.empty()) return;
-            cur->seq_no = n_batches++;
+        // main thread: chunks in input order (main_thread_mer, src/closures.rs:117-123)
+        for (size_t next_out = 0;;) {
+            Chunk *c = nullptr;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return todo.size() < (size_t)(2 * o.gpus); });  // bounded queue (the reference's -q idea)
-                todo.push_back(std::move(cur));
+                cv.wait(lk, [&] {
+                    return done.count(next_out) != 0 || !werr.empty() || (gpu_workers_left == 0 && to_format.empty() && formatting == 0);
+                });
+                auto it = done.find(next_out);
+                if (it == done.end()) break;  // everything written, or a worker failed
+                c = it->second;
+                done.erase(it);
             }
-            cv.notify_all();
-            cur.reset(new Batch());
-            drain(false);
-        };
-        read_fastx(o.reads, reads_fasta, [&](const std::string &id, const std::string &seq) {
-            cur->ids.push_back(id);
-            cur->bases += seq;
-            cur->offs.push_back(cur->bases.size());
-            if (cur->bases.size() >= o.batch_bases) submit();
-        });
-        submit();
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            eof = true;
+            if (!c->paf.empty()) fwrite(c->paf.data(), 1, c->paf.size(), paf);
+            if (unm && !c->unmapped.empty()) fwrite(c->unmapped.data(), 1, c->unmapped.size(), unm);
+            feed.recycle(c);
+            ++next_out;
         }
-        cv.notify_all();
-        drain(true);
         for (auto &t : workers) t.join();
-        if (!werr.empty()) throw Error(werr);
+        cv.notify_all();
+        for (auto &t : formatters) if (t.joinable()) t.join();
+        if (!werr.empty()) {
+            fclose(paf);
+            if (unm) fclose(unm);
+            remove((prefix + ".paf").c_str());  // never leave a partial PAF behind a failure
+            throw Error(werr);
+        }
         fclose(paf);
         if (unm) fclose(unm);
         printf("Mapped query sequences in %s.\n", rust_duration(secs(t0)).c_str());  // src/closures.rs:211

@@ -35,7 +35,8 @@ using namespace mq;
 // MQ_HIT_OVERFLOW (the host-buffer entry points then redo it with f16 = 65536).
 struct SplitArgs {
     const uint8_t *bases;
-    const uint64_t *offsets;
+    const uint64_t *offsets;  // n + 1: read r starts at offsets[r]; offsets[n] = end of the buffer
+    const uint32_t *lens;     // null: read r ends at offsets[r + 1]; else its length (raw FASTX buffers: headers and quality lines in between)
     uint32_t n;
     DevParams P;
     unsigned long long *mz_hash;
@@ -211,8 +212,8 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         if (lane == 0) r = atomicAdd(&A.counters[0], 1u);
         r = rdfirst(r);
         if (r >= A.n) break;
-        const uint64_t o0 = A.offsets[r], o1 = A.offsets[r + 1];
-        const uint64_t len = o1 - o0;
+        const uint64_t o0 = A.offsets[r];
+        const uint64_t len = A.lens ? (uint64_t)A.lens[r] : A.offsets[r + 1] - o0;
         uint32_t cnt = 0;
         uint64_t base = 0;
         // extract(): len < l + k - 1 => None (src/mers.rs:44)
@@ -267,8 +268,8 @@ __global__ __launch_bounds__(64 * SEED_WAVES, MQ_SEED_MIN_WAVES) void seed_reads
         if (lane == 0) r = atomicAdd(&A.counters[0], 1u);
         r = rdfirst(r);
         if (r >= A.n) break;
-        const uint64_t o0 = A.offsets[r], o1 = A.offsets[r + 1];
-        const uint64_t len = o1 - o0;
+        const uint64_t o0 = A.offsets[r];
+        const uint64_t len = A.lens ? (uint64_t)A.lens[r] : A.offsets[r + 1] - o0;
         uint32_t cnt = 0;
         uint64_t base = 0;
         if (len >= (uint64_t)P.l + P.k - 1u) {
@@ -305,8 +306,8 @@ __global__ __launch_bounds__(64) void seed_general_kernel(const SplitArgs A) {
         i = rdfirst(i);
         if (i >= nq) break;
         const uint32_t r = A.queue[i];
-        const uint64_t o0 = A.offsets[r], o1 = A.offsets[r + 1];
-        const uint64_t len = o1 - o0;
+        const uint64_t o0 = A.offsets[r];
+        const uint64_t len = A.lens ? (uint64_t)A.lens[r] : A.offsets[r + 1] - o0;
         uint64_t base;
         uint32_t cap;
         list_region(A, o0 - o_base, len, r, base, cap);
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(64 * ML_WAVES, MQ_ML_MIN_WAVES) void map_lists_kern
         if (lane == 0) r = atomicAdd(&A.counters[1], 1u);
         r = rdfirst(r);
         if (r >= A.n) break;
-        const uint64_t len = A.offsets[r + 1] - A.offsets[r];
+        const uint64_t len = A.lens ? (uint64_t)A.lens[r] : A.offsets[r + 1] - A.offsets[r];
         map_read<CH, TIMING>(A, SS[wv], scratch, r, len, A.mz_count[r], A.mz_base[r], t_steps, t_lookups);
         wave_sync();
     }
@@ -556,6 +557,8 @@ struct mq_ctx {
     uint64_t st_off_cap = 0;
     mq_hit *st_out = nullptr;
     uint64_t st_out_cap = 0;
+    uint32_t *st_lens = nullptr;
+    uint64_t st_lens_cap = 0;
     uint64_t *h_off = nullptr;      // page-locked: relative offsets on their way to the device
     uint64_t h_off_cap = 0;
     mq_hit *h_out = nullptr;        // page-locked: hits on their way back
@@ -564,6 +567,7 @@ struct mq_ctx {
     bool pending = false;
     const uint8_t *p_bases = nullptr;
     const uint64_t *p_offsets = nullptr;
+    const uint32_t *p_lens = nullptr;
     uint32_t p_n = 0;
     mq_hit *p_out = nullptr;
 };
@@ -620,7 +624,7 @@ void mq_params_default(mq_params *p) {
     p->c = 4;
     p->s = 11;
     p->g = 2000;
-    p->reserved = 0;
+    p->flags = 0;
 }
 
 }  // extern "C"
@@ -769,6 +773,7 @@ static void ctx_release(mq_ctx *c) {
     hipFree(c->st_bases);
     hipFree(c->st_off);
     hipFree(c->st_out);
+    hipFree(c->st_lens);
     if (c->h_off) hipHostFree(c->h_off);
     if (c->h_out) hipHostFree(c->h_out);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -823,7 +828,7 @@ mq_index *mq_index_new(const mq_params *params, int device) {
     idx->dp.c = params->c;
     idx->dp.s = params->s;
     idx->dp.g = params->g;
-    idx->dp.pad = 0;
+    idx->dp.fold = (params->flags & MQ_FLAG_FOLD_CASE) ? 1u : 0u;
     const char *cc = getenv("MQ_CHAIN_CHUNK");
     if (cc && atoi(cc) == 4) idx->chain_chunk = 4;
     const char *fg = getenv("MQ_FORCE_GENERAL");
@@ -1154,6 +1159,7 @@ struct LaunchOpt {
     uint32_t cap_override = 0;
     uint32_t grid_override = 0;
     uint32_t f16 = 0;                      // 0 => list_f16(idx)
+    const uint32_t *d_lens = nullptr;      // spans form: per-read lengths
 };
 
 // One launch sequence on stream `st` using the context's scratch.  ctx_ensure(c, n, total_bases, f16) must have succeeded.
@@ -1166,6 +1172,7 @@ static int launch_map(mq_ctx *c, const uint8_t *d_bases, const uint64_t *d_offse
     SplitArgs A;
     A.bases = d_bases;
     A.offsets = d_offsets;
+    A.lens = o.d_lens;
     A.n = n;
     A.P = idx->dp;
     A.mz_hash = c->mz_hash;
@@ -1221,7 +1228,7 @@ static int launch_map(mq_ctx *c, const uint8_t *d_bases, const uint64_t *d_offse
 
 // Reads that came back MQ_HIT_OVERFLOW (more Match runs than the per-wave scratch holds, or a minimizer list denser than its
 // region): map those again on the GPU with worst-case scratch and list regions on a small grid.  Never a CPU path.
-static int redo_overflow(mq_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out) {
+static int redo_overflow(mq_ctx *c, const uint8_t *bases, const uint64_t *offsets, const uint32_t *lens, uint32_t n, mq_hit *out) {
     mq_index *idx = c->idx;
     std::vector<uint32_t> redo;
     for (uint32_t i = 0; i < n; ++i)
@@ -1230,7 +1237,7 @@ static int redo_overflow(mq_ctx *c, const uint8_t *bases, const uint64_t *offset
     uint64_t sub_max = 0;
     std::vector<uint64_t> so(redo.size() + 1, 0);
     for (size_t j = 0; j < redo.size(); ++j) {
-        const uint64_t L = offsets[redo[j] + 1] - offsets[redo[j]];
+        const uint64_t L = lens ? (uint64_t)lens[redo[j]] : offsets[redo[j] + 1] - offsets[redo[j]];
         so[j + 1] = so[j] + L;
         sub_max = std::max(sub_max, L);
     }
@@ -1275,8 +1282,11 @@ static int redo_overflow(mq_ctx *c, const uint8_t *bases, const uint64_t *offset
     return MQ_OK;
 }
 
-// host buffers -> device staging -> launch sequence -> page-locked hits, all asynchronous on the context's stream
-static int ctx_submit(mq_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out) {
+// host buffers -> device staging -> launch sequence -> page-locked hits, all asynchronous on the context's stream.
+// lens == nullptr: offsets has n + 1 entries and read i is bases[offsets[i], offsets[i+1]).  lens != nullptr (spans form): the
+// whole buffer bases[0, buf_bytes) goes to the device and read i is bases[offsets[i], offsets[i] + lens[i]) (n offsets).
+static int ctx_submit(mq_ctx *c, const uint8_t *bases, uint64_t buf_bytes, const uint64_t *offsets, const uint32_t *lens, uint32_t n,
+                      mq_hit *out) {
     mq_index *idx = c->idx;
     if (c->pending) return set_err(MQ_ESTATE, "context has a submitted batch: call mq_ctx_wait first");
     if (!idx->finalized) return set_err(MQ_ESTATE, "index not finalized");
@@ -1285,25 +1295,45 @@ static int ctx_submit(mq_ctx *c, const uint8_t *bases, const uint64_t *offsets, 
     if (rc) return rc;
     if ((rc = grow_pinned(c->h_off, c->h_off_cap, (uint64_t)n + 1))) return rc;
     if ((rc = grow_pinned(c->h_out, c->h_out_cap, (uint64_t)n))) return rc;
-    const uint64_t total = offsets[n] - offsets[0];
-    for (uint32_t i = 0; i < n; ++i) {
-        if (offsets[i + 1] < offsets[i]) return set_err(MQ_EINVAL, "offsets must be non-decreasing");
-        if (offsets[i + 1] - offsets[i] >= (1ull << 32)) return set_err(MQ_EINVAL, "sequence length must be < 2^32");
-        c->h_off[i] = offsets[i] - offsets[0];
+    uint64_t total, first;
+    if (!lens) {
+        first = offsets[0];
+        total = offsets[n] - offsets[0];
+        for (uint32_t i = 0; i < n; ++i) {
+            if (offsets[i + 1] < offsets[i]) return set_err(MQ_EINVAL, "offsets must be non-decreasing");
+            if (offsets[i + 1] - offsets[i] >= (1ull << 32)) return set_err(MQ_EINVAL, "sequence length must be < 2^32");
+            c->h_off[i] = offsets[i] - first;
+        }
+    } else {
+        first = 0;
+        total = buf_bytes;
+        uint64_t prev_end = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (offsets[i] < prev_end || offsets[i] + lens[i] > buf_bytes) return set_err(MQ_EINVAL, "spans must be in order, disjoint and inside the buffer");
+            prev_end = offsets[i] + lens[i];
+            c->h_off[i] = offsets[i];
+        }
     }
     c->h_off[n] = total;
     if ((rc = ctx_ensure(c, n, total, list_f16(idx)))) return rc;
     if ((rc = grow(c->st_bases, c->st_bases_cap, total + 64))) return rc;
     if ((rc = grow(c->st_off, c->st_off_cap, (uint64_t)n + 1))) return rc;
     if ((rc = grow(c->st_out, c->st_out_cap, (uint64_t)n))) return rc;
-    if (total) HIPCHK(hipMemcpyAsync(c->st_bases, bases + offsets[0], total, hipMemcpyHostToDevice, c->stream));
+    if (lens && (rc = grow(c->st_lens, c->st_lens_cap, (uint64_t)n))) return rc;
+    if (total) HIPCHK(hipMemcpyAsync(c->st_bases, bases + first, total, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->st_off, c->h_off, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    rc = launch_map(c, c->st_bases, c->st_off, n, c->st_out, c->stream);
+    LaunchOpt o;
+    if (lens) {
+        HIPCHK(hipMemcpyAsync(c->st_lens, lens, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        o.d_lens = c->st_lens;
+    }
+    rc = launch_map(c, c->st_bases, c->st_off, n, c->st_out, c->stream, o);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(c->h_out, c->st_out, (size_t)n * sizeof(mq_hit), hipMemcpyDeviceToHost, c->stream));
     c->pending = true;
     c->p_bases = bases;
     c->p_offsets = offsets;
+    c->p_lens = lens;
     c->p_n = n;
     c->p_out = out;
     return MQ_OK;
@@ -1316,7 +1346,7 @@ static int ctx_wait(mq_ctx *c) {
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     memcpy(c->p_out, c->h_out, (size_t)c->p_n * sizeof(mq_hit));
-    return redo_overflow(c, c->p_bases, c->p_offsets, c->p_n, c->p_out);
+    return redo_overflow(c, c->p_bases, c->p_offsets, c->p_lens, c->p_n, c->p_out);
 }
 
 static int ctx_map_device(mq_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases, mq_hit *d_out,
@@ -1349,7 +1379,13 @@ void mq_ctx_free(mq_ctx *ctx) {
 
 int mq_ctx_submit(mq_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out) {
     if (!ctx || (n && (!offsets || !out))) return set_err(MQ_EINVAL, "bad arguments");
-    return ctx_submit(ctx, bases, offsets, n, out);
+    return ctx_submit(ctx, bases, 0, offsets, nullptr, n, out);
+}
+
+int mq_ctx_submit_spans(mq_ctx *ctx, const uint8_t *buf, uint64_t buf_bytes, const uint64_t *starts, const uint32_t *lens, uint32_t n,
+                        mq_hit *out) {
+    if (!ctx || (n && (!buf || !starts || !lens || !out))) return set_err(MQ_EINVAL, "bad arguments");
+    return ctx_submit(ctx, buf, buf_bytes, starts, lens, n, out);
 }
 
 int mq_ctx_wait(mq_ctx *ctx) {
@@ -1359,7 +1395,7 @@ int mq_ctx_wait(mq_ctx *ctx) {
 
 int mq_ctx_map_batch(mq_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out) {
     if (!ctx || (n && (!offsets || !out))) return set_err(MQ_EINVAL, "bad arguments");
-    int rc = ctx_submit(ctx, bases, offsets, n, out);
+    int rc = ctx_submit(ctx, bases, 0, offsets, nullptr, n, out);
     if (rc) return rc;
     return ctx_wait(ctx);
 }
@@ -1380,7 +1416,7 @@ int mq_map_batch_device(mq_index *idx, const uint8_t *d_bases, const uint64_t *d
 int mq_map_batch(mq_index *idx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out) {
     if (!idx || (n && (!offsets || !out))) return set_err(MQ_EINVAL, "bad arguments");
     std::lock_guard<std::mutex> lk(idx->mu);
-    int rc = ctx_submit(idx->def_ctx, bases, offsets, n, out);
+    int rc = ctx_submit(idx->def_ctx, bases, 0, offsets, nullptr, n, out);
     if (rc) return rc;
     return ctx_wait(idx->def_ctx);
 }

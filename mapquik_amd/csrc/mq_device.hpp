@@ -35,7 +35,7 @@ constexpr int MAX_L = 64;
 struct DevParams {
     uint64_t bound;  // density bound: keep l-mer iff min(fh,rh) <= bound
     uint32_t k, l, use_hpc, c, s, g;
-    uint32_t pad;
+    uint32_t fold;  // 1: a-z count as A-Z (to_ascii_uppercase of src/closures.rs:63,106 done here instead of by the caller)
 };
 
 // 32-byte table slot: one aligned 32-B sector per probe.  key==0 <=> empty (a real key 0 lives in the extra slot).
@@ -223,6 +223,7 @@ __device__ __forceinline__ void seed_segment(const uint8_t *__restrict__ seq, ui
     uint64_t prevF = 0, prevR = 0;  // per-lane inclusive prefixes of the previous block
     uint64_t carryF = 0, carryR = 0;
     uint32_t prev_byte = a > 0 ? (uint32_t)seq[a - 1] : 0x100u;
+    if (P.fold && prev_byte - 'a' < 26u) prev_byte -= 32u;
     // lane constants
     const uint32_t from = (lane - l) & 63u;
     const bool src_cur = lane + l <= 63u;
@@ -269,7 +270,8 @@ __device__ __forceinline__ void seed_segment(const uint8_t *__restrict__ seq, ui
     for (uint64_t pos = a;; pos += 64) {
         const uint64_t i = pos + lane;
         const bool inr = i < len;
-        const uint32_t bt = inr ? (uint32_t)seq[i] : 0u;
+        uint32_t bt = inr ? (uint32_t)seq[i] : 0u;
+        if (P.fold && bt - 'a' < 26u) bt -= 32u;
         uint32_t pb = (uint32_t)__shfl_up((int)bt, 1, 64);
         if (lane == 0) pb = prev_byte;
         const bool head = inr && (!P.use_hpc || bt != pb);

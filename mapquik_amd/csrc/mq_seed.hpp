@@ -148,7 +148,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
 // prev_code0: the code before the first base of the sequence when raw0 == 0 (4 = none: the first base is a head).
 // Returns false on a byte other than A C G T.
 __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, uint32_t len, uint32_t raw0, uint32_t carry_n,
-                                             uint32_t &carry_prev, bool use_hpc, const SeedTables &T, SeedLds &S, uint32_t &n_codes,
+                                             uint32_t &carry_prev, bool use_hpc, bool fold, const SeedTables &T, SeedLds &S, uint32_t &n_codes,
                                              uint32_t &n_blocks, uint32_t &raw_end) {
     const uint32_t lane = lane_id();
     uint32_t n_sr = (len - raw0 + SD_SR_RAW - 1u) / SD_SR_RAW;
@@ -259,7 +259,8 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
     n_codes = b2 >> 1;
     if (lane == 0) S.cnt[n_blocks] = (uint16_t)n_codes;
     wave_sync();
-    return __ballot(bad != 0) == 0;
+    // bad holds byte ^ its reconstruction from the 2-bit code: zero for A C G T; exactly 0x20 for a c g t (accepted when folding)
+    return __ballot((bad & (fold ? 0xDFDFDFDFu : 0xFFFFFFFFu)) != 0) == 0;
 }
 
 // ------------------------------------------------------------------ stage B
@@ -466,7 +467,7 @@ __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict
     while (raw0 < len) {
         uint32_t n_codes = 0, n_blocks = 0, raw_end = 0;
         const unsigned long long t0 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
-        const bool ok = seed_stage_a(seq, len, raw0, carry_n, carry_prev, P.use_hpc != 0, T, S, n_codes, n_blocks, raw_end);
+        const bool ok = seed_stage_a(seq, len, raw0, carry_n, carry_prev, P.use_hpc != 0, P.fold != 0, T, S, n_codes, n_blocks, raw_end);
         const unsigned long long t1 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
         if (TIMING) tacc[0] += t1 - t0;
         if (!ok) return SD_NOT_FAST;

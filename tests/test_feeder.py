@@ -1,0 +1,93 @@
+"""The native driver's FASTX feeder (mapquik_amd/csrc/host/fastx_feeder.hpp) against a plain Python parser: FASTA (single- and
+multi-line), FASTQ, CRLF, missing final newline, gzip and lz4 input, chunk sizes from 64 bytes up, 1 and 4 threads.  Host only
+(chunk buffers from malloc): what get_reader + seq_io give the reference (src/main.rs:60-75, src/closures.rs:177-187)."""
+import ctypes as C
+import gzip
+import random
+import subprocess
+
+import pytest
+
+from mapquik_amd import build as B
+
+
+def _make(n, fastq, multiline, crlf, rng):
+    recs, out = [], []
+    nl = "\r\n" if crlf else "\n"
+    for i in range(n):
+        L = rng.choice([0, 1, 5, 50, 200, 1000, 3000])
+        seq = "".join(rng.choice("ACGTacgtN") for _ in range(L))
+        rid = "r%d" % i
+        recs.append((rid, seq))
+        if fastq:
+            q = "".join(rng.choice("@+!IJ>") for _ in range(L))  # quality lines that begin with '@' or '+'
+            out.append("@%s desc %d%s%s%s+%s%s%s" % (rid, i, nl, seq, nl, nl, q, nl))
+        elif multiline:
+            w = rng.choice([60, 80, 7])
+            lines = [seq[j:j + w] for j in range(0, len(seq), w)] or [""]
+            out.append(">%s desc%s%s%s" % (rid, nl, nl.join(lines), nl))
+        else:
+            out.append(">%s%s%s%s" % (rid, nl, seq, nl))
+    return recs, "".join(out)
+
+
+def _dump(tool, path, fastq, chunk, threads):
+    r = subprocess.run([tool, str(path), "fastq" if fastq else "fasta", str(chunk), str(threads)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    got = [ln.split("\t") for ln in r.stdout.split("\n") if ln != ""]
+    return [g if len(g) == 3 else g + [""] for g in got]
+
+
+def _lz4_frame(data):
+    try:
+        L = C.CDLL("liblz4.so.1")
+    except OSError:
+        pytest.skip("liblz4.so.1 not present")
+    L.LZ4F_compressFrameBound.restype = C.c_size_t
+    L.LZ4F_compressFrameBound.argtypes = [C.c_size_t, C.c_void_p]
+    L.LZ4F_compressFrame.restype = C.c_size_t
+    L.LZ4F_compressFrame.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    cap = L.LZ4F_compressFrameBound(len(data), None)
+    dst = C.create_string_buffer(cap)
+    n = L.LZ4F_compressFrame(dst, cap, data, len(data), None)
+    assert n > 0 and n <= cap
+    return dst.raw[:n]
+
+
+@pytest.fixture(scope="module")
+def tool():
+    return B.build_feeder_dump()
+
+
+@pytest.mark.parametrize("fastq,multiline", [(False, False), (False, True), (True, False)])
+@pytest.mark.parametrize("crlf", [False, True])
+def test_feeder_matches_plain_parser(tool, tmp_path, fastq, multiline, crlf):
+    rng = random.Random(11 + 2 * fastq + multiline + 4 * crlf)
+    recs, text = _make(200, fastq, multiline, crlf, rng)
+    want = [[a, str(len(b)), b] for a, b in recs]
+    for trailing in (True, False):
+        t = text if trailing else text.rstrip("\r\n")
+        raw, gz = tmp_path / "t.fx", tmp_path / "t.fx.gz"
+        raw.write_text(t, newline="")
+        with gzip.open(gz, "wt", newline="") as f:
+            f.write(t)
+        for path in (raw, gz):
+            for chunk, th in ((64, 4), (1000, 1), (5000, 4), (1 << 28, 2)):
+                assert _dump(tool, path, fastq, chunk, th) == want, (str(path), chunk, th, trailing)
+
+
+def test_feeder_reads_lz4_frames(tool, tmp_path):
+    recs, text = _make(150, True, False, False, random.Random(5))
+    p = tmp_path / "reads.fq.lz4"
+    p.write_bytes(_lz4_frame(text.encode()))
+    assert _dump(tool, p, True, 4096, 3) == [[a, str(len(b)), b] for a, b in recs]
+
+
+def test_feeder_long_record_spanning_many_chunks(tool, tmp_path):
+    rng = random.Random(9)
+    seqs = ["".join(rng.choice("ACGT") for _ in range(n)) for n in (10, 3_000_000, 20)]
+    p = tmp_path / "long.fa"
+    p.write_text("".join(">c%d\n%s\n" % (i, "\n".join(s[j:j + 80] for j in range(0, len(s), 80))) for i, s in enumerate(seqs)))
+    got = _dump(tool, p, False, 100_000, 4)
+    assert [(g[0], int(g[1])) for g in got] == [("c%d" % i, len(s)) for i, s in enumerate(seqs)]
+    assert got[1][2] == seqs[1]

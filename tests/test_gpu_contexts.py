@@ -1,0 +1,158 @@
+"""GPU: stream-slot contexts (mq_ctx), the spans form with in-kernel case folding, and the minimizer-list pool -- all against
+the CPU oracle, bit-exact.  Reference behaviour: workers map concurrently over one read-only index (src/closures.rs:183,187,
+src/index.rs:108-116); sequences are upper-cased before the seam (src/closures.rs:63,106)."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mq():
+    import mapquik_amd
+    if mapquik_amd.device_count() <= 0:
+        pytest.fail("no HIP device visible: GPU tests must run on the GPU box")
+    return mapquik_amd
+
+
+@pytest.fixture(scope="module")
+def small(simlib):
+    return simlib.make_genome([900000, 600000], seed=41, repeat_frac=0.1, tandem_frac=0.02)
+
+
+def _index_both(mq, oracle, small, ps, **kw):
+    g, off, names = small
+    P, po = mq.Params(**ps, **kw), oracle.params(**ps)
+    ix, ox = mq.Index(P), oracle.Index()
+    for r in range(off.size - 1):
+        s = g[int(off[r]):int(off[r + 1])]
+        assert ix.add_ref(r, names[r], s) == ox.add_ref(r, names[r], s, po)
+    assert ix.finalize() == ox.count()
+    return ix, ox, po
+
+
+def _cmp(hits, want):
+    assert np.array_equal(hits["status"] == 1, want["mapped"] != 0)
+    m = want["mapped"] != 0
+    for a in ("ref_id", "rc", "mapq", "q_start", "q_end", "r_start", "r_end", "score"):
+        assert np.array_equal(hits[a][m].astype(np.uint64), want[a][m].astype(np.uint64)), a
+
+
+def test_contexts_map_concurrently_on_one_index(mq, oracle, simlib, small):
+    """Three contexts of one finalized index driven from three threads at once, several rounds each; plus submit/wait double
+    buffering on one thread.  Every batch must equal the oracle's answer."""
+    g, off, names = small
+    ix, ox, po = _index_both(mq, oracle, small, dict())
+    batches = [simlib.make_reads(g, off, 300, seed=100 + i) for i in range(3)]
+    wants = [ox.map_batch(b["bases"], b["offsets"], po, threads=4) for b in batches]
+    errs = []
+
+    def worker(i):
+        try:
+            c = ix.context()
+            for _ in range(4):
+                _cmp(c.map_batch(batches[i]["bases"], batches[i]["offsets"]), wants[i])
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    # index-level entry point from several threads at once: serialised by the index lock, still right
+    th = [threading.Thread(target=lambda i=i: _cmp(ix.map_batch(batches[i]["bases"], batches[i]["offsets"]), wants[i])) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    # double buffering: two contexts, submit both, then wait both
+    c0, c1 = ix.context(), ix.context()
+    c0.submit(batches[0]["bases"], batches[0]["offsets"])
+    c1.submit(batches[1]["bases"], batches[1]["offsets"])
+    _cmp(c1.wait(), wants[1])
+    _cmp(c0.wait(), wants[0])
+    with pytest.raises(mq.MapquikError):
+        c0.submit(batches[0]["bases"], batches[0]["offsets"])
+        c0.submit(batches[0]["bases"], batches[0]["offsets"])  # a second submit before wait is refused
+    c0.wait()
+
+
+@pytest.mark.parametrize("ps", [dict(), dict(k=3, l=12, density=0.05, use_hpc=False)])
+def test_spans_of_a_raw_fastq_buffer_with_case_folding(mq, oracle, simlib, small, ps):
+    """Reads handed over as spans of raw FASTQ text (headers, '+' and quality lines in between), half of the bases in lower
+    case, some reads with N / n: MQ_FLAG_FOLD_CASE makes the kernels do the reference's to_ascii_uppercase."""
+    g, off, names = small
+    ix, ox, po = _index_both(mq, oracle, small, ps, fold_case=True)
+    reads = simlib.make_reads(g, off, 200, seed=77, len_mean=9000, len_sd=5000, len_min=20)
+    bases, offs = reads["bases"].copy(), reads["offsets"]
+    rng = np.random.default_rng(3)
+    for i in range(0, 200, 9):  # a few reads get N runs: those take the general seeder
+        a = int(offs[i]) + 5
+        bases[a:a + 7] = ord("N")
+    want = ox.map_batch(bases, offs, po, threads=4)
+    mixed = bases.copy()
+    low = rng.random(mixed.size) < 0.5
+    mixed[low] |= 0x20  # a-z for half of the bases (N -> n too)
+    parts, starts, lens, pos = [], [], [], 0
+    for i in range(200):
+        s = mixed[int(offs[i]):int(offs[i + 1])].tobytes()
+        hdr = b"@read%d some description\n" % i
+        rec = hdr + s + b"\n+\n" + b"I" * len(s) + b"\n"
+        starts.append(pos + len(hdr))
+        lens.append(len(s))
+        parts.append(rec)
+        pos += len(rec)
+    buf = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    c = ix.context()
+    c.submit_spans(buf, starts, lens)
+    hits = c.wait()
+    _cmp(hits, want)
+    # the same through the plain offsets form: lower case folds there too
+    _cmp(ix.map_batch(mixed, offs), want)
+    # without the flag, lower-case reads hash as non-ACGT (the seam's contract: already upper-cased): answers differ
+    ix2, _, _ = _index_both(mq, oracle, small, ps)
+    h2 = ix2.map_batch(mixed, offs)
+    assert (h2["status"] == 1).sum() < (want["mapped"] != 0).sum() // 4
+
+
+def test_dense_lists_move_to_the_pool_and_pool_exhaustion_is_loud(mq, oracle, simlib, small, monkeypatch):
+    """MQ_LIST_F16=1 leaves every read a 64-entry region: the lists of all but the shortest reads outgrow it and are written
+    again into pool regions (same answers).  With a density so high that the pool runs out too, the device-resident entry
+    point reports MQ_HIT_OVERFLOW for the reads that did not fit and the host-buffer form redoes exactly those."""
+    import ctypes as C
+    g, off, names = small
+    monkeypatch.setenv("MQ_LIST_F16", "1")
+    ix, ox, po = _index_both(mq, oracle, small, dict())
+    reads = simlib.make_reads(g, off, 400, seed=5)
+    want = ox.map_batch(reads["bases"], reads["offsets"], po, threads=4)
+    _cmp(ix.map_batch(reads["bases"], reads["offsets"]), want)
+    # pool exhaustion: density 0.5 -> ~0.5 entries per base against a pool of 2^20 entries
+    ps = dict(k=3, l=14, density=0.5)
+    ix, ox, po = _index_both(mq, oracle, small, ps)
+    reads = simlib.make_reads(g, off, 400, seed=6, len_mean=12000)
+    bases, offs = reads["bases"], reads["offsets"]
+    assert bases.size * 0.3 > (1 << 20)
+    want = ox.map_batch(bases, offs, po, threads=4)
+    _cmp(ix.map_batch(bases, offs), want)  # host form: complete
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    db, do, dout = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    n = offs.size - 1
+    assert hip.hipMalloc(C.byref(db), bases.size) == 0 and hip.hipMalloc(C.byref(do), offs.size * 8) == 0 and hip.hipMalloc(C.byref(dout), n * 40) == 0
+    hip.hipMemcpy(db, bases.ctypes.data, bases.size, 1)
+    hip.hipMemcpy(do, offs.ctypes.data, offs.size * 8, 1)
+    ix.map_batch_device(db.value, do.value, n, int(offs[-1] - offs[0]), dout.value, 0)
+    raw = np.zeros(n, dtype=mq.hit_dtype)
+    hip.hipMemcpy(raw.ctypes.data, dout, n * 40, 2)
+    over = raw["status"] == 2
+    assert over.any() and not over.all()
+    ok = ~over
+    assert np.array_equal(raw["status"][ok] == 1, want["mapped"][ok] != 0)
+    for p in (db, do, dout):
+        hip.hipFree(p)
