@@ -156,6 +156,9 @@ int mq_ctx_wait(mq_ctx *ctx);
  * MQ_FLAG_FOLD_CASE the host never has to touch a base.  starts/lens/buf/out must stay valid until mq_ctx_wait. */
 int mq_ctx_submit_spans(mq_ctx *ctx, const uint8_t *buf, uint64_t buf_bytes, const uint64_t *starts, const uint32_t *lens, uint32_t n,
                         mq_hit *out);
+/* Pre-size the context's device staging, minimizer lists and scratch for batches of up to n_reads reads / total_bytes buffer
+ * bytes, so that the first submit does not pay for the allocations. */
+int mq_ctx_reserve(mq_ctx *ctx, uint32_t n_reads, uint64_t total_bytes);
 /* mq_map_batch_device on this context. */
 int mq_ctx_map_batch_device(mq_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases,
                             mq_hit *d_out, void *stream);

@@ -24,7 +24,7 @@ EXPORTS = ["mq_last_error", "mq_abi_version", "mq_device_count", "mq_params_defa
            "mq_index_add_ref", "mq_index_add_ref_device", "mq_index_finalize", "mq_index_get_stats", "mq_index_ref_info",
            "mq_map_batch", "mq_map_batch_device", "mq_map_reserve", "mq_kminmers_batch", "mq_index_lookup", "mq_format_paf",
            "mq_last_map_ms", "mq_last_map_path_counts", "mq_host_alloc", "mq_host_free", "mq_index_save", "mq_index_load", "mq_map_probe_stats",
-           "mq_ctx_new", "mq_ctx_free", "mq_ctx_map_batch", "mq_ctx_submit", "mq_ctx_submit_spans", "mq_ctx_wait", "mq_ctx_map_batch_device", "mq_ctx_last_map_ms", "mq_probe_rate"]
+           "mq_ctx_new", "mq_ctx_free", "mq_ctx_map_batch", "mq_ctx_submit", "mq_ctx_submit_spans", "mq_ctx_wait", "mq_ctx_reserve", "mq_ctx_map_batch_device", "mq_ctx_last_map_ms", "mq_probe_rate"]
 
 
 class MapquikError(RuntimeError):
@@ -90,6 +90,7 @@ def load_library(path=None):
     L.mq_ctx_submit.argtypes = [vp, vp, vp, u32, vp]
     L.mq_ctx_submit_spans.argtypes = [vp, vp, u64, vp, vp, u32, vp]
     L.mq_ctx_wait.argtypes = [vp]
+    L.mq_ctx_reserve.argtypes = [vp, u32, u64]
     L.mq_ctx_map_batch_device.argtypes = [vp, vp, vp, u32, u64, vp, vp]
     L.mq_ctx_last_map_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.mq_probe_rate.argtypes = [vp, u32, u32, u32, u32, C.POINTER(C.c_float), C.POINTER(u64), C.POINTER(u64)]

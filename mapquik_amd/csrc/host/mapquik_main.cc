@@ -3,8 +3,8 @@
 // The hot path runs on the GPU through mapquik_host.hpp / the C ABI.  Reads come through fastx_feeder.hpp (parallel chunk
 // reader for raw files, one inflate thread + parser threads for .gz / .lz4), go to the GPU as raw FASTX bytes + spans
 // (mq_ctx_submit_spans, three stream slots per GPU so that copy-in, kernels and copy-out of consecutive chunks overlap),
-// and the PAF is formatted by a small thread pool and written in input order.  The reference FASTA still goes through the
-// simple line reader below (it is read once).
+// and the PAF is formatted by a small thread pool and written in input order.  The reference FASTA comes through the same
+// feeder (its records go to mq_index_add_ref straight from the page-locked chunks).
 #include <zlib.h>
 
 #include <algorithm>
@@ -81,78 +81,6 @@ static bool is_fasta_name(const std::string &n) {
            ends_with(n, ".fasta");
 }
 
-// get_reader (src/main.rs:60-75): raw or gzip through zlib (which also reads plain files); lz4 is not supported here
-struct Reader {
-    gzFile f = nullptr;
-    std::vector<char> buf;
-    explicit Reader(const std::string &path) : buf(1 << 20) {
-        if (ends_with(path, ".lz4")) {
-            fprintf(stderr, "Error opening compressed file: lz4 input is not supported by this driver\n");
-            exit(2);
-        }
-        f = gzopen(path.c_str(), "rb");
-        if (!f) {
-            fprintf(stderr, "Error opening compressed file: %s\n", path.c_str());
-            exit(2);
-        }
-        gzbuffer(f, 1 << 20);
-    }
-    ~Reader() { if (f) gzclose(f); }
-    bool line(std::string &out) {
-        out.clear();
-        for (;;) {
-            if (!gzgets(f, buf.data(), (int)buf.size())) return !out.empty();
-            const size_t n = strlen(buf.data());
-            out.append(buf.data(), n);
-            if (n && buf[n - 1] == '\n') break;
-        }
-        while (!out.empty() && (out.back() == '\n' || out.back() == '\r')) out.pop_back();
-        return true;
-    }
-};
-
-static std::string first_word(const std::string &h) {
-    size_t e = 1;
-    while (e < h.size() && !isspace((unsigned char)h[e])) ++e;
-    return h.substr(1, e - 1);
-}
-static void upper(std::string &s) {
-    for (auto &c : s)
-        if (c >= 'a' && c <= 'z') c = (char)(c - 32);  // to_ascii_uppercase (src/closures.rs:63,106)
-}
-
-// calls fn(id, seq) per record; FASTA may be multi-line, FASTQ is 4-line
-template <class Fn>
-static void read_fastx(const std::string &path, bool fasta, Fn fn) {
-    Reader r(path);
-    std::string ln, id, seq;
-    if (fasta) {
-        bool have = false;
-        while (r.line(ln)) {
-            if (!ln.empty() && ln[0] == '>') {
-                if (have) { upper(seq); fn(id, seq); }
-                id = first_word(ln);
-                seq.clear();
-                have = true;
-            } else if (have) {
-                seq += ln;
-            }
-        }
-        if (have) { upper(seq); fn(id, seq); }
-    } else {
-        std::string plus, qual;
-        while (r.line(ln)) {
-            if (ln.empty()) continue;
-            id = first_word(ln);
-            if (!r.line(seq)) break;
-            r.line(plus);
-            r.line(qual);
-            upper(seq);
-            fn(id, seq);
-        }
-    }
-}
-
 struct Opt {
     std::string reads, reference, prefix;
     bool has_prefix = false, debug = false, low_memory = false, nosimd = false, nohpc = false, parallelfastx = false, unmapped = false;
@@ -160,7 +88,8 @@ struct Opt {
     double density = -1;
     int device = 0;
     int gpus = 1;
-    unsigned long long batch_bases = 1ull << 28;  // raw input bytes per chunk
+    unsigned long long batch_bases = 1ull << 25;  // raw input bytes per chunk (page-locked buffers this size; pinning memory is the
+                                                  // start-up cost of the read phase, so chunks are small)
 };
 
 static void usage() {
@@ -247,39 +176,79 @@ int main(int argc, char **argv) {
         }
         auto dev_of = [&](int g) { return fake && n_dev > 0 ? (o.device + g) % n_dev : o.device + g; };
 
-        auto t0 = Clock::now();
-        std::vector<std::pair<std::string, std::string>> refs;
-        read_fastx(o.reference, ref_fasta, [&](const std::string &id, const std::string &seq) { refs.emplace_back(id, seq); });
-        std::vector<std::unique_ptr<ReadOnlyIndex>> ro((size_t)o.gpus);
-        std::vector<std::vector<size_t>> counts((size_t)o.gpus);
-        std::vector<std::string> errs((size_t)o.gpus);
-        {
-            std::vector<std::thread> th;
-            for (int g = 0; g < o.gpus; ++g)
-                th.emplace_back([&, g]() {
-                    try {
-                        Index index(P, dev_of(g));
-                        for (size_t r = 0; r < refs.size(); ++r)
-                            counts[g].push_back(mers::ref_extract(r, refs[r].first, (const uint8_t *)refs[r].second.data(), refs[r].second.size(), P, index));
-                        ro[g].reset(new ReadOnlyIndex(std::move(index).into_read_only()));
-                    } catch (const Error &e) { errs[g] = e.what(); }
-                });
-            for (auto &t : th) t.join();
-        }
-        for (auto &e : errs) if (!e.empty()) throw Error(e);
-        for (size_t r = 0; r < refs.size(); ++r) printf("Indexed reference %s: %zu k-min-mers.\n", refs[r].first.c_str(), counts[0][r]);  // src/closures.rs:58
-        refs.clear();
-        refs.shrink_to_fit();
-        printf("Indexed %llu unique k-min-mers in %s.\n", (unsigned long long)ro[0]->unique_count(), rust_duration(secs(t0)).c_str());
-
-        t0 = Clock::now();
-        if (P.use_pfx && !ends_with(o.reads, ".gz") && !ends_with(o.reads, ".lz4")) puts("Warning: using experimental rust-parallelfastx (exciting!)");
+        // The read feeder starts now: while the reference is read and indexed it allocates its page-locked chunk buffers and
+        // reads + parses the first chunks (as many as its pool holds).  Parsing reads does not depend on the index.
         using feeder::Chunk;
         const int n_parse = (int)std::max<size_t>(1, threads);
         const int n_slots = 3;  // stream slots per GPU: copy-in, kernels and copy-out of consecutive chunks overlap
         const int n_format = std::max(1, std::min(4, n_parse / 2));
         feeder::Feeder feed(o.reads, !reads_fasta, o.batch_bases, n_parse, n_parse + o.gpus * (n_slots + 1) + n_format + 2);
-        feed.start();
+        const bool prefetch = getenv("MQ_DRIVER_NO_PREFETCH") == nullptr;  // measurement hook: start reading only when the index is ready
+        if (prefetch) feed.start();
+
+        auto t0 = Clock::now();
+        // index_mers (src/closures.rs:46-51) per reference record, in file order; every GPU builds its own replica of the
+        // index from the same page-locked chunk (one thread per GPU per record); the kernels fold soft-masked lower case
+        std::vector<std::unique_ptr<Index>> building((size_t)o.gpus);
+        for (int g = 0; g < o.gpus; ++g) building[g].reset(new Index(P, dev_of(g)));
+        {
+            // pageable chunk buffers here: every reference byte is copied to the device exactly once, and pinning memory costs
+            // more than a pageable copy saves
+            feeder::Feeder rfeed(o.reference, !ref_fasta, 1ull << 28, n_parse, n_parse + 4, [](size_t n) { return malloc(n); },
+                                 [](void *q) { free(q); });
+            rfeed.start();
+            std::map<size_t, Chunk *> held;
+            size_t next = 0, ref_idx = 0;
+            std::string name;
+            auto flush = [&]() {
+                for (auto it = held.find(next); it != held.end(); it = held.find(next)) {
+                    Chunk *c = it->second;
+                    for (size_t i = 0; i < c->starts.size(); ++i) {
+                        name.assign((const char *)c->buf + c->ids[i].off, c->ids[i].len);
+                        std::vector<size_t> cnt((size_t)o.gpus, 0);
+                        std::vector<std::string> errs((size_t)o.gpus);
+                        std::vector<std::thread> th;
+                        for (int g = 0; g < o.gpus; ++g)
+                            th.emplace_back([&, g]() {
+                                try {
+                                    cnt[g] = mers::ref_extract(ref_idx, name, c->buf + c->starts[i], c->lens[i], P, *building[g]);
+                                } catch (const Error &e) { errs[g] = e.what(); }
+                            });
+                        for (auto &t : th) t.join();
+                        for (auto &e : errs) if (!e.empty()) throw Error(e);
+                        printf("Indexed reference %s: %zu k-min-mers.\n", name.c_str(), cnt[0]);  // src/closures.rs:58
+                        ++ref_idx;
+                    }
+                    held.erase(it);
+                    rfeed.recycle(c);
+                    ++next;
+                }
+            };
+            while (Chunk *c = rfeed.next()) {
+                held[c->seq_no] = c;
+                flush();
+            }
+            flush();
+        }
+        std::vector<std::unique_ptr<ReadOnlyIndex>> ro((size_t)o.gpus);
+        {
+            std::vector<std::string> errs((size_t)o.gpus);
+            std::vector<std::thread> th;
+            for (int g = 0; g < o.gpus; ++g)
+                th.emplace_back([&, g]() {
+                    try {
+                        ro[g].reset(new ReadOnlyIndex(std::move(*building[g]).into_read_only()));
+                    } catch (const Error &e) { errs[g] = e.what(); }
+                });
+            for (auto &t : th) t.join();
+            for (auto &e : errs) if (!e.empty()) throw Error(e);
+            building.clear();
+        }
+        printf("Indexed %llu unique k-min-mers in %s.\n", (unsigned long long)ro[0]->unique_count(), rust_duration(secs(t0)).c_str());
+
+        t0 = Clock::now();
+        if (P.use_pfx && !ends_with(o.reads, ".gz") && !ends_with(o.reads, ".lz4")) puts("Warning: using experimental rust-parallelfastx (exciting!)");
+        if (!prefetch) feed.start();
         std::mutex mu;
         std::condition_variable cv;
         std::deque<Chunk *> to_format;               // mapped, waiting for a formatter
@@ -310,6 +279,9 @@ int main(int argc, char **argv) {
                     for (int sl = 0; sl < n_slots; ++sl) {
                         ctx[sl] = mq_ctx_new(ro[g]->handle());
                         if (!ctx[sl]) throw Error(std::string("mq_ctx_new: ") + last_error());
+                        const uint64_t cb = std::min<uint64_t>(o.batch_bases + o.batch_bases / 8 + (1u << 20), feed.bytes_in() + 64);
+                        if (mq_ctx_reserve(ctx[sl], (uint32_t)std::min<uint64_t>(cb / 2000 + 1024, 1u << 24), cb) != MQ_OK)
+                            throw Error(std::string("mq_ctx_reserve: ") + last_error());
                     }
                     for (size_t k = 0;; ++k) {
                         Chunk *c = feed.next();

@@ -1388,6 +1388,20 @@ int mq_ctx_submit_spans(mq_ctx *ctx, const uint8_t *buf, uint64_t buf_bytes, con
     return ctx_submit(ctx, buf, buf_bytes, starts, lens, n, out);
 }
 
+int mq_ctx_reserve(mq_ctx *ctx, uint32_t n_reads, uint64_t total_bytes) {
+    if (!ctx) return set_err(MQ_EINVAL, "ctx is NULL");
+    mq_ctx *c = ctx;
+    int rc = use_device(c->idx);
+    if (rc) return rc;
+    if ((rc = grow_pinned(c->h_off, c->h_off_cap, (uint64_t)n_reads + 1))) return rc;
+    if ((rc = grow_pinned(c->h_out, c->h_out_cap, (uint64_t)n_reads))) return rc;
+    if ((rc = ctx_ensure(c, n_reads, total_bytes, list_f16(c->idx)))) return rc;
+    if ((rc = grow(c->st_bases, c->st_bases_cap, total_bytes + 64))) return rc;
+    if ((rc = grow(c->st_off, c->st_off_cap, (uint64_t)n_reads + 1))) return rc;
+    if ((rc = grow(c->st_out, c->st_out_cap, (uint64_t)n_reads))) return rc;
+    return grow(c->st_lens, c->st_lens_cap, (uint64_t)n_reads);
+}
+
 int mq_ctx_wait(mq_ctx *ctx) {
     if (!ctx) return set_err(MQ_EINVAL, "ctx is NULL");
     return ctx_wait(ctx);

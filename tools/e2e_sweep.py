@@ -1,0 +1,47 @@
+"""Diagnostic: file -> PAF rate of the native driver for several thread counts / chunk sizes / input formats, on the bench's
+CHM13-like workload.  usage: python tools/e2e_sweep.py [genome_scale] [n_reads]"""
+import gzip, os, re, subprocess, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from mapquik_amd import build as B
+from tools import sim
+
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 196608
+lens = [max(40, int(x * scale)) for x in sim.CHM13_LIKE]
+genome, off, names = sim.make_genome(lens, seed=2013, threads=16, repeat_frac=0.05, tandem_frac=0.01)
+reads = sim.make_reads(genome, off, n_reads, seed=3013, threads=16)
+exe = B.build_cli()
+base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+with tempfile.TemporaryDirectory(dir=base) as wd:
+    ref, rd, fq = os.path.join(wd, "ref.fa"), os.path.join(wd, "reads.fa"), os.path.join(wd, "reads.fq")
+    with open(ref, "wb") as f:
+        for r in range(len(names)):
+            f.write(b">" + names[r].encode() + b"\n")
+            genome[int(off[r]):int(off[r + 1])].tofile(f)
+            f.write(b"\n")
+    o = reads["offsets"]
+    with open(rd, "wb") as f, open(fq, "wb") as g:
+        for i in range(n_reads):
+            s = reads["bases"][int(o[i]):int(o[i + 1])]
+            f.write(b">r%d\n" % i); s.tofile(f); f.write(b"\n")
+            if i < n_reads // 4:
+                g.write(b"@r%d\n" % i); s.tofile(g); g.write(b"\n+\n"); g.write(b"I" * s.size); g.write(b"\n")
+    bases = int(o[n_reads]); qbases = int(o[n_reads // 4])
+
+    def run(path, nb, extra, tag, env=None):
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, path, "--reference", ref, "-p", os.path.join(wd, "o")] + extra, capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, **(env or {})))
+        wall = time.perf_counter() - t0
+        m = re.search(r"Mapped query sequences in ([0-9.]+)(s|ms|µs|ns)", r.stdout)
+        t = float(m.group(1)) * {"s": 1, "ms": 1e-3, "µs": 1e-6, "ns": 1e-9}[m.group(2)] if m else float("nan")
+        print("%-44s map phase %.3f s = %.2f Gbases/s   wall %.1f s  rc %d %s" % (tag, t, nb / t / 1e9, wall, r.returncode, r.stderr[-200:] if r.returncode else ""), flush=True)
+
+    NP = {"MQ_DRIVER_NO_PREFETCH": "1"}
+    run(rd, bases, ["--threads", "16"], "FASTA 16 threads, prefetch during indexing")
+    for th in (16, 8, 4, 2):
+        run(rd, bases, ["--threads", str(th)], "FASTA %d threads, no prefetch" % th, NP)
+    for cb in (1 << 25, 1 << 29):
+        run(rd, bases, ["--threads", "16", "--batch-bases", str(cb)], "FASTA 16 threads chunk %d MB, no prefetch" % (cb >> 20), NP)
+    run(fq, qbases, ["--threads", "16"], "FASTQ 16 threads (quarter of the reads), no prefetch", NP)
