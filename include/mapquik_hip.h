@@ -118,6 +118,9 @@ int mq_index_get_stats(const mq_index *idx, mq_index_stats *out);
  * The file holds the parameters, the reference names/lengths and the slot table; mq_index_load returns a finalized index. */
 int mq_index_save(const mq_index *idx, const char *path);
 mq_index *mq_index_load(const char *path, int device);
+/* A replica of a finalized index on HIP device `device` (device-to-device copy of the table; the multi-GPU drivers build the
+ * index once and clone it instead of indexing the reference on every GPU).  Free it with mq_index_free. */
+mq_index *mq_index_clone(const mq_index *src, int device);
 int mq_index_ref_info(const mq_index *idx, uint32_t ref_id, const char **name, uint64_t *len);
 
 /* find_matches (src/mers.rs:77-102) for n reads.  bases: concatenated reads; offsets: n+1 prefix offsets.

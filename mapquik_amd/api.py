@@ -23,7 +23,7 @@ assert hit_dtype.itemsize == 40 and kminmer_dtype.itemsize == 24
 EXPORTS = ["mq_last_error", "mq_abi_version", "mq_device_count", "mq_params_default", "mq_index_new", "mq_index_free",
            "mq_index_add_ref", "mq_index_add_ref_device", "mq_index_finalize", "mq_index_get_stats", "mq_index_ref_info",
            "mq_map_batch", "mq_map_batch_device", "mq_map_reserve", "mq_kminmers_batch", "mq_index_lookup", "mq_format_paf",
-           "mq_last_map_ms", "mq_last_map_path_counts", "mq_host_alloc", "mq_host_free", "mq_index_save", "mq_index_load", "mq_map_probe_stats",
+           "mq_last_map_ms", "mq_last_map_path_counts", "mq_host_alloc", "mq_host_free", "mq_index_save", "mq_index_load", "mq_index_clone", "mq_map_probe_stats",
            "mq_ctx_new", "mq_ctx_free", "mq_ctx_map_batch", "mq_ctx_submit", "mq_ctx_submit_spans", "mq_ctx_wait", "mq_ctx_reserve", "mq_ctx_map_batch_device", "mq_ctx_last_map_ms", "mq_probe_rate"]
 
 
@@ -100,6 +100,8 @@ def load_library(path=None):
     L.mq_last_map_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.mq_map_probe_stats.argtypes = [vp, vp, vp, u32, u64, vp, C.POINTER(u64), C.POINTER(u64)]
     L.mq_index_save.argtypes = [vp, C.c_char_p]
+    L.mq_index_clone.restype = vp
+    L.mq_index_clone.argtypes = [vp, C.c_int]
     L.mq_index_load.restype = vp
     L.mq_index_load.argtypes = [C.c_char_p, C.c_int]
     L.mq_host_alloc.restype = vp
@@ -173,6 +175,13 @@ class Index:
         if not h:
             raise _err(L, "mq_index_load")
         return cls(None, device, _handle=h)
+
+    def clone(self, device):
+        """A replica of this finalized index on another device (device-to-device copy, no re-indexing)."""
+        h = self._L.mq_index_clone(self._h, device)
+        if not h:
+            raise _err(self._L, "mq_index_clone")
+        return Index(self.params, device, _handle=h)
 
     def close(self):
         if getattr(self, "_h", None):

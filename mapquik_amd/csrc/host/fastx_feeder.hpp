@@ -46,7 +46,7 @@ struct Chunk {
     std::vector<uint32_t> lens;
     std::vector<IdSpan> ids;
     std::vector<mq_hit> hits;
-    std::string paf, unmapped;  // formatted output of this chunk
+    std::string paf, unmapped, unmapped_fa;  // formatted output of this chunk
     void clear() {
         begin = bytes = 0;
         starts.clear();
@@ -55,6 +55,7 @@ struct Chunk {
         hits.clear();
         paf.clear();
         unmapped.clear();
+        unmapped_fa.clear();
     }
 };
 

@@ -91,6 +91,12 @@ class ReadOnlyIndex {
         mq_index_get_stats(h, &st);
         return ReadOnlyIndex(h, st.n_unique);
     }
+    // a replica on another device (device-to-device copy of the table)
+    ReadOnlyIndex clone_to(int device) const {
+        mq_index *h = mq_index_clone(h_, device);
+        if (!h) throw Error("ReadOnlyIndex::clone_to: " + last_error());
+        return ReadOnlyIndex(h, unique_);
+    }
     void save(const std::string &path) const {
         if (mq_index_save(h_, path.c_str()) != MQ_OK) throw Error("ReadOnlyIndex::save: " + last_error());
     }

@@ -88,6 +88,9 @@ struct Opt {
     double density = -1;
     int device = 0;
     int gpus = 1;
+    std::string second;  // "k2,l2,d2"
+    long k2 = 0, l2 = 0;
+    double d2 = 0;
     unsigned long long batch_bases = 1ull << 25;  // raw input bytes per chunk (page-locked buffers this size; pinning memory is the
                                                   // start-up cost of the read phase, so chunks are small)
 };
@@ -98,73 +101,17 @@ static void usage() {
          "        --parallelfastx\n        --unmapped      (extension) also write <prefix>.unmapped.out\n\nOPTIONS:\n"
          "    -b <b>\n    -c, --chain <chain>\n    -d, --density <density>\n    -g, --gap-diff <gap-diff>\n    -k <k>\n    -l <l>\n"
          "    -p, --prefix <prefix>\n    -q <q>\n        --reference <reference>\n    -s, --seed <seed>\n        --threads <threads>\n"
-         "        --device <n>    (extension) first HIP device ordinal\n        --gpus <n>      (extension) shard read batches over n GPUs, index replicated\n        --batch-bases <n> (extension)\n\nARGS:\n    <reads>");
+         "        --device <n>    (extension) first HIP device ordinal\n        --gpus <n>      (extension) shard read batches over n GPUs, index replicated\n        --batch-bases <n> (extension) raw input bytes per chunk\n        --second-pass <k2,l2,d2> (extension) map the unmapped reads again with these parameters: <prefix>-k2-l2-d2.{fa,paf,unmapped.out}\n\nARGS:\n    <reads>");
 }
 
-int main(int argc, char **argv) {
-    const auto start = Clock::now();
-    Opt o;
-    for (int i = 1; i < argc; ++i) {
-        const std::string a = argv[i];
-        auto val = [&]() -> const char * {
-            if (i + 1 >= argc) { fprintf(stderr, "error: %s needs a value\n", a.c_str()); exit(2); }
-            return argv[++i];
-        };
-        if (a == "-h" || a == "--help") { usage(); return 0; }
-        else if (a == "--debug") o.debug = true;
-        else if (a == "--low-memory") o.low_memory = true;
-        else if (a == "--nosimd") o.nosimd = true;
-        else if (a == "--nohpc") o.nohpc = true;
-        else if (a == "--parallelfastx") o.parallelfastx = true;
-        else if (a == "--unmapped") o.unmapped = true;
-        else if (a == "-p" || a == "--prefix") { o.prefix = val(); o.has_prefix = true; }
-        else if (a == "-k") o.k = atol(val());
-        else if (a == "-l") o.l = atol(val());
-        else if (a == "-d" || a == "--density") o.density = atof(val());
-        else if (a == "-c" || a == "--chain") o.c = atol(val());
-        else if (a == "-s" || a == "--seed") o.s = atol(val());
-        else if (a == "-g" || a == "--gap-diff") o.g = atol(val());
-        else if (a == "--reference") o.reference = val();
-        else if (a == "--threads") o.threads = atol(val());
-        else if (a == "-b") o.b = atol(val());
-        else if (a == "-q") o.q = atol(val());
-        else if (a == "--device") o.device = atoi(val());
-        else if (a == "--gpus") o.gpus = std::max(1, atoi(val()));
-        else if (a == "--batch-bases") o.batch_bases = strtoull(val(), nullptr, 10);
-        else if (!a.empty() && a[0] == '-') { fprintf(stderr, "error: Found argument '%s' which wasn't expected\n", a.c_str()); return 2; }
-        else o.reads = a;
-    }
-    if (o.reads.empty()) { fprintf(stderr, "Please specify an input file.\n"); return 101; }          // panic!, src/main.rs:191
-    if (o.reference.empty()) { fprintf(stderr, "Please specify a reference file.\n"); return 101; }   // src/main.rs:192
-
-    Params P;
-    size_t threads = 8;
-    const bool reads_fasta = is_fasta_name(o.reads), ref_fasta = is_fasta_name(o.reference);
-    if (reads_fasta) printf("Input file: %s\nFormat: FASTA\n", o.reads.c_str());
-    if (ref_fasta) printf("Reference file: %s\nFormat: FASTA\n", o.reference.c_str());
-    if (o.k >= 0) P.k = (size_t)o.k; else printf("Warning: Using default k value (%zu).\n", P.k);
-    if (o.l >= 0) P.l = (size_t)o.l; else printf("Warning: Using default l value (%zu).\n", P.l);
-    if (o.b >= 0) P.b = (size_t)o.b; else printf("Warning: Using default buffer size (%zuX).\n", P.b);
-    if (o.q >= 0) P.q = (size_t)o.q; else printf("Warning: Using default queue length (%zu).\n", P.q);
-    if (o.density >= 0) P.density = o.density; else printf("Warning: Using default density value (%s%%).\n", rust_float(P.density * 100.0).c_str());
-    if (o.threads >= 0) threads = (size_t)o.threads; else printf("Warning: Using default number of threads (8).\n");
-    if (o.c >= 0) P.c = (size_t)o.c; else printf("Warning: Using default minimum chain length (%zu).\n", P.c);
-    if (o.s >= 0) P.s = (size_t)o.s; else printf("Warning: Using default minimum number of matching seeds (%zu).\n", P.s);
-    if (o.g >= 0) P.g = (size_t)o.g; else printf("Warning: Using default maximum seed gap difference (%zu).\n", P.g);
-    std::string prefix = "mapquik-k" + std::to_string(P.k) + "-d" + rust_float(P.density) + "-l" + std::to_string(P.l);
-    if (o.has_prefix) prefix = o.prefix; else printf("Warning: Using default output prefix (%s).\n", prefix.c_str());
-    P.debug = o.debug;
-    P.use_hpc = !o.nohpc;
-    P.use_simd = !o.nosimd;
-    P.use_pfx = o.parallelfastx;
-    P.fold_case = true;  // raw FASTX bytes go to the GPU: the kernels do the reference's to_ascii_uppercase
-    if (P.use_hpc) puts(P.use_simd ? "Using HPC ntHash, with SIMD" : "Using HPC ntHash, scalar");
-    else puts(P.use_simd ? "Using regular ntHash (not HPC), with SIMD" : "Using regular ntHash (not HPC), scalar");
-
-    try {
+// One run of the reference's flow (src/closures.rs:22-212): index the reference, map the reads, write <prefix>.paf in input
+// order.  second_fa != "": the reads left unmapped also go to that FASTA file (for the second pass).
+static int run_pass(const Opt &o, const Params &P, const std::string &reads_path, bool reads_fasta, bool ref_fasta, const std::string &prefix,
+                    size_t threads, const std::string &second_fa) {
         FILE *paf = fopen((prefix + ".paf").c_str(), "w");  // src/closures.rs:32
         if (!paf) { fprintf(stderr, "Couldn't create %s.paf\n", prefix.c_str()); return 101; }
-        FILE *unm = o.unmapped ? fopen((prefix + ".unmapped.out").c_str(), "w") : nullptr;
+        FILE *unm = (o.unmapped || !o.second.empty()) ? fopen((prefix + ".unmapped.out").c_str(), "w") : nullptr;
+        FILE *ufa = second_fa.empty() ? nullptr : fopen(second_fa.c_str(), "w");  // the unmapped reads as FASTA (seqtk subseq in the reference's script)
 
         // --gpus N: the index is replicated (every GPU indexes the same reference), read batches are dealt round-robin,
         // PAF lines are written in batch order = input order.  No collective: reads are independent.
@@ -182,15 +129,15 @@ int main(int argc, char **argv) {
         const int n_parse = (int)std::max<size_t>(1, threads);
         const int n_slots = 3;  // stream slots per GPU: copy-in, kernels and copy-out of consecutive chunks overlap
         const int n_format = std::max(1, std::min(4, n_parse / 2));
-        feeder::Feeder feed(o.reads, !reads_fasta, o.batch_bases, n_parse, n_parse + o.gpus * (n_slots + 1) + n_format + 2);
+        feeder::Feeder feed(reads_path, !reads_fasta, o.batch_bases, n_parse, n_parse + o.gpus * (n_slots + 1) + n_format + 2);
         const bool prefetch = getenv("MQ_DRIVER_NO_PREFETCH") == nullptr;  // measurement hook: start reading only when the index is ready
         if (prefetch) feed.start();
 
         auto t0 = Clock::now();
-        // index_mers (src/closures.rs:46-51) per reference record, in file order; every GPU builds its own replica of the
-        // index from the same page-locked chunk (one thread per GPU per record); the kernels fold soft-masked lower case
-        std::vector<std::unique_ptr<Index>> building((size_t)o.gpus);
-        for (int g = 0; g < o.gpus; ++g) building[g].reset(new Index(P, dev_of(g)));
+        // index_mers (src/closures.rs:46-51) per reference record, in file order, on the first GPU; the finalized table is then
+        // copied device to device to the other GPUs (mq_index_clone).  The kernels fold soft-masked lower case.
+        std::vector<std::unique_ptr<Index>> building(1);
+        building[0].reset(new Index(P, dev_of(0)));
         {
             // pageable chunk buffers here: every reference byte is copied to the device exactly once, and pinning memory costs
             // more than a pageable copy saves
@@ -205,18 +152,8 @@ int main(int argc, char **argv) {
                     Chunk *c = it->second;
                     for (size_t i = 0; i < c->starts.size(); ++i) {
                         name.assign((const char *)c->buf + c->ids[i].off, c->ids[i].len);
-                        std::vector<size_t> cnt((size_t)o.gpus, 0);
-                        std::vector<std::string> errs((size_t)o.gpus);
-                        std::vector<std::thread> th;
-                        for (int g = 0; g < o.gpus; ++g)
-                            th.emplace_back([&, g]() {
-                                try {
-                                    cnt[g] = mers::ref_extract(ref_idx, name, c->buf + c->starts[i], c->lens[i], P, *building[g]);
-                                } catch (const Error &e) { errs[g] = e.what(); }
-                            });
-                        for (auto &t : th) t.join();
-                        for (auto &e : errs) if (!e.empty()) throw Error(e);
-                        printf("Indexed reference %s: %zu k-min-mers.\n", name.c_str(), cnt[0]);  // src/closures.rs:58
+                        const size_t cnt = mers::ref_extract(ref_idx, name, c->buf + c->starts[i], c->lens[i], P, *building[0]);
+                        printf("Indexed reference %s: %zu k-min-mers.\n", name.c_str(), cnt);  // src/closures.rs:58
                         ++ref_idx;
                     }
                     held.erase(it);
@@ -232,22 +169,23 @@ int main(int argc, char **argv) {
         }
         std::vector<std::unique_ptr<ReadOnlyIndex>> ro((size_t)o.gpus);
         {
+            ro[0].reset(new ReadOnlyIndex(std::move(*building[0]).into_read_only()));
+            building.clear();
             std::vector<std::string> errs((size_t)o.gpus);
             std::vector<std::thread> th;
-            for (int g = 0; g < o.gpus; ++g)
+            for (int g = 1; g < o.gpus; ++g)
                 th.emplace_back([&, g]() {
                     try {
-                        ro[g].reset(new ReadOnlyIndex(std::move(*building[g]).into_read_only()));
+                        ro[g].reset(new ReadOnlyIndex(ro[0]->clone_to(dev_of(g))));
                     } catch (const Error &e) { errs[g] = e.what(); }
                 });
             for (auto &t : th) t.join();
             for (auto &e : errs) if (!e.empty()) throw Error(e);
-            building.clear();
         }
         printf("Indexed %llu unique k-min-mers in %s.\n", (unsigned long long)ro[0]->unique_count(), rust_duration(secs(t0)).c_str());
 
         t0 = Clock::now();
-        if (P.use_pfx && !ends_with(o.reads, ".gz") && !ends_with(o.reads, ".lz4")) puts("Warning: using experimental rust-parallelfastx (exciting!)");
+        if (P.use_pfx && !ends_with(reads_path, ".gz") && !ends_with(reads_path, ".lz4")) puts("Warning: using experimental rust-parallelfastx (exciting!)");
         if (!prefetch) feed.start();
         std::mutex mu;
         std::condition_variable cv;
@@ -338,6 +276,13 @@ int main(int argc, char **argv) {
                             c->paf.push_back('\n');
                         } else if (h.status == MQ_HIT_UNMAPPED) {
                             if (unm) { c->unmapped += id; c->unmapped.push_back('\n'); }
+                            if (ufa) {
+                                c->unmapped_fa.push_back('>');
+                                c->unmapped_fa += id;
+                                c->unmapped_fa.push_back('\n');
+                                c->unmapped_fa.append((const char *)c->buf + c->starts[i], c->lens[i]);
+                                c->unmapped_fa.push_back('\n');
+                            }
                         } else {
                             fail("find_matches: read " + id + " could not be processed");
                             break;
@@ -366,6 +311,7 @@ int main(int argc, char **argv) {
             }
             if (!c->paf.empty()) fwrite(c->paf.data(), 1, c->paf.size(), paf);
             if (unm && !c->unmapped.empty()) fwrite(c->unmapped.data(), 1, c->unmapped.size(), unm);
+            if (ufa && !c->unmapped_fa.empty()) fwrite(c->unmapped_fa.data(), 1, c->unmapped_fa.size(), ufa);
             feed.recycle(c);
             ++next_out;
         }
@@ -375,12 +321,99 @@ int main(int argc, char **argv) {
         if (!werr.empty()) {
             fclose(paf);
             if (unm) fclose(unm);
+            if (ufa) fclose(ufa);
             remove((prefix + ".paf").c_str());  // never leave a partial PAF behind a failure
             throw Error(werr);
         }
         fclose(paf);
         if (unm) fclose(unm);
+        if (ufa) fclose(ufa);
         printf("Mapped query sequences in %s.\n", rust_duration(secs(t0)).c_str());  // src/closures.rs:211
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    const auto start = Clock::now();
+    Opt o;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> const char * {
+            if (i + 1 >= argc) { fprintf(stderr, "error: %s needs a value\n", a.c_str()); exit(2); }
+            return argv[++i];
+        };
+        if (a == "-h" || a == "--help") { usage(); return 0; }
+        else if (a == "--debug") o.debug = true;
+        else if (a == "--low-memory") o.low_memory = true;
+        else if (a == "--nosimd") o.nosimd = true;
+        else if (a == "--nohpc") o.nohpc = true;
+        else if (a == "--parallelfastx") o.parallelfastx = true;
+        else if (a == "--unmapped") o.unmapped = true;
+        else if (a == "-p" || a == "--prefix") { o.prefix = val(); o.has_prefix = true; }
+        else if (a == "-k") o.k = atol(val());
+        else if (a == "-l") o.l = atol(val());
+        else if (a == "-d" || a == "--density") o.density = atof(val());
+        else if (a == "-c" || a == "--chain") o.c = atol(val());
+        else if (a == "-s" || a == "--seed") o.s = atol(val());
+        else if (a == "-g" || a == "--gap-diff") o.g = atol(val());
+        else if (a == "--reference") o.reference = val();
+        else if (a == "--threads") o.threads = atol(val());
+        else if (a == "-b") o.b = atol(val());
+        else if (a == "-q") o.q = atol(val());
+        else if (a == "--device") o.device = atoi(val());
+        else if (a == "--gpus") o.gpus = std::max(1, atoi(val()));
+        else if (a == "--batch-bases") o.batch_bases = strtoull(val(), nullptr, 10);
+        else if (a == "--second-pass") {
+            o.second = val();
+            char *e1 = nullptr, *e2 = nullptr;
+            o.k2 = strtol(o.second.c_str(), &e1, 10);
+            o.l2 = (e1 && *e1 == ',') ? strtol(e1 + 1, &e2, 10) : 0;
+            o.d2 = (e2 && *e2 == ',') ? atof(e2 + 1) : -1;
+            if (o.k2 < 1 || o.l2 < 1 || !(o.d2 > 0)) { fprintf(stderr, "error: --second-pass wants k2,l2,d2\n"); return 2; }
+        }
+        else if (!a.empty() && a[0] == '-') { fprintf(stderr, "error: Found argument '%s' which wasn't expected\n", a.c_str()); return 2; }
+        else o.reads = a;
+    }
+    if (o.reads.empty()) { fprintf(stderr, "Please specify an input file.\n"); return 101; }          // panic!, src/main.rs:191
+    if (o.reference.empty()) { fprintf(stderr, "Please specify a reference file.\n"); return 101; }   // src/main.rs:192
+
+    Params P;
+    size_t threads = 8;
+    const bool reads_fasta = is_fasta_name(o.reads), ref_fasta = is_fasta_name(o.reference);
+    if (reads_fasta) printf("Input file: %s\nFormat: FASTA\n", o.reads.c_str());
+    if (ref_fasta) printf("Reference file: %s\nFormat: FASTA\n", o.reference.c_str());
+    if (o.k >= 0) P.k = (size_t)o.k; else printf("Warning: Using default k value (%zu).\n", P.k);
+    if (o.l >= 0) P.l = (size_t)o.l; else printf("Warning: Using default l value (%zu).\n", P.l);
+    if (o.b >= 0) P.b = (size_t)o.b; else printf("Warning: Using default buffer size (%zuX).\n", P.b);
+    if (o.q >= 0) P.q = (size_t)o.q; else printf("Warning: Using default queue length (%zu).\n", P.q);
+    if (o.density >= 0) P.density = o.density; else printf("Warning: Using default density value (%s%%).\n", rust_float(P.density * 100.0).c_str());
+    if (o.threads >= 0) threads = (size_t)o.threads; else printf("Warning: Using default number of threads (8).\n");
+    if (o.c >= 0) P.c = (size_t)o.c; else printf("Warning: Using default minimum chain length (%zu).\n", P.c);
+    if (o.s >= 0) P.s = (size_t)o.s; else printf("Warning: Using default minimum number of matching seeds (%zu).\n", P.s);
+    if (o.g >= 0) P.g = (size_t)o.g; else printf("Warning: Using default maximum seed gap difference (%zu).\n", P.g);
+    std::string prefix = "mapquik-k" + std::to_string(P.k) + "-d" + rust_float(P.density) + "-l" + std::to_string(P.l);
+    if (o.has_prefix) prefix = o.prefix; else printf("Warning: Using default output prefix (%s).\n", prefix.c_str());
+    P.debug = o.debug;
+    P.use_hpc = !o.nohpc;
+    P.use_simd = !o.nosimd;
+    P.use_pfx = o.parallelfastx;
+    P.fold_case = true;  // raw FASTX bytes go to the GPU: the kernels do the reference's to_ascii_uppercase
+    if (P.use_hpc) puts(P.use_simd ? "Using HPC ntHash, with SIMD" : "Using HPC ntHash, scalar");
+    else puts(P.use_simd ? "Using regular ntHash (not HPC), with SIMD" : "Using regular ntHash (not HPC), scalar");
+
+    const std::string second_prefix = prefix + "-" + std::to_string(o.k2) + "-" + std::to_string(o.l2) + "-" + rust_float(o.d2);
+    try {
+        int rc = run_pass(o, P, o.reads, reads_fasta, ref_fasta, prefix, threads, o.second.empty() ? std::string() : second_prefix + ".fa");
+        if (rc) return rc;
+        if (!o.second.empty()) {
+            // the second pass of experiments/chm13/run_chm13_mapquik_unmapped.sh:8-24: the reads the first pass left unmapped,
+            // mapped again with (k2, l2, d2) against a second index of the same reference
+            P.k = (size_t)o.k2;
+            P.l = (size_t)o.l2;
+            P.density = o.d2;
+            printf("Second pass: %s with k=%zu l=%zu density=%s\n", (second_prefix + ".fa").c_str(), P.k, P.l, rust_float(P.density).c_str());
+            rc = run_pass(o, P, second_prefix + ".fa", true, ref_fasta, second_prefix, threads, std::string());
+            if (rc) return rc;
+        }
     } catch (const Error &e) {
         fprintf(stderr, "mapquik: %s\n", e.what());
         return 101;

@@ -1132,6 +1132,40 @@ mq_index *mq_index_load(const char *path, int device) {
     return idx;
 }
 
+// A replica of a finalized index on another device: the table travels device to device (xGMI between the GPUs of a node)
+// instead of being rebuilt from the reference on every GPU.
+mq_index *mq_index_clone(const mq_index *src, int device) {
+    if (!src) {
+        set_err(MQ_EINVAL, "src is NULL");
+        return nullptr;
+    }
+    if (!src->finalized) {
+        set_err(MQ_ESTATE, "index not finalized");
+        return nullptr;
+    }
+    mq_index *idx = mq_index_new(&src->params, device);
+    if (!idx) return nullptr;
+    idx->refs = src->refs;
+    idx->n_kmm_total = src->n_kmm_total;
+    idx->n_keys = src->n_keys;
+    idx->n_unique = src->n_unique;
+    bool ok = alloc_table(idx, src->nslots) == MQ_OK;
+    if (ok) ok = hipMemcpyPeer(idx->table, device, src->table, src->device, (size_t)(src->nslots + 1) * sizeof(Slot)) == hipSuccess;
+    uint32_t max_id = 0;
+    for (auto &kv : idx->refs) max_id = std::max(max_id, kv.first);
+    const size_t nl = (size_t)max_id + 1;
+    if (ok) ok = hipSetDevice(device) == hipSuccess && hipMalloc((void **)&idx->d_ref_lens, nl * sizeof(uint64_t)) == hipSuccess;
+    if (ok) ok = hipMemcpyPeer(idx->d_ref_lens, device, src->d_ref_lens, src->device, nl * sizeof(uint64_t)) == hipSuccess;
+    if (ok) ok = hipDeviceSynchronize() == hipSuccess;
+    if (!ok) {
+        mq_index_free(idx);
+        set_err(MQ_EHIP, "mq_index_clone: device-to-device copy failed");
+        return nullptr;
+    }
+    idx->finalized = true;
+    return idx;
+}
+
 int mq_index_ref_info(const mq_index *idx, uint32_t ref_id, const char **name, uint64_t *len) {
     if (!idx) return set_err(MQ_EINVAL, "idx is NULL");
     auto it = idx->refs.find(ref_id);

@@ -156,3 +156,94 @@ def test_dense_lists_move_to_the_pool_and_pool_exhaustion_is_loud(mq, oracle, si
     assert np.array_equal(raw["status"][ok] == 1, want["mapped"][ok] != 0)
     for p in (db, do, dout):
         hip.hipFree(p)
+
+
+@pytest.mark.parametrize("mode", ["weak", "strong"])
+def test_bench_line_small_run(mode):
+    """bench.py end to end at a small scale in both scaling modes: one JSON line with the contract's keys, the roofline and
+    (weak mode) the end-to-end section; strong mode deals one host-resident read set through mapquik_amd.shard."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--genome-scale", "0.01", "--reads", "3000", "--steps", "2", "--warmup", "1",
+           "--scaling", mode, "--no-cpu-baseline", "--e2e-file-reads", "1500"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "end_to_end", "q60", "q60_wrong"):
+        assert k in j, k
+    assert j["scaling"] == mode and j["value"] > 0 and j["overflow_reads"] == 0
+    assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
+    assert j["q60"] > 0.9 * 3000 and j["q60_wrong"] <= 2
+    e = j["end_to_end"]
+    assert e["host_buffers_hits_identical"] and e["host_buffers_gbases_s"] > 0
+    assert e["file_to_paf"].get("paf_lines", 0) > 1300, e
+
+
+def test_index_clone_is_a_deep_replica(mq, oracle, simlib, small):
+    g, off, names = small
+    ix, ox, po = _index_both(mq, oracle, small, dict())
+    reads = simlib.make_reads(g, off, 200, seed=8)
+    want = ox.map_batch(reads["bases"], reads["offsets"], po, threads=4)
+    rep = ix.clone(0)
+    assert rep.stats() == ix.stats()
+    ix.close()  # the replica owns its table
+    _cmp(rep.map_batch(reads["bases"], reads["offsets"]), want)
+    assert rep.ref_info(1)[0] == names[1]
+
+
+def test_native_driver_second_pass(mq, oracle, simlib, tmp_path):
+    """--second-pass k2,l2,d2 (experiments/chm13/run_chm13_mapquik_unmapped.sh:8-24 in one process): the reads the first pass
+    leaves unmapped are written as FASTA and mapped again with the second parameter set; both PAFs equal the oracle's."""
+    import subprocess
+    from mapquik_amd import build
+    exe = build.build_cli()
+    g, off, names = simlib.make_genome([700000, 500000], seed=77, repeat_frac=0.1)
+    clean = simlib.make_reads(g, off, 120, seed=1, len_mean=9000, len_sd=3000)
+    noisy = simlib.make_reads(g, off, 60, seed=2, len_mean=9000, len_sd=3000, err=0.06)  # mostly unmapped at k=5 l=31
+    seqs, ids = [], []
+    for tag, rd in (("c", clean), ("n", noisy)):
+        o = rd["offsets"]
+        for i in range(o.size - 1):
+            seqs.append(rd["bases"][int(o[i]):int(o[i + 1])])
+            ids.append("%s%d" % (tag, i))
+    order = np.random.default_rng(4).permutation(len(seqs))
+    seqs, ids = [seqs[i] for i in order], [ids[i] for i in order]
+    ref, rdp = tmp_path / "ref.fa", tmp_path / "reads.fa"
+    with open(ref, "wb") as w:
+        for r in range(2):
+            w.write(b">" + names[r].encode() + b"\n" + g[int(off[r]):int(off[r + 1])].tobytes() + b"\n")
+    with open(rdp, "wb") as w:
+        for n, s in zip(ids, seqs):
+            w.write(b">" + n.encode() + b"\n" + s.tobytes() + b"\n")
+    prefix = str(tmp_path / "p1")
+    r = subprocess.run([exe, str(rdp), "--reference", str(ref), "-p", prefix, "--second-pass", "4,14,0.05", "--batch-bases", "300000"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("Mapped query sequences in") == 2 and "Second pass:" in r.stdout
+
+    def oracle_paf(ps, names_, seqs_):
+        po = oracle.params(**ps)
+        ox = oracle.Index()
+        for k in range(2):
+            ox.add_ref(k, names[k], g[int(off[k]):int(off[k + 1])], po)
+        offs = np.zeros(len(seqs_) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([s.size for s in seqs_])
+        bases = np.concatenate(seqs_) if seqs_ else np.zeros(0, dtype=np.uint8)
+        res = ox.map_batch(bases, offs, po, threads=2)
+        return oracle.paf_lines(ox, names_, res), res
+
+    want1, res1 = oracle_paf(dict(), ids, seqs)
+    assert open(prefix + ".paf").read() == "".join(x + "\n" for x in want1)
+    un = [i for i in range(len(ids)) if res1["mapped"][i] == 0]
+    assert 20 < len(un) < 120
+    assert open(prefix + ".unmapped.out").read().split() == [ids[i] for i in un]
+    p2 = prefix + "-4-14-0.05"
+    fa = open(p2 + ".fa").read().split("\n")
+    assert fa[0::2][:len(un)] == [">" + ids[i] for i in un] and fa[1] == seqs[un[0]].tobytes().decode()
+    want2, res2 = oracle_paf(dict(k=4, l=14, density=0.05), [ids[i] for i in un], [seqs[i] for i in un])
+    assert open(p2 + ".paf").read() == "".join(x + "\n" for x in want2)
+    assert (res2["mapped"] != 0).sum() > len(un) // 2  # the second parameter set recovers most of them
