@@ -414,7 +414,8 @@ int main(int argc, char **argv) {
             rc = run_pass(o, P, second_prefix + ".fa", true, ref_fasta, second_prefix, threads, std::string());
             if (rc) return rc;
         }
-    } catch (const Error &e) {
+    } catch (const std::exception &e) {  // mapquik::Error, feeder::FeederError: the reference panics (exit code 101)
+        fflush(stdout);
         fprintf(stderr, "mapquik: %s\n", e.what());
         return 101;
     }

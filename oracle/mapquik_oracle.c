@@ -73,8 +73,23 @@ uint64_t mqo_ntc64(const uint8_t *s, size_t i, size_t l) {
     return f < r ? f : r;
 }
 
+/* Hedge for the unpinned seeding decisions: the frozen reading is variant 0.  The other
+ * variants exist only so that tools/check_against_upstream.sh can tell, on a machine that can build the real crate,
+ * WHICH decision is wrong if the k-min-mer dumps differ: bit 0 = strict `<` on the density bound instead of `<=`,
+ * bit 1 = FH is f32 (the bound is computed in single precision).  Never set by tests or by the product. */
+static int g_variant = 0;
+void mqo_set_variant(int v) { g_variant = v; }
+int mqo_get_variant(void) { return g_variant; }
+static inline int keep_hash(uint64_t h, uint64_t bound) { return (g_variant & 1) ? h < bound : h <= bound; }
+
 /* hash_bound = ((density as FH) * (H::MAX as FH)) as H ; Rust float->int casts saturate, NaN -> 0 */
 uint64_t mqo_density_bound(double density) {
+    if (g_variant & 2) {
+        float f = (float)density * 18446744073709551615.0f;
+        if (!(f > 0.0f)) return 0;
+        if (f >= 18446744073709551616.0f) return UINT64_MAX;
+        return (uint64_t)f;
+    }
     double d = density * 18446744073709551615.0; /* u64::MAX as f64 == 2^64 */
     if (!(d > 0.0)) return 0;
     if (d >= 18446744073709551616.0) return UINT64_MAX;
@@ -159,7 +174,7 @@ size_t mqo_minimizers_naive(const uint8_t *seq, size_t len, const mqo_params *p,
     if (l >= 1 && n >= l) {
         for (size_t j = 0; j + l <= n; j++) {
             uint64_t h = mqo_ntc64(c, j, l);
-            if (h <= bound) {
+            if (keep_hash(h, bound)) {
                 if (out && cnt < cap) {
                     out[cnt].pos = pos[j];
                     out[cnt].hash = h;
@@ -206,7 +221,7 @@ static size_t minimizers_core(const uint8_t *seq, size_t len, const mqo_params *
         n++;
         if (n >= l) {
             uint64_t h = fh < rh ? fh : rh;
-            if (h <= bound) {
+            if (keep_hash(h, bound)) {
                 if (grow && cnt >= cap) {
                     cap = cap ? cap * 2 : 512;
                     out = (mqo_minimizer *)realloc(out, cap * sizeof(*out));

@@ -113,6 +113,9 @@ uint64_t mqo_nt_seed(uint8_t c);                                   /* ntHash-1 s
 uint64_t mqo_ntf64(const uint8_t *s, size_t i, size_t l);          /* forward hash of s[i..i+l) */
 uint64_t mqo_ntr64(const uint8_t *s, size_t i, size_t l);          /* reverse-complement hash */
 uint64_t mqo_ntc64(const uint8_t *s, size_t i, size_t l);          /* min(fwd, rev) */
+/* diagnostic variants of the unpinned seeding decisions (0 = the frozen reading; see mapquik_oracle.c) */
+void mqo_set_variant(int v);
+int mqo_get_variant(void);
 uint64_t mqo_density_bound(double density);                        /* (density * u64::MAX as f64) as u64 */
 uint64_t mqo_siphash(const uint8_t *msg, size_t len, uint64_t k0, uint64_t k1, int c_rounds, int d_rounds);
 uint64_t mqo_tuple_hash(const uint64_t *mers, size_t k);           /* Rust DefaultHasher over a [u64] slice */

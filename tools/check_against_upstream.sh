@@ -3,23 +3,61 @@
 # a Rust nightly toolchain (cargo), network access for the reference's crates (incl. the unpinned git dependency
 # rust-seq2kminmers, Cargo.toml:30) and an MI355X.  Not run in the authoring container (no cargo, no network).
 #
-#   tools/check_against_upstream.sh <reads.fa|fq[.gz]> <reference.fa> [extra mapquik flags...]
+#   tools/check_against_upstream.sh <reads.fa|fq[.gz]> <reference.fa> [extra mapquik flags: -k -l -d --nohpc ...]
 #
-# Builds ekimb/mapquik, maps the reads with it and with this repo's native driver using the same flags, and diffs the PAFs
-# byte for byte in input order (the reference's default seq_io path writes in input order, src/closures.rs:117-123).
-# It also records the resolved revision of rust-seq2kminmers so that a divergence can be tied to a crate version.
+# Step 1 (localises a divergence): the reference is patched to print every reference k-min-mer it indexes
+#   (src/mers.rs:29: the commented `println!("{:?}", kminmer)` becomes a tab-separated line under MQ_DUMP), the same tuples
+#   are produced by this repo's CPU oracle in its frozen reading (variant 0) and in the diagnostic variants of the unpinned
+#   decisions (D2/D3 of DESIGN.md: 1 = strict `<` on the density bound, 2 = f32 bound, 3 = both), and the first differing
+#   tuple per variant is shown: start/end wrong => D5-D7 (HPC positions); a missing/extra tuple => D2/D3 (bound) or D1
+#   (ntHash); only `rev`/hash wrong => D8/D9 (orientation, tuple hash).  With --nosimd as an extra flag the scalar HashMode of
+#   the crate is exercised instead of the SIMD one (D12).
+# Step 2: maps the reads with the reference and with this repo's native driver using the same flags and diffs the PAFs byte
+#   for byte in input order (the reference's default seq_io path writes in input order, src/closures.rs:117-123).
+# The resolved revision of rust-seq2kminmers is recorded so that a divergence can be tied to a crate version.
 set -euo pipefail
 READS=${1:?reads}; REF=${2:?reference}; shift 2
 HERE=$(cd "$(dirname "$0")/.." && pwd)
 WORK=${WORK:-$(mktemp -d)}
 command -v cargo >/dev/null || { echo "cargo not found: this script needs a Rust toolchain (rustup install nightly)"; exit 2; }
 if [ ! -d "$WORK/mapquik" ]; then git clone https://github.com/ekimb/mapquik "$WORK/mapquik"; fi
-( cd "$WORK/mapquik" && cargo +nightly build --release && grep -A2 'name = "rust-seq2kminmers"' Cargo.lock | tee "$WORK/seq2kminmers.rev" )
+( cd "$WORK/mapquik" &&
+  sed -i 's|^\(\s*\)//println!("{:?}", kminmer);|\1if std::env::var("MQ_DUMP").is_ok() { eprintln!("KMM\\t{}\\t{}\\t{}\\t{}\\t{}", kminmer.start, kminmer.end, kminmer.offset, kminmer.rev, kminmer.get_hash()); }|' src/mers.rs &&
+  cargo +nightly build --release && grep -A2 'name = "rust-seq2kminmers"' Cargo.lock | tee "$WORK/seq2kminmers.rev" )
 python3 -c "import sys; sys.path.insert(0, '$HERE'); from mapquik_amd import build; build.build_cli()"
+
+# ---- step 1: reference k-min-mer tuples (single worker thread so that the dump is in file order)
+MQ_DUMP=1 "$WORK/mapquik/target/release/mapquik" "$READS" --reference "$REF" -p "$WORK/dump" --threads 1 "$@" 2> "$WORK/upstream.kmm.raw" > /dev/null || true
+grep '^KMM' "$WORK/upstream.kmm.raw" > "$WORK/upstream.kmm" || true
+OFLAGS=()
+args=("$@"); i=0
+while [ $i -lt ${#args[@]} ]; do
+  case "${args[$i]}" in
+    -k|-l) OFLAGS+=("${args[$i]}" "${args[$((i+1))]}"); i=$((i+2));;
+    -d|--density) OFLAGS+=(-d "${args[$((i+1))]}"); i=$((i+2));;
+    --nohpc) OFLAGS+=(--nohpc); i=$((i+1));;
+    *) i=$((i+1));;
+  esac
+done
+best=""
+for v in 0 1 2 3; do
+  python3 "$HERE/tools/dump_kminmers.py" "$REF" --variant $v "${OFLAGS[@]}" > "$WORK/oracle.v$v.kmm"
+  if cmp -s "$WORK/upstream.kmm" "$WORK/oracle.v$v.kmm"; then
+    echo "k-min-mer tuples: oracle variant $v IDENTICAL to the reference ($(wc -l < "$WORK/upstream.kmm") tuples)"; best=$v
+  else
+    echo "k-min-mer tuples: oracle variant $v differs; first difference:"
+    diff "$WORK/upstream.kmm" "$WORK/oracle.v$v.kmm" | head -4 || true
+  fi
+done
+[ "$best" = "0" ] && echo "seeding stage PINNED: the frozen reading (variant 0) reproduces the crate" || echo "seeding stage NOT pinned by variant 0 (matching variant: '${best:-none}'): see DESIGN.md section 2 for which decision each field belongs to"
+
+# ---- step 2: PAF identity
 "$WORK/mapquik/target/release/mapquik" "$READS" --reference "$REF" -p "$WORK/upstream" "$@"
 "$HERE/mapquik_amd/lib/mapquik" "$READS" --reference "$REF" -p "$WORK/hip" "$@"
 if cmp -s "$WORK/upstream.paf" "$WORK/hip.paf"; then
   echo "IDENTICAL: $(wc -l < "$WORK/hip.paf") PAF lines"
 else
-  echo "DIFFERENT: see $WORK/upstream.paf vs $WORK/hip.paf"; diff "$WORK/upstream.paf" "$WORK/hip.paf" | head -20; exit 1
+  echo "DIFFERENT: see $WORK/upstream.paf vs $WORK/hip.paf"; diff "$WORK/upstream.paf" "$WORK/hip.paf" | head -20
+  python3 "$HERE/tools/paf_concordance.py" "$WORK/upstream.paf" "$WORK/hip.paf" || true
+  exit 1
 fi

@@ -39,6 +39,22 @@ with tempfile.TemporaryDirectory(dir=base) as wd:
         print("%-44s map phase %.3f s = %.2f Gbases/s   wall %.1f s  rc %d %s" % (tag, t, nb / t / 1e9, wall, r.returncode, r.stderr[-200:] if r.returncode else ""), flush=True)
 
     NP = {"MQ_DRIVER_NO_PREFETCH": "1"}
+    if os.environ.get("E2E_BIG"):  # steady state: an input several times the size of the feeder's buffer pool
+        reps = int(os.environ["E2E_BIG"])
+        big = os.path.join(wd, "big.fa")
+        with open(big, "wb") as f:
+            for rep in range(reps):
+                for i in range(n_reads):
+                    f.write(b">r%d_%d\n" % (i, rep)); reads["bases"][int(o[i]):int(o[i + 1])].tofile(f); f.write(b"\n")
+        for th in (16, 8):
+            run(big, bases * reps, ["--threads", str(th)], "FASTA x%d (%d Gbases), %d threads, no prefetch" % (reps, bases * reps // 10**9, th), NP)
+        run(big, bases * reps, ["--threads", "16"], "FASTA x%d, 16 threads, prefetch" % reps)
+        gz = os.path.join(wd, "reads_q.fa.gz")
+        with gzip.open(gz, "wb", compresslevel=1) as f:
+            for i in range(n_reads // 8):
+                f.write(b">r%d\n" % i); f.write(reads["bases"][int(o[i]):int(o[i + 1])].tobytes()); f.write(b"\n")
+        run(gz, int(o[n_reads // 8]), ["--threads", "16"], "FASTA.gz (eighth of the reads), 16 threads, no prefetch", NP)
+        os.remove(big)
     run(rd, bases, ["--threads", "16"], "FASTA 16 threads, prefetch during indexing")
     for th in (16, 8, 4, 2):
         run(rd, bases, ["--threads", str(th)], "FASTA %d threads, no prefetch" % th, NP)
