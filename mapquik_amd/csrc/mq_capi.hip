@@ -77,9 +77,10 @@ __device__ __forceinline__ bool pool_take(const SplitArgs &A, uint32_t cnt, uint
 }
 
 // seed phase, fast seeder: list length, SD_NOT_FAST (declined: non-ACGT byte, ...) or LIST_OVERFLOW; base moves with the list
+template <int STOP = 0>
 __device__ __forceinline__ uint32_t seed_read_fast(const SplitArgs &A, const SeedTables &T, SeedLds &S, const uint8_t *seq,
                                                    uint32_t len, uint64_t &base, uint32_t cap, uint32_t &n_moved) {
-    uint32_t cnt = seed_sequence_fast(seq, len, A.P, T, S, A.mz_hash + base, A.mz_pos + base, cap);
+    uint32_t cnt = seed_sequence_fast<STOP>(seq, len, A.P, T, S, A.mz_hash + base, A.mz_pos + base, cap);
     if (cnt != SD_NOT_FAST && cnt > cap) {  // denser than its region: once more, into an exact-size pool region
         if (pool_take(A, cnt, base)) {
             seed_sequence_fast(seq, len, A.P, T, S, A.mz_hash + base, A.mz_pos + base, cnt);
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
 #endif
 constexpr int SEED_WAVES = 4;
 
+template <int STOP = 0>
 __global__ __launch_bounds__(64 * SEED_WAVES, MQ_SEED_MIN_WAVES) void seed_reads_kernel(const SplitArgs A) {
     __shared__ SeedTables T;
     __shared__ SeedLds SS[SEED_WAVES];
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(64 * SEED_WAVES, MQ_SEED_MIN_WAVES) void seed_reads
         if (len >= (uint64_t)P.l + P.k - 1u) {
             uint32_t cap;
             list_region(A, o0 - o_base, len, r, base, cap);
-            cnt = A.force_general ? SD_NOT_FAST : seed_read_fast(A, T, S, A.bases + o0, (uint32_t)len, base, cap, n_moved);
+            cnt = A.force_general ? SD_NOT_FAST : seed_read_fast<STOP>(A, T, S, A.bases + o0, (uint32_t)len, base, cap, n_moved);
             if (cnt == SD_NOT_FAST) n_general++;
             else n_fast++;
         }
@@ -690,7 +692,7 @@ static int ensure_geometry(mq_index *idx) {
     int occ = 0, rc;
     if ((rc = occ_of((const void *)map_kernel<64, false>, 64 * MAP_WAVES, occ))) return rc;
     idx->grid_fused = (uint32_t)(occ * idx->n_cu);
-    if ((rc = occ_of((const void *)seed_reads_kernel, 64 * SEED_WAVES, occ))) return rc;
+    if ((rc = occ_of((const void *)seed_reads_kernel<0>, 64 * SEED_WAVES, occ))) return rc;
     idx->grid_seed = (uint32_t)(occ * idx->n_cu);
     if ((rc = occ_of((const void *)map_lists_kernel<64, false>, 64 * ML_WAVES, occ))) return rc;
     idx->grid_map = (uint32_t)(occ * idx->n_cu);
@@ -1240,7 +1242,11 @@ static int launch_map(mq_ctx *c, const uint8_t *d_bases, const uint64_t *d_offse
         HIPCHK(hipGetLastError());
     } else {
         const uint32_t gs = std::min<uint32_t>(idx->grid_seed, (n + SEED_WAVES - 1) / SEED_WAVES);
-        hipLaunchKernelGGL(seed_reads_kernel, dim3(gs), dim3(64 * SEED_WAVES), 0, st, A);
+        const char *ss = getenv("MQ_SEED_STOP");  // diagnostic: stage attribution by truncation (results are NOT valid)
+        const int stop = ss ? atoi(ss) : 0;
+        if (stop == 1) hipLaunchKernelGGL(seed_reads_kernel<1>, dim3(gs), dim3(64 * SEED_WAVES), 0, st, A);
+        else if (stop == 2) hipLaunchKernelGGL(seed_reads_kernel<2>, dim3(gs), dim3(64 * SEED_WAVES), 0, st, A);
+        else hipLaunchKernelGGL(seed_reads_kernel<0>, dim3(gs), dim3(64 * SEED_WAVES), 0, st, A);
         HIPCHK(hipGetLastError());
         // the reads the fast seeder declined: the queue length lives on the device, so the grid is fixed and waves that find
         // the queue empty leave at once

@@ -102,18 +102,28 @@ __device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int d) {
 }
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, uint32_t r) { return __builtin_rotateleft64(x, (uint64_t)(r & 63u)); }
 __device__ __forceinline__ uint64_t rotr64(uint64_t x, uint32_t r) { return __builtin_rotateright64(x, (uint64_t)(r & 63u)); }
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+// Wave reductions on the DPP network (row_shr inside each row of 16, then row_bcast:15 / row_bcast:31 across rows): VALU-rate
+// moves, where __shfl_xor would go through ds_bpermute (~24 cycles of issue each, profiles/r02_valu_issue.txt).  Lanes that
+// a shift leaves without a source read `old` = the operation's identity.  All 64 lanes must be active.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return x;
 }
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
-    return v;
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return rdlane(wave_incl_scan_u32(v), 63); }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));
+    return rdlane(x, 63);
 }
 
 // ------------------------------------------------------------------ ntHash-1 seeds (64-bit), non-ACGT -> 0

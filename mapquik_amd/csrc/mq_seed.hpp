@@ -37,6 +37,8 @@ constexpr uint32_t SD_FLAG_BLKS = 4 * ((SD_LC_MAX + 63) / 64);  // 16-step block
 constexpr uint32_t SD_CODES_DW = 4 * ((63 * SD_LC_MAX + 16 * ((SD_LC_MAX + 15) / 16) + MAX_L + 32) / 64 + 1);  // packed 2-bit codes + zero read-ahead padding (whole uint4s)
 static_assert((63 * SD_LC_MAX + 16 * ((SD_LC_MAX + 15) / 16) + MAX_L + 32) / 16 < SD_CODES_DW, "code stream read-ahead padding");
 static_assert((SD_LC_MAX + 15) / 16 <= SD_FLAG_BLKS && SD_FLAG_BLKS % 4 == 0, "flag words");
+constexpr uint32_t SD_OWNER_CAP = 256;                     // candidates listed per round of stage R (four lane-batches)
+static_assert(SD_BLOCKS <= 256, "block_of holds block numbers in a byte");
 
 // workgroup-shared look-up tables (built once per workgroup)
 struct SeedTables {
@@ -56,6 +58,8 @@ struct SeedLds {
     uint32_t carry_codes[4];                     // codes carried into the next tile (<= 63)
     uint32_t carry_pos[64];                      // their raw positions
     uint16_t lane_prefix[66];                    // exclusive prefix of the lanes' candidate counts
+    uint8_t block_of[SD_CODES_MAX / 64 + 3];     // block_of[c]: the 64-base block that holds code 64 c (the walk to a code's block starts there)
+    uint8_t owner[SD_OWNER_CAP];                 // stage R: candidate (in position order, one round of them) -> owning lane
 };
 
 // 2-bit code = (ASCII >> 1) & 3 : A=0 C=1 T=2 G=3 ; complement = code ^ 2
@@ -131,18 +135,6 @@ struct Hash2 {
     }
 };
 
-// ------------------------------------------------------------------ DPP wave scan (no LDS crossbar: ds_bpermute costs ~24 cycles)
-// inclusive prefix sum over the 64 lanes: 4 row_shr steps inside each row of 16, then row_bcast:15 / row_bcast:31
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
-    return x;
-}
-
 // ------------------------------------------------------------------ stage A
 // One tile: raw bases [raw0, raw_end), raw_end = min(raw0 + 8192, len); the code stream opens with carry_n carried codes.
 // prev_code0: the code before the first base of the sequence when raw0 == 0 (4 = none: the first base is a head).
@@ -179,6 +171,7 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
     for (uint32_t w = 0; w < SD_FLAG_BLKS / 4u; ++w) S.flags[lane * (SD_FLAG_BLKS / 4u) + w] = 0ull;  // stage B sets bits in its own blocks only
     wave_sync();
     if (lane < 4u && carry_n) S.codes[lane] = S.carry_codes[lane];  // the carried codes open the stream
+    if (lane == 0) S.block_of[0] = 0;  // codes [carry_n, 64): the walk starts at block 0 (whose range may begin after code 0)
     uint32_t b2 = 2u * carry_n;  // bits written so far = 2 * codes
     uint32_t bad = 0;
     constexpr uint32_t S1 = 0x00430041u, S0 = 0x00470054u;  // v_perm pool: selector 0,2 -> 'A','C' ; 4,6 -> 'T','G'
@@ -240,6 +233,10 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
         const uint32_t total = rdlane(incl, 63);
         uint32_t bo = b2 + incl - mine;
         S.cnt[sr * 64u + lane] = (uint16_t)(bo >> 1);
+        {  // a block holds at most 64 codes, so at most one multiple of 64 falls into its code range [c0, c1)
+            const uint32_t c0 = bo >> 1, c1 = (bo + mine) >> 1, m = (c0 + 63u) & ~63u;
+            if (m < c1) S.block_of[m >> 6] = (uint8_t)(sr * 64u + lane);
+        }
         S.heads[sr * 64u + lane] = (unsigned long long)(hb[0] | (hb[1] << 16)) | ((unsigned long long)(hb[2] | (hb[3] << 16)) << 32);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -380,11 +377,9 @@ __device__ __forceinline__ uint32_t select_bit64(unsigned long long m, uint32_t 
 }
 
 // raw position of compressed base j of the current tile
-__device__ __forceinline__ uint32_t seed_rawpos(const SeedLds &S, uint32_t n_blocks, float scale, uint32_t raw_base, uint32_t carry_n, uint32_t j) {
+__device__ __forceinline__ uint32_t seed_rawpos(const SeedLds &S, uint32_t raw_base, uint32_t carry_n, uint32_t j) {
     if (j < carry_n) return S.carry_pos[j];  // a base of the previous tile's last l-1
-    uint32_t b = (uint32_t)((float)j * scale);  // interpolate, then walk to the block with cnt[b] <= j < cnt[b+1]
-    if (b >= n_blocks) b = n_blocks - 1u;
-    while ((uint32_t)S.cnt[b] > j) --b;
+    uint32_t b = S.block_of[j >> 6];         // the block of code 64 * (j / 64); j's block is that one or one of the next few
     while ((uint32_t)S.cnt[b + 1u] <= j) ++b;
     return raw_base + b * 64u + select_bit64(S.heads[b], j - (uint32_t)S.cnt[b]);
 }
@@ -414,41 +409,48 @@ __device__ __forceinline__ uint32_t seed_stage_r(const SeedTables &T, SeedLds &S
     const uint32_t total = rdlane(incl, 63);
     S.lane_prefix[lane] = (uint16_t)(incl - my_count);
     wave_sync();
-    const float scale = (float)n_blocks / (float)(n_codes ? n_codes : 1u);
-    for (uint32_t i0 = 0; i0 < total; i0 += 64u) {
-        const uint32_t i = i0 + lane;
-        if (i < total) {
-            // owner = the largest lane L with prefix[L] <= i (its count is then > 0)
-            uint32_t L = 0;
+    const uint32_t my_prefix = incl - my_count;
+    const uint32_t max_count = wave_max_u32(my_count);
+    for (uint32_t r0 = 0; r0 < total; r0 += SD_OWNER_CAP) {  // rounds of SD_OWNER_CAP candidates (one round unless the density is high)
+        // every lane writes its number over its candidates' places: owner[] then maps a candidate to its lane without a search
+        for (uint32_t e = 0; e < max_count; ++e) {
+            const uint32_t at = my_prefix + e - r0;
+            if (e < my_count && at < SD_OWNER_CAP) S.owner[at] = (uint8_t)lane;
+        }
+        wave_sync();
+        const uint32_t r1 = total - r0 < SD_OWNER_CAP ? total : r0 + SD_OWNER_CAP;
+        for (uint32_t i0 = r0; i0 < r1; i0 += 64u) {
+            const uint32_t i = i0 + lane;
+            if (i < r1) {
+                const uint32_t L = S.owner[i - r0];
+                uint32_t e = i - (uint32_t)S.lane_prefix[L];  // rank of the step among L's candidate steps
+                const unsigned long long *lf = &S.flags[L * (SD_FLAG_BLKS / 4u)];
+                uint32_t t = 0;
+                unsigned long long word = lf[0];
 #pragma unroll
-            for (uint32_t st = 32; st >= 1; st >>= 1)
-                if ((uint32_t)S.lane_prefix[L + st] <= i) L += st;
-            uint32_t e = i - (uint32_t)S.lane_prefix[L];  // rank of the step among L's candidate steps
-            const unsigned long long *lf = &S.flags[L * (SD_FLAG_BLKS / 4u)];
-            uint32_t t = 0;
-            unsigned long long word = lf[0];
-#pragma unroll
-            for (uint32_t w = 1; w < SD_FLAG_BLKS / 4u; ++w) {
-                const uint32_t c = (uint32_t)__popcll(word);
-                if (e >= c) {
-                    e -= c;
-                    word = lf[w];
-                    t = 64u * w;
+                for (uint32_t w = 1; w < SD_FLAG_BLKS / 4u; ++w) {
+                    const uint32_t c = (uint32_t)__popcll(word);
+                    if (e >= c) {
+                        e -= c;
+                        word = lf[w];
+                        t = 64u * w;
+                    }
+                }
+                t += select_bit64(word, e);
+                const uint32_t j = L * lc + t;
+                const Hash2 wh = window_hash(T, S, P.l, j);
+                const uint64_t F = ((uint64_t)wh.fhi << 32) | wh.flo, R = ((uint64_t)wh.rhi << 32) | wh.rlo;
+                const uint64_t hv = F < R ? F : R;
+                if (hv > P.bound) inexact = true;
+                const uint32_t dest = out_base + i;
+                const uint32_t pos = seed_rawpos(S, raw_base, carry_n, j);
+                if (dest < out_cap) {
+                    mz_hash[dest] = hv;
+                    mz_pos[dest] = pos;
                 }
             }
-            t += select_bit64(word, e);
-            const uint32_t j = L * lc + t;
-            const Hash2 wh = window_hash(T, S, P.l, j);
-            const uint64_t F = ((uint64_t)wh.fhi << 32) | wh.flo, R = ((uint64_t)wh.rhi << 32) | wh.rlo;
-            const uint64_t hv = F < R ? F : R;
-            if (hv > P.bound) inexact = true;
-            const uint32_t dest = out_base + i;
-            const uint32_t pos = seed_rawpos(S, n_blocks, scale, raw_base, carry_n, j);
-            if (dest < out_cap) {
-                mz_hash[dest] = hv;
-                mz_pos[dest] = pos;
-            }
         }
+        wave_sync();
     }
     inexact = __ballot(inexact) != 0;
     return total;
@@ -456,39 +458,35 @@ __device__ __forceinline__ uint32_t seed_stage_r(const SeedTables &T, SeedLds &S
 
 // Whole sequence through the fast path, tile by tile.  Returns the number of minimizers (may exceed out_cap: overflow, the
 // list is then incomplete) or 0xFFFFFFFF when the sequence does not qualify (non-ACGT byte / inexact candidate).
-// TIMING (diagnostic builds only): tacc[0..2] += cycles spent in stages A, B, R.
+// STOP (diagnostic builds of the split pipeline only, never a product path): 1 = stage A only, 2 = stages A and B; the lists are
+// then incomplete on purpose: a profiler attributes instructions and time to the stages by difference.
 constexpr uint32_t SD_NOT_FAST = 0xFFFFFFFFu;
-template <bool TIMING = false>
+template <int STOP = 0>
 __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict__ seq, uint32_t len, const DevParams &P, const SeedTables &T,
                                                        SeedLds &S, unsigned long long *__restrict__ mz_hash,
-                                                       uint32_t *__restrict__ mz_pos, uint32_t out_cap, unsigned long long *tacc = nullptr) {
+                                                       uint32_t *__restrict__ mz_pos, uint32_t out_cap) {
     const uint32_t lane = lane_id();
     uint32_t raw0 = 0, carry_n = 0, carry_prev = 0, n_out = 0;
     while (raw0 < len) {
         uint32_t n_codes = 0, n_blocks = 0, raw_end = 0;
-        const unsigned long long t0 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
         const bool ok = seed_stage_a(seq, len, raw0, carry_n, carry_prev, P.use_hpc != 0, P.fold != 0, T, S, n_codes, n_blocks, raw_end);
-        const unsigned long long t1 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
-        if (TIMING) tacc[0] += t1 - t0;
         if (!ok) return SD_NOT_FAST;
         const bool more = raw_end < len;
-        if (n_codes >= P.l) {
+        if (STOP != 1 && n_codes >= P.l) {
             const uint32_t w_eff = n_codes - P.l + 1u;
             seed_stage_b(T, S, P, w_eff);
-            const unsigned long long t2 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
-            if (TIMING) tacc[1] += t2 - t1;
-            bool inexact = false;
-            n_out += seed_stage_r(T, S, P, w_eff, n_blocks, n_codes, raw0, carry_n, mz_hash, mz_pos, n_out, out_cap, inexact);
-            if (inexact) return SD_NOT_FAST;
-            if (TIMING) tacc[2] += __builtin_amdgcn_s_memtime() - t2;
+            if (STOP != 2) {
+                bool inexact = false;
+                n_out += seed_stage_r(T, S, P, w_eff, n_blocks, n_codes, raw0, carry_n, mz_hash, mz_pos, n_out, out_cap, inexact);
+                if (inexact) return SD_NOT_FAST;
+            }
         }
         if (more) {
             // the last l-1 compressed bases (all of them when the tile has fewer: a very long homopolymer run) open the next
             // tile's code stream; their raw positions stay available for windows that start in them
             const uint32_t new_cn = n_codes < P.l - 1u ? n_codes : P.l - 1u;
-            const float scale = (float)n_blocks / (float)(n_codes ? n_codes : 1u);
             uint32_t cpos = 0, ccode = 0;
-            if (lane < new_cn) cpos = seed_rawpos(S, n_blocks, scale, raw0, carry_n, n_codes - new_cn + lane);
+            if (lane < new_cn) cpos = seed_rawpos(S, raw0, carry_n, n_codes - new_cn + lane);
             if (lane < 4u) {
                 const uint32_t sb = 2u * (n_codes - new_cn) + 32u * lane;
                 ccode = __builtin_amdgcn_alignbit(S.codes[(sb >> 5) + 1u], S.codes[sb >> 5], sb & 31u);

@@ -16,7 +16,7 @@ for grp in \
   "WRITE_SIZE" \
   "TCC_HIT_sum TCC_MISS_sum" ; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pass$i" -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 3 --warmup 1 "$@" > "$OUT/pass$i.json" 2> "$OUT/pass$i.err"
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pass$i" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-e2e --steps 3 --warmup 1 "$@" > "$OUT/pass$i.json" 2> "$OUT/pass$i.err"
   echo "pass $i ($grp): rc=$?"
 done
 python3 - "$OUT" <<'PY'
