@@ -115,7 +115,10 @@ __device__ __forceinline__ uint32_t seed_read_general(const SplitArgs &A, WaveLd
     return cnt;
 }
 
-constexpr int ML_NB = 4;                               // lane-batches of 64 k-min-mers hashed and probed together
+#ifndef MQ_ML_NB
+#define MQ_ML_NB 7
+#endif
+constexpr int ML_NB = MQ_ML_NB;                              // lane-batches of 64 k-min-mers hashed and probed together
 constexpr uint32_t ML_LIST_CAP = 64 * ML_NB + MAX_K;   // minimizers staged in LDS at a time
 struct MapListLds {
     unsigned long long h[ML_LIST_CAP];
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(64) void seed_general_kernel(const SplitArgs A) {
 }
 
 #ifndef MQ_ML_MIN_WAVES
-#define MQ_ML_MIN_WAVES 8
+#define MQ_ML_MIN_WAVES 6
 #endif
 constexpr int ML_WAVES = 4;
 
