@@ -994,9 +994,12 @@ int64_t mq_index_finalize(mq_index *idx) {
     int rc = use_device(idx);
     if (rc) return rc;
     uint64_t nslots = 1024;
-    const char *lf = getenv("MQ_TABLE_FACTOR");  // slots per inserted k-min-mer (power-of-two rounding on top); default 4 => load <= 0.25:
-    // ~85 % of a read's lookups miss, a miss walks to the first empty slot, and every extra step is a dependent 128-B line fill
-    const uint64_t factor = lf && atoi(lf) >= 2 ? (uint64_t)atoi(lf) : 4ull;  // >= 2: a full table would make a miss walk forever
+    // slots per inserted k-min-mer (power-of-two rounding on top); default 8 => load <= 0.125 (17 GB for a human genome, 6 % of
+    // the HBM).  ~85 % of a read's lookups miss, a miss walks to the first empty slot, and every extra step is one more dependent
+    // random access of a memory system that sustains ~52 G of them per second (tools/probe_rate.py).  Measured on the CHM13-like
+    // bench: factor 2: 926, 4: 1000, 8: 1034, 16: 1044, 32: 1051 Gbases/s.
+    const char *lf = getenv("MQ_TABLE_FACTOR");
+    const uint64_t factor = lf && atoi(lf) >= 2 ? (uint64_t)atoi(lf) : 8ull;  // >= 2: a full table would make a miss walk forever
     while (nslots < factor * idx->n_kmm_total) nslots <<= 1;
     rc = alloc_table(idx, nslots);
     if (rc) return rc;
