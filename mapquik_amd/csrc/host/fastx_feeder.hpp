@@ -309,13 +309,16 @@ class Feeder {
                 // read [lo - 1, hi + tail): one byte before to know whether lo is a line start; the tail until the owning
                 // record of hi's successor is complete (grown as needed)
                 uint64_t tail = std::min<uint64_t>(1u << 20, file_size_ - hi);
+                const uint64_t from = lo ? lo - 1 : 0;
+                uint64_t got = 0;  // bytes of [from, ...) already in the buffer: a longer tail only reads what is missing
                 for (;;) {
-                    const uint64_t from = lo ? lo - 1 : 0, want = hi + tail - from;
+                    const uint64_t want = hi + tail - from;
                     if (c->cap < want) {  // a record longer than the tail: a private, larger buffer (beyond the pool limit if need be)
+                        Chunk *big = get_buffer(want, true);
+                        if (got) memcpy(big->buf, c->buf, got);
                         recycle(c);
-                        c = get_buffer(want, true);
+                        c = big;
                     }
-                    uint64_t got = 0;
                     while (got < want) {
                         const ssize_t r = pread(fd_, c->buf + got, want - got, (off_t)(from + got));
                         if (r <= 0) throw FeederError("read error: " + path_);
@@ -327,7 +330,7 @@ class Feeder {
                     uint64_t last = got;
                     if (first != NEED_MORE && hi < file_size_) last = next_record_start(c->buf, skip + (hi - lo), got, fastq_, at_eof);
                     if (first == NEED_MORE || last == NEED_MORE) {  // the record that straddles hi is longer than the tail
-                        tail = std::min<uint64_t>(tail * 4, file_size_ - hi);
+                        tail = std::min<uint64_t>(std::max<uint64_t>(tail * 4, chunk_bytes_), file_size_ - hi);
                         continue;
                     }
                     if (first >= last || first >= skip + (hi - lo)) {

@@ -221,7 +221,9 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         uint32_t cnt = 0;
         uint64_t base = 0;
         // extract(): len < l + k - 1 => None (src/mers.rs:44)
-        if (len >= (uint64_t)P.l + P.k - 1u) {
+        if (len >> 32) {
+            cnt = LIST_OVERFLOW;  // beyond the documented limit (checked on the host where the host sees the lengths): loud, not wrong
+        } else if (len >= (uint64_t)P.l + P.k - 1u) {
             uint32_t cap;
             list_region(A, o0 - o_base, len, r, base, cap);
             cnt = A.force_general ? SD_NOT_FAST : seed_read_fast(A, T, S.seed, A.bases + o0, (uint32_t)len, base, cap, n_moved);
@@ -277,7 +279,9 @@ __global__ __launch_bounds__(64 * SEED_WAVES, MQ_SEED_MIN_WAVES) void seed_reads
         const uint64_t len = A.lens ? (uint64_t)A.lens[r] : A.offsets[r + 1] - o0;
         uint32_t cnt = 0;
         uint64_t base = 0;
-        if (len >= (uint64_t)P.l + P.k - 1u) {
+        if (len >> 32) {
+            cnt = LIST_OVERFLOW;
+        } else if (len >= (uint64_t)P.l + P.k - 1u) {
             uint32_t cap;
             list_region(A, o0 - o_base, len, r, base, cap);
             cnt = A.force_general ? SD_NOT_FAST : seed_read_fast<STOP>(A, T, S, A.bases + o0, (uint32_t)len, base, cap, n_moved);
@@ -520,6 +524,7 @@ __global__ void probe_rate_kernel(const Slot *__restrict__ table, uint64_t mask,
 
 // =================================================================== host side
 
+constexpr uint32_t MQ_MAX_REF_ID = 1u << 24;
 static thread_local std::string g_err;
 static int set_err(int code, const std::string &msg) {
     g_err = msg;
@@ -805,7 +810,7 @@ static mq_ctx *ctx_create(mq_index *idx) {
 
 extern "C" {
 
-mq_index *mq_index_new(const mq_params *params, int device) {
+mq_index *mq_index_new(const mq_params *params, int device) try {
     if (!params) {
         set_err(MQ_EINVAL, "params is NULL");
         return nullptr;
@@ -859,6 +864,12 @@ mq_index *mq_index_new(const mq_params *params, int device) {
         return nullptr;
     }
     return idx;
+} catch (const std::bad_alloc &) {
+    set_err(MQ_ENOMEM, "out of host memory");
+    return nullptr;
+} catch (const std::exception &e) {
+    set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+    return nullptr;
 }
 
 void mq_index_free(mq_index *idx) {
@@ -876,7 +887,7 @@ static int64_t add_ref_device_locked(mq_index *idx, uint32_t ref_id, const char 
     if (!idx || (!d_seq && len)) return set_err(MQ_EINVAL, "bad arguments");
     if (idx->finalized) return set_err(MQ_ESTATE, "index already finalized");
     if (len >= (1ull << 32)) return set_err(MQ_EINVAL, "sequence length must be < 2^32");
-    if (ref_id >= (1u << 31)) return set_err(MQ_EINVAL, "ref_id must be < 2^31");
+    if (ref_id >= MQ_MAX_REF_ID) return set_err(MQ_EINVAL, "ref_id must be < 2^24 (reference lengths are kept in a dense device array)");
     if (idx->refs.count(ref_id)) return set_err(MQ_EINVAL, "duplicate ref_id");
     int rc = use_device(idx);
     if (rc) return rc;
@@ -962,13 +973,17 @@ static int64_t add_ref_device_locked(mq_index *idx, uint32_t ref_id, const char 
     return n_kmm;
 }
 
-int64_t mq_index_add_ref_device(mq_index *idx, uint32_t ref_id, const char *name, const uint8_t *d_seq, uint64_t len) {
+int64_t mq_index_add_ref_device(mq_index *idx, uint32_t ref_id, const char *name, const uint8_t *d_seq, uint64_t len) try {
     if (!idx) return set_err(MQ_EINVAL, "idx is NULL");
     std::lock_guard<std::mutex> lk(idx->mu);
     return add_ref_device_locked(idx, ref_id, name, d_seq, len);
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
-int64_t mq_index_add_ref(mq_index *idx, uint32_t ref_id, const char *name, const uint8_t *seq, uint64_t len) {
+int64_t mq_index_add_ref(mq_index *idx, uint32_t ref_id, const char *name, const uint8_t *seq, uint64_t len) try {
     if (!idx || (!seq && len)) return set_err(MQ_EINVAL, "bad arguments");
     std::lock_guard<std::mutex> lk(idx->mu);
     int rc = use_device(idx);
@@ -985,9 +1000,13 @@ int64_t mq_index_add_ref(mq_index *idx, uint32_t ref_id, const char *name, const
     int64_t r = add_ref_device_locked(idx, ref_id, name, d, len);
     if (d) hipFree(d);
     return r;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
-int64_t mq_index_finalize(mq_index *idx) {
+int64_t mq_index_finalize(mq_index *idx) try {
     if (!idx) return set_err(MQ_EINVAL, "idx is NULL");
     std::lock_guard<std::mutex> lk(idx->mu);
     if (idx->finalized) return (int64_t)idx->n_unique;
@@ -1032,9 +1051,13 @@ int64_t mq_index_finalize(mq_index *idx) {
     HIPCHK(hipMemcpy(idx->d_ref_lens, lens.data(), lens.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     idx->finalized = true;
     return (int64_t)idx->n_unique;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
-int mq_index_get_stats(const mq_index *idx, mq_index_stats *out) {
+int mq_index_get_stats(const mq_index *idx, mq_index_stats *out) try {
     if (!idx || !out) return set_err(MQ_EINVAL, "bad arguments");
     out->n_refs = idx->refs.size();
     out->n_kminmers = idx->n_kmm_total;
@@ -1044,13 +1067,17 @@ int mq_index_get_stats(const mq_index *idx, mq_index_stats *out) {
     out->table_bytes = (idx->nslots + 1) * sizeof(Slot);
     out->slot_bytes = sizeof(Slot);
     return MQ_OK;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
 // On-disk index (the reference has none and rebuilds on every run, src/closures.rs:24-94): header, parameters, reference
 // table, then the finalized slot table verbatim.  Little-endian, this library's layout (MQ_INDEX_MAGIC names the version).
 static const char MQ_INDEX_MAGIC[8] = {'M', 'Q', 'H', 'I', 'P', 'I', 'X', '1'};
 
-int mq_index_save(const mq_index *idx, const char *path) {
+int mq_index_save(const mq_index *idx, const char *path) try {
     if (!idx || !path) return set_err(MQ_EINVAL, "bad arguments");
     if (!idx->finalized) return set_err(MQ_ESTATE, "index not finalized");
     int rc = use_device(idx);
@@ -1077,9 +1104,13 @@ int mq_index_save(const mq_index *idx, const char *path) {
     }
     ok = (fclose(f) == 0) && ok;
     return ok ? MQ_OK : set_err(MQ_EINVAL, std::string("short write: ") + path);
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
-mq_index *mq_index_load(const char *path, int device) {
+mq_index *mq_index_load(const char *path, int device) try {
     if (!path) {
         set_err(MQ_EINVAL, "path is NULL");
         return nullptr;
@@ -1093,7 +1124,8 @@ mq_index *mq_index_load(const char *path, int device) {
     mq_params p;
     uint64_t hdr[6];
     if (fread(magic, 1, 8, f) != 8 || memcmp(magic, MQ_INDEX_MAGIC, 8) != 0 || fread(&p, sizeof(p), 1, f) != 1 ||
-        fread(hdr, sizeof(hdr), 1, f) != 1 || hdr[0] != sizeof(Slot) || hdr[1] == 0 || (hdr[1] & (hdr[1] - 1)) != 0) {
+        fread(hdr, sizeof(hdr), 1, f) != 1 || hdr[0] != sizeof(Slot) || hdr[1] == 0 || (hdr[1] & (hdr[1] - 1)) != 0 ||
+        hdr[1] > (1ull << 40) || hdr[3] >= hdr[1] /* a table without an empty slot would make a miss walk forever */ || hdr[5] > MQ_MAX_REF_ID) {
         fclose(f);
         set_err(MQ_EINVAL, std::string("not a mapquik HIP index (or another layout version): ") + path);
         return nullptr;
@@ -1107,7 +1139,7 @@ mq_index *mq_index_load(const char *path, int device) {
     for (uint64_t i = 0; ok && i < hdr[5]; ++i) {
         uint32_t id = 0, nl = 0;
         uint64_t len = 0;
-        ok = fread(&id, 4, 1, f) == 1 && fread(&nl, 4, 1, f) == 1 && fread(&len, 8, 1, f) == 1 && nl < (1u << 20);
+        ok = fread(&id, 4, 1, f) == 1 && fread(&nl, 4, 1, f) == 1 && fread(&len, 8, 1, f) == 1 && nl < (1u << 20) && id < MQ_MAX_REF_ID;
         std::string name(nl, '\0');
         ok = ok && (nl == 0 || fread(&name[0], 1, nl, f) == nl);
         if (ok) idx->refs[id] = std::make_pair(name, len);
@@ -1138,11 +1170,17 @@ mq_index *mq_index_load(const char *path, int device) {
     idx->n_unique = hdr[4];
     idx->finalized = true;
     return idx;
+} catch (const std::bad_alloc &) {
+    set_err(MQ_ENOMEM, "out of host memory");
+    return nullptr;
+} catch (const std::exception &e) {
+    set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+    return nullptr;
 }
 
 // A replica of a finalized index on another device: the table travels device to device (xGMI between the GPUs of a node)
 // instead of being rebuilt from the reference on every GPU.
-mq_index *mq_index_clone(const mq_index *src, int device) {
+mq_index *mq_index_clone(const mq_index *src, int device) try {
     if (!src) {
         set_err(MQ_EINVAL, "src is NULL");
         return nullptr;
@@ -1172,23 +1210,37 @@ mq_index *mq_index_clone(const mq_index *src, int device) {
     }
     idx->finalized = true;
     return idx;
+} catch (const std::bad_alloc &) {
+    set_err(MQ_ENOMEM, "out of host memory");
+    return nullptr;
+} catch (const std::exception &e) {
+    set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+    return nullptr;
 }
 
-int mq_index_ref_info(const mq_index *idx, uint32_t ref_id, const char **name, uint64_t *len) {
+int mq_index_ref_info(const mq_index *idx, uint32_t ref_id, const char **name, uint64_t *len) try {
     if (!idx) return set_err(MQ_EINVAL, "idx is NULL");
     auto it = idx->refs.find(ref_id);
     if (it == idx->refs.end()) return set_err(MQ_EINVAL, "unknown ref_id");
     if (name) *name = it->second.first.c_str();
     if (len) *len = it->second.second;
     return MQ_OK;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
-int mq_map_reserve(mq_index *idx, uint32_t n_reads, uint64_t total_bases) {
+int mq_map_reserve(mq_index *idx, uint32_t n_reads, uint64_t total_bases) try {
     if (!idx) return set_err(MQ_EINVAL, "idx is NULL");
     std::lock_guard<std::mutex> lk(idx->mu);
     int rc = use_device(idx);
     if (rc) return rc;
     return ctx_ensure(idx->def_ctx, n_reads, total_bases, list_f16(idx));
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
 }  // extern "C"
@@ -1409,12 +1461,18 @@ static int ctx_map_device(mq_ctx *c, const uint8_t *d_bases, const uint64_t *d_o
 
 extern "C" {
 
-mq_ctx *mq_ctx_new(mq_index *idx) {
+mq_ctx *mq_ctx_new(mq_index *idx) try {
     if (!idx) {
         set_err(MQ_EINVAL, "idx is NULL");
         return nullptr;
     }
     return ctx_create(idx);
+} catch (const std::bad_alloc &) {
+    set_err(MQ_ENOMEM, "out of host memory");
+    return nullptr;
+} catch (const std::exception &e) {
+    set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+    return nullptr;
 }
 
 void mq_ctx_free(mq_ctx *ctx) {
@@ -1423,18 +1481,26 @@ void mq_ctx_free(mq_ctx *ctx) {
     ctx_release(ctx);
 }
 
-int mq_ctx_submit(mq_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out) {
+int mq_ctx_submit(mq_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out) try {
     if (!ctx || (n && (!offsets || !out))) return set_err(MQ_EINVAL, "bad arguments");
     return ctx_submit(ctx, bases, 0, offsets, nullptr, n, out);
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
 int mq_ctx_submit_spans(mq_ctx *ctx, const uint8_t *buf, uint64_t buf_bytes, const uint64_t *starts, const uint32_t *lens, uint32_t n,
-                        mq_hit *out) {
+                        mq_hit *out) try {
     if (!ctx || (n && (!buf || !starts || !lens || !out))) return set_err(MQ_EINVAL, "bad arguments");
     return ctx_submit(ctx, buf, buf_bytes, starts, lens, n, out);
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
-int mq_ctx_reserve(mq_ctx *ctx, uint32_t n_reads, uint64_t total_bytes) {
+int mq_ctx_reserve(mq_ctx *ctx, uint32_t n_reads, uint64_t total_bytes) try {
     if (!ctx) return set_err(MQ_EINVAL, "ctx is NULL");
     mq_ctx *c = ctx;
     int rc = use_device(c->idx);
@@ -1446,43 +1512,67 @@ int mq_ctx_reserve(mq_ctx *ctx, uint32_t n_reads, uint64_t total_bytes) {
     if ((rc = grow(c->st_off, c->st_off_cap, (uint64_t)n_reads + 1))) return rc;
     if ((rc = grow(c->st_out, c->st_out_cap, (uint64_t)n_reads))) return rc;
     return grow(c->st_lens, c->st_lens_cap, (uint64_t)n_reads);
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
-int mq_ctx_wait(mq_ctx *ctx) {
+int mq_ctx_wait(mq_ctx *ctx) try {
     if (!ctx) return set_err(MQ_EINVAL, "ctx is NULL");
     return ctx_wait(ctx);
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
-int mq_ctx_map_batch(mq_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out) {
+int mq_ctx_map_batch(mq_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out) try {
     if (!ctx || (n && (!offsets || !out))) return set_err(MQ_EINVAL, "bad arguments");
     int rc = ctx_submit(ctx, bases, 0, offsets, nullptr, n, out);
     if (rc) return rc;
     return ctx_wait(ctx);
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
 int mq_ctx_map_batch_device(mq_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases,
-                            mq_hit *d_out, void *stream) {
+                            mq_hit *d_out, void *stream) try {
     if (!ctx) return set_err(MQ_EINVAL, "ctx is NULL");
     return ctx_map_device(ctx, d_bases, d_offsets, n, total_bases, d_out, (hipStream_t)stream);
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
 int mq_map_batch_device(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases,
-                        mq_hit *d_out, void *stream) {
+                        mq_hit *d_out, void *stream) try {
     if (!idx) return set_err(MQ_EINVAL, "idx is NULL");
     std::lock_guard<std::mutex> lk(idx->mu);
     return ctx_map_device(idx->def_ctx, d_bases, d_offsets, n, total_bases, d_out, (hipStream_t)stream);
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
-int mq_map_batch(mq_index *idx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out) {
+int mq_map_batch(mq_index *idx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, mq_hit *out) try {
     if (!idx || (n && (!offsets || !out))) return set_err(MQ_EINVAL, "bad arguments");
     std::lock_guard<std::mutex> lk(idx->mu);
     int rc = ctx_submit(idx->def_ctx, bases, 0, offsets, nullptr, n, out);
     if (rc) return rc;
     return ctx_wait(idx->def_ctx);
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
 int mq_kminmers_batch(mq_index *idx, const uint8_t *bases, const uint64_t *offsets, uint32_t n, const uint64_t *kmm_offsets,
-                      mq_kminmer *out, uint32_t *counts) {
+                      mq_kminmer *out, uint32_t *counts) try {
     if (!idx || (n && (!offsets || !kmm_offsets || !counts))) return set_err(MQ_EINVAL, "bad arguments");
     if (n == 0) return MQ_OK;
     std::lock_guard<std::mutex> lk(idx->mu);
@@ -1542,9 +1632,13 @@ int mq_kminmers_batch(mq_index *idx, const uint8_t *bases, const uint64_t *offse
     cleanup();
     if (e != hipSuccess) return set_err(MQ_EHIP, std::string("mq_kminmers_batch copy-out: ") + hipGetErrorString(e));
     return MQ_OK;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
-int mq_index_lookup(mq_index *idx, const uint64_t *hashes, uint32_t n, uint8_t *found, mq_kminmer *entries, uint32_t *ref_ids) {
+int mq_index_lookup(mq_index *idx, const uint64_t *hashes, uint32_t n, uint8_t *found, mq_kminmer *entries, uint32_t *ref_ids) try {
     if (!idx || (n && (!hashes || !found || !entries || !ref_ids))) return set_err(MQ_EINVAL, "bad arguments");
     if (!idx->finalized) return set_err(MQ_ESTATE, "index not finalized");
     if (n == 0) return MQ_OK;
@@ -1572,9 +1666,13 @@ int mq_index_lookup(mq_index *idx, const uint64_t *hashes, uint32_t n, uint8_t *
     hipFree(d_k); hipFree(d_f); hipFree(d_e); hipFree(d_r);
     if (e != hipSuccess) return set_err(MQ_EHIP, std::string("mq_index_lookup: ") + hipGetErrorString(e));
     return MQ_OK;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
-int mq_format_paf(const mq_index *idx, const char *q_id, uint64_t q_len, const mq_hit *hit, char *buf, size_t cap) {
+int mq_format_paf(const mq_index *idx, const char *q_id, uint64_t q_len, const mq_hit *hit, char *buf, size_t cap) try {
     if (!idx || !q_id || !hit || !buf) return set_err(MQ_EINVAL, "bad arguments");
     if (hit->status != MQ_HIT_MAPPED) return set_err(MQ_EINVAL, "hit is not mapped: the reference writes no line");
     auto it = idx->refs.find(hit->ref_id);
@@ -1585,6 +1683,10 @@ int mq_format_paf(const mq_index *idx, const char *q_id, uint64_t q_len, const m
                      hit->q_end, hit->rc ? "-" : "+", it->second.first.c_str(), r_len, hit->r_start, hit->r_end, hit->score, r_len,
                      hit->mapq);
     return w;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
 void *mq_host_alloc(size_t bytes) {
@@ -1601,7 +1703,7 @@ void mq_host_free(void *p) {
     if (p) hipHostFree(p);
 }
 
-int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general) {
+int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general) try {
     if (!idx || !n_fast || !n_general) return set_err(MQ_EINVAL, "bad arguments");
     std::lock_guard<std::mutex> lk(idx->mu);
     mq_ctx *c = idx->def_ctx;
@@ -1614,10 +1716,14 @@ int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general
     *n_fast = v[0];
     *n_general = v[1];
     return MQ_OK;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
 int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases, mq_hit *d_out,
-                       uint64_t *lookups, uint64_t *extra_steps) {
+                       uint64_t *lookups, uint64_t *extra_steps) try {
     if (!idx || !lookups || !extra_steps) return set_err(MQ_EINVAL, "bad arguments");
     std::lock_guard<std::mutex> lk(idx->mu);
     mq_ctx *c = idx->def_ctx;
@@ -1631,9 +1737,13 @@ int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_
     *extra_steps = v[0];
     *lookups = v[1];
     return MQ_OK;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
-int mq_last_map_ms(mq_index *idx, float *ms) {
+int mq_last_map_ms(mq_index *idx, float *ms) try {
     if (!idx || !ms) return set_err(MQ_EINVAL, "bad arguments");
     std::lock_guard<std::mutex> lk(idx->mu);
     mq_ctx *c = idx->def_ctx;
@@ -1641,10 +1751,14 @@ int mq_last_map_ms(mq_index *idx, float *ms) {
     HIPCHK(hipEventSynchronize(c->ev1));
     HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
     return MQ_OK;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
 int mq_probe_rate(mq_index *idx, uint32_t blocks, uint32_t per_thread, uint32_t bitmap_log2, uint32_t table_too, float *ms,
-                  uint64_t *lookups, uint64_t *extra_steps) {
+                  uint64_t *lookups, uint64_t *extra_steps) try {
     if (!idx || !ms || !lookups || !extra_steps) return set_err(MQ_EINVAL, "bad arguments");
     if (!idx->finalized) return set_err(MQ_ESTATE, "index not finalized");
     std::lock_guard<std::mutex> lk(idx->mu);
@@ -1679,14 +1793,22 @@ int mq_probe_rate(mq_index *idx, uint32_t blocks, uint32_t per_thread, uint32_t 
     *lookups = (uint64_t)blocks * 256ull * per_thread;
     *extra_steps = acc[1] / 2;  // two launches accumulated
     return MQ_OK;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
-int mq_ctx_last_map_ms(mq_ctx *ctx, float *ms) {
+int mq_ctx_last_map_ms(mq_ctx *ctx, float *ms) try {
     if (!ctx || !ms) return set_err(MQ_EINVAL, "bad arguments");
     if (!ctx->ev_valid) return set_err(MQ_ESTATE, "no map launch recorded");
     HIPCHK(hipEventSynchronize(ctx->ev1));
     HIPCHK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
     return MQ_OK;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
 }  // extern "C"
