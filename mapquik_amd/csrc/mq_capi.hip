@@ -181,7 +181,7 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
 }
 
 #ifndef MQ_MAP_WAVES
-#define MQ_MAP_WAVES 4
+#define MQ_MAP_WAVES 8
 #endif
 #ifndef MQ_MAP_MIN_WAVES
 #define MQ_MAP_MIN_WAVES 4
@@ -198,8 +198,13 @@ union MapWaveLds {
 // CH: lanes per chunk in the chain stage (64 in production; 4 only in tests so that ordinary reads take the multi-chunk path)
 template <int CH, bool TIMING = false>
 __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(const SplitArgs A) {
-    __shared__ SeedTables T;
-    __shared__ MapWaveLds SS[MAP_WAVES];
+    // one block of LDS with the tables FIRST: T.rot's entries are addressed through the 16-bit immediate offset of ds_read_b128
+    __shared__ struct {
+        SeedTables T;
+        MapWaveLds SS[MAP_WAVES];
+    } W;
+    SeedTables &T = W.T;
+    MapWaveLds(&SS)[MAP_WAVES] = W.SS;
     build_seed_tables(T, A.P.l);
     __syncthreads();  // the only workgroup-wide rendezvous; waves are independent from here on
     const uint32_t lane = lane_id();
@@ -255,12 +260,16 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
 #ifndef MQ_SEED_MIN_WAVES
 #define MQ_SEED_MIN_WAVES 4
 #endif
-constexpr int SEED_WAVES = 4;
+constexpr int SEED_WAVES = 8;
 
 template <int STOP = 0>
 __global__ __launch_bounds__(64 * SEED_WAVES, MQ_SEED_MIN_WAVES) void seed_reads_kernel(const SplitArgs A) {
-    __shared__ SeedTables T;
-    __shared__ SeedLds SS[SEED_WAVES];
+    __shared__ struct {
+        SeedTables T;
+        SeedLds SS[SEED_WAVES];
+    } W;
+    SeedTables &T = W.T;
+    SeedLds(&SS)[SEED_WAVES] = W.SS;
     build_seed_tables(T, A.P.l);
     __syncthreads();
     const uint32_t lane = lane_id();

@@ -42,7 +42,8 @@ static_assert(SD_BLOCKS <= 256, "block_of holds block numbers in a byte");
 
 // workgroup-shared look-up tables (built once per workgroup)
 struct SeedTables {
-    uint4 roll[16];      // index out | in<<2 : {rol(h(out),l)^h(in) lo,hi ; ror(hc(out),1)^rol(hc(in),l-1) lo,hi}
+    uint4 rot[32 * 16];  // index s*16 + (out | in<<2), s = 0..31 : {ror(A,s) lo,hi ; rol(B,s) lo,hi} with the roll terms
+                         //   A = rol(h(out),l)^h(in), B = ror(hc(out),1)^rol(hc(in),l-1); rotation by s+32 = the same entry, halves swapped
     uint4 warm[4];       // index code        : {h(c) lo,hi ; rol(hc(c),l-1) lo,hi}
     uint4 quad[256];     // index c0 | c1<<2 | c2<<4 | c3<<6 : four Horner steps at once, {F4 lo,hi ; R4 lo,hi} with
                          //   F4 = rol(h(c0),3)^rol(h(c1),2)^rol(h(c2),1)^h(c3),  R4 = ror(X0,3)^ror(X1,2)^ror(X2,1)^X3,  X = rol(hc(c),l-1)
@@ -81,11 +82,11 @@ __device__ __forceinline__ void build_seed_tables(SeedTables &T, uint32_t l) {
         }
         T.lut[i] = (uint16_t)(out | ((2 * n) << 8) | (hb << 12));
     }
-    if (threadIdx.x < 16) {
-        const uint32_t o = threadIdx.x & 3u, in = threadIdx.x >> 2;
-        const uint64_t f = rotl64(seed_of(o), l) ^ seed_of(in);
-        const uint64_t r = rotr64(seed_of(o ^ 2u), 1) ^ rotl64(seed_of(in ^ 2u), l - 1u);
-        T.roll[threadIdx.x] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
+    for (uint32_t i = threadIdx.x; i < 32u * 16u; i += blockDim.x) {
+        const uint32_t sft = i >> 4, o = i & 3u, in = (i >> 2) & 3u;
+        const uint64_t f = rotr64(rotl64(seed_of(o), l) ^ seed_of(in), sft);
+        const uint64_t r = rotl64(rotr64(seed_of(o ^ 2u), 1) ^ rotl64(seed_of(in ^ 2u), l - 1u), sft);
+        T.rot[i] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
     }
     if (threadIdx.x < 4) {
         const uint64_t f = seed_of(threadIdx.x);
@@ -284,6 +285,50 @@ __device__ __forceinline__ Hash2 window_hash(const SeedTables &T, const SeedLds 
     return h;
 }
 
+// One 16-step block of stage B in the ROTATING FRAME.  With F_t, R_t the two hashes of the lane's window t, the lane keeps
+//   G_t = ror(F_t, t),  H_t = rol(R_t, t):   G_{t+1} = G_t ^ ror(A_t, t+1),  H_{t+1} = H_t ^ rol(B_t, t+1)
+// (A_t, B_t = the roll terms of (out, in) at step t), so a step updates the hashes with four XORs and no rotate; the rotated
+// terms come from T.rot with the rotation in the read's immediate offset (t mod 64 is a compile-time constant: PH = block
+// number mod 4).  Only the density test needs un-rotated bits, and only the high words: one v_alignbit per strand with a
+// constant amount.  LIM_CHECK: the lane's last, partial block (steps >= lim are not taken).
+template <int PH, bool LIM_CHECK>
+__device__ __forceinline__ uint32_t stage_b_block(const SeedTables &T, uint32_t &glo, uint32_t &ghi, uint32_t &hlo, uint32_t &hhi, uint4 (&tv)[4],
+                                                  uint32_t xe, uint32_t xo, uint32_t xe_n, uint32_t xo_n, uint32_t bhi, uint32_t lim) {
+    auto nib16 = [](uint32_t xe_, uint32_t xo_, uint32_t s) { return ((((s & 1u) ? xo_ : xe_) >> (4u * (s >> 1))) & 0xFu); };
+    uint32_t fbits = 0;  // step t of the block ends up at bit 15 - t
+#pragma unroll
+    for (uint32_t t = 0; t < 16; ++t) {
+        if (!LIM_CHECK || t < lim) {
+            constexpr uint32_t dummy = 0;
+            (void)dummy;
+            const uint32_t TT = 16u * (uint32_t)PH + t;  // step number mod 64 (compile-time after unrolling)
+            // high words of F = rol(G, TT) and R = ror(H, TT)
+            const uint32_t fh = TT == 0 ? ghi : TT < 32 ? __builtin_amdgcn_alignbit(ghi, glo, 32u - TT) : TT == 32 ? glo : __builtin_amdgcn_alignbit(glo, ghi, 64u - TT);
+            const uint32_t rh = TT == 0 ? hhi : TT < 32 ? __builtin_amdgcn_alignbit(hlo, hhi, TT) : TT == 32 ? hlo : __builtin_amdgcn_alignbit(hhi, hlo, TT - 32u);
+            const uint32_t mhi = fh < rh ? fh : rh;
+            // fbits = 2 * fbits + (mhi <= bhi): v_cmp into vcc, v_addc with vcc as carry-in (high words only; the exact test runs in stage R)
+            asm("v_cmp_ge_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(fbits) : "v"(mhi), "s"(bhi) : "vcc");
+            const uint4 e = tv[t & 3u];
+            if (((TT + 1u) & 63u) < 32u) {
+                glo ^= e.x;
+                ghi ^= e.y;
+                hlo ^= e.z;
+                hhi ^= e.w;
+            } else {  // rotation by s + 32: the stored entry with its halves swapped
+                glo ^= e.y;
+                ghi ^= e.x;
+                hlo ^= e.w;
+                hhi ^= e.z;
+            }
+            // the look-up of step t + 4 (rotation (TT + 5) mod 64), in flight while the next steps run
+            const uint32_t s4 = (TT + 5u) & 31u;
+            tv[t & 3u] = (t + 4u < 16u) ? T.rot[s4 * 16u + nib16(xe, xo, t + 4u)] : T.rot[s4 * 16u + nib16(xe_n, xo_n, t + 4u - 16u)];
+        }
+    }
+    if (LIM_CHECK) fbits <<= 16u - lim;
+    return fbits;
+}
+
 // Rolls ntHash over windows [0, w_eff) of the tile's code stream; lane L owns windows [L*lc, (L+1)*lc), lc = ceil(w_eff/64).
 // The outcome of every step's high-word test goes into the lane's flag word; nothing else is kept (stage R computes a
 // candidate's hashes again).  Steps past the last window (only the last active lane has them) may set bits too: stage R
@@ -295,7 +340,8 @@ __device__ __forceinline__ void seed_stage_b(const SeedTables &T, SeedLds &S, co
     const uint32_t s0 = lane * lc;
     const uint32_t bhi = (uint32_t)(P.bound >> 32);
     if (s0 < w_eff) {  // lanes beyond the last window sit out (exec-masked)
-        Hash2 h = window_hash(T, S, l, s0);  // the lane's first window
+        const Hash2 h0 = window_hash(T, S, l, s0);  // the lane's first window: G_0 = F_0, H_0 = R_0
+        uint32_t glo = h0.flo, ghi = h0.fhi, hlo = h0.rlo, hhi = h0.rhi;
         // nibble m of xe / xo = out | in<<2 for step 2m / 2m+1 of a 16-step block
         auto mk_xe = [](uint32_t ow, uint32_t iw) { return (ow & 0x33333333u) | ((iw & 0x33333333u) << 2); };
         auto mk_xo = [](uint32_t ow, uint32_t iw) { return ((ow >> 2) & 0x33333333u) | (iw & 0xCCCCCCCCu); };
@@ -312,10 +358,10 @@ __device__ __forceinline__ void seed_stage_b(const SeedTables &T, SeedLds &S, co
             xe = mk_xe(ow, iw);
             xo = mk_xo(ow, iw);
         }
-        // ring of table values for the next four steps: their LDS reads are in flight while a step tests and rolls
+        // ring of table values for the next four steps (rotations 1..4): their LDS reads are in flight while a step tests and updates
         uint4 tv[4];
 #pragma unroll
-        for (uint32_t s = 0; s < 4; ++s) tv[s] = T.roll[nib(xe, xo, s)];
+        for (uint32_t s = 0; s < 4; ++s) tv[s] = T.rot[(s + 1u) * 16u + nib(xe, xo, s)];
         const uint32_t nb = (lc + 15u) >> 4;
         uint16_t *fl = reinterpret_cast<uint16_t *>(S.flags) + lane * SD_FLAG_BLKS;
         for (uint32_t blk = 0; blk < nb; ++blk) {
@@ -329,23 +375,21 @@ __device__ __forceinline__ void seed_stage_b(const SeedTables &T, SeedLds &S, co
                 xo_n = mk_xo(ow, iw);
             }
             const uint32_t lim = lc - 16u * blk;  // steps left (wave-uniform): the last block may be partial
-            uint32_t fbits = 0;                   // step t of the block ends up at bit 15 - t
-            auto step = [&](uint32_t t) {
-                const uint32_t mhi = h.fhi < h.rhi ? h.fhi : h.rhi;
-                // fbits = 2 * fbits + (mhi <= bhi): v_cmp into vcc, v_addc with vcc as carry-in (high words only; the exact test runs in stage R)
-                asm("v_cmp_ge_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(fbits) : "v"(mhi), "s"(bhi) : "vcc");
-                h.roll(tv[t & 3u]);
-                tv[t & 3u] = (t + 4u < 16u) ? T.roll[nib(xe, xo, t + 4u)] : T.roll[nib(xe_n, xo_n, t + 4u - 16u)];
-            };
+            uint32_t fbits;
             if (lim >= 16u) {
-#pragma unroll
-                for (uint32_t t = 0; t < 16; ++t) step(t);
-            } else {
-#pragma unroll
-                for (uint32_t t = 0; t < 16; ++t) {
-                    if (t < lim) step(t);
+                switch (blk & 3u) {
+                    case 0: fbits = stage_b_block<0, false>(T, glo, ghi, hlo, hhi, tv, xe, xo, xe_n, xo_n, bhi, 16u); break;
+                    case 1: fbits = stage_b_block<1, false>(T, glo, ghi, hlo, hhi, tv, xe, xo, xe_n, xo_n, bhi, 16u); break;
+                    case 2: fbits = stage_b_block<2, false>(T, glo, ghi, hlo, hhi, tv, xe, xo, xe_n, xo_n, bhi, 16u); break;
+                    default: fbits = stage_b_block<3, false>(T, glo, ghi, hlo, hhi, tv, xe, xo, xe_n, xo_n, bhi, 16u); break;
                 }
-                fbits <<= 16u - lim;
+            } else {
+                switch (blk & 3u) {
+                    case 0: fbits = stage_b_block<0, true>(T, glo, ghi, hlo, hhi, tv, xe, xo, xe_n, xo_n, bhi, lim); break;
+                    case 1: fbits = stage_b_block<1, true>(T, glo, ghi, hlo, hhi, tv, xe, xo, xe_n, xo_n, bhi, lim); break;
+                    case 2: fbits = stage_b_block<2, true>(T, glo, ghi, hlo, hhi, tv, xe, xo, xe_n, xo_n, bhi, lim); break;
+                    default: fbits = stage_b_block<3, true>(T, glo, ghi, hlo, hhi, tv, xe, xo, xe_n, xo_n, bhi, lim); break;
+                }
             }
             fl[blk] = (uint16_t)(__brev(fbits) >> 16);  // bit t <=> step t
             xe = xe_n;
