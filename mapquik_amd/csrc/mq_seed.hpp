@@ -1,18 +1,19 @@
 // mq_seed.hpp -- the fast seeder: an ACGT-only sequence -> its ordered minimizer list (hash, raw position) in HBM.
 //
-// One wave per sequence, tile by tile (12,288 raw bases = three super-rows of 64 bases per lane); per-wave LDS 7.5 KB, so that
-// workgroups of 4 waves (36 KB with the shared tables) run 4 to a CU.  Everything lives in LDS between the stages; nothing but
+// One wave per sequence, tile by tile (12,288 raw bases = three super-rows of 64 bases per lane); per-wave LDS 7.95 KB, so that
+// workgroups of 8 waves (78 KB with the shared tables) run 2 to a CU.  Everything lives in LDS between the stages; nothing but
 // the final list goes to HBM.  (Measured on MI355X: 2 super-rows 920, 3 super-rows 950 Gbases/s; 5 or 6 waves per SIMD at
 // 2 super-rows bought nothing, the fused kernel needs 128 VGPRs for its map phase.)
 //   stage A  decode + homopolymer compression: SWAR ASCII -> 2-bit codes (OR-merge + 4x4 transpose of 2-bit elements),
 //            validity by v_perm_b32 reconstruction, a 1024-entry LDS look-up (previous code + 4 codes -> compacted codes,
 //            count, run-head bits), one DPP prefix sum per super-row, ds_or of the packed codes into the tile's code stream.
 //            By-products kept in LDS: run-head bit mask (1 bit per raw base) and the compressed count at every 64-base block.
-//   stage B  lanes own contiguous chunks of ceil(windows / 64) compressed positions and ROLL ntHash over them:
-//            fh' = rol(fh,1) ^ rol(h(out),l) ^ h(in),  rh' = ror(rh,1) ^ ror(hc(out),1) ^ rol(hc(in),l-1)
-//            with one 16-entry LDS table indexed by (out,in) -> one ds_read_b128 per step, four look-ups in flight.
-//            The per-step test is min(fh.hi, rh.hi) <= hi(bound); its outcome is shifted into a per-lane flag word (three
-//            VALU instructions, no branch, no scalar work, nothing stored); the flag words go to LDS once per 16 steps.
+//   stage B  lanes own contiguous chunks of ceil(windows / 64) compressed positions and ROLL ntHash over them in a rotating
+//            frame (the hashes are kept un-rotated: four XORs per step with pre-rotated roll terms from an 8 KB table, the
+//            rotation sits in the ds_read_b128's immediate offset), four look-ups in flight.
+//            The per-step test is min(fh.hi, rh.hi) <= hi(bound) (one v_alignbit per strand to un-rotate the high word); its
+//            outcome is shifted into a per-lane flag word (v_cmp + v_addc: no branch, no scalar work, nothing stored); the
+//            flag words go to LDS once per 16 steps.
 //   stage R  lane = candidate, in position order: the owning lane by binary search in the lanes' count prefix, the step by
 //            bit select in that lane's flags; the window's two hashes computed again from the code stream, four bases per
 //            look-up (256-entry table); exact 64-bit test; raw position = block search in the per-block counts + select on
