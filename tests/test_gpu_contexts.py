@@ -247,3 +247,33 @@ def test_native_driver_second_pass(mq, oracle, simlib, tmp_path):
     want2, res2 = oracle_paf(dict(k=4, l=14, density=0.05), [ids[i] for i in un], [seqs[i] for i in un])
     assert open(p2 + ".paf").read() == "".join(x + "\n" for x in want2)
     assert (res2["mapped"] != 0).sum() > len(un) // 2  # the second parameter set recovers most of them
+
+
+@pytest.mark.parametrize("ps", [dict(), dict(k=3, l=12, density=0.05), dict(use_hpc=False, k=7, l=64, density=0.02)])
+def test_split_pipeline_equals_the_fused_kernel(mq, oracle, simlib, small, monkeypatch, ps):
+    """MQ_PIPELINE=split (seed_reads_kernel, seed_general_kernel, map_lists_kernel: the diagnostic form a profiler prices phase by
+    phase) must give the product kernel's bytes: same device functions.  Reads with N runs go through the queue to the general
+    seeder there; MQ_LIST_F16=1 on top forces the pool path of both seeders; k-min-mer dumps agree too."""
+    g, off, names = small
+    reads = simlib.make_reads(g, off, 300, seed=31, len_mean=15000, len_sd=8000, len_min=10)
+    bases, offs = reads["bases"].copy(), reads["offsets"]
+    for i in range(0, 300, 7):
+        a = int(offs[i]) + 3
+        if a + 5 < int(offs[i + 1]):
+            bases[a:a + 5] = ord("N")
+    ix, ox, po = _index_both(mq, oracle, small, ps)
+    want = ox.map_batch(bases, offs, po, threads=4)
+    fused = ix.map_batch(bases, offs)
+    _cmp(fused, want)
+    kf = ix.kminmers_batch(bases[:int(offs[20])], offs[:21])
+    monkeypatch.setenv("MQ_PIPELINE", "split")
+    ix2, _, _ = _index_both(mq, oracle, small, ps)
+    split = ix2.map_batch(bases, offs)
+    assert np.array_equal(split.view(np.uint8), fused.view(np.uint8))
+    n_fast, n_gen = ix2.last_map_path_counts()
+    assert n_gen >= 40 and n_fast > 200
+    ks = ix2.kminmers_batch(bases[:int(offs[20])], offs[:21])
+    assert all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(kf, ks))
+    monkeypatch.setenv("MQ_LIST_F16", "1")
+    ix3, _, _ = _index_both(mq, oracle, small, ps)
+    assert np.array_equal(ix3.map_batch(bases, offs).view(np.uint8), fused.view(np.uint8))
