@@ -6,14 +6,18 @@
 // chunk goes to the GPU as it is (headers, line ends, quality lines), reads are (start, length) spans of it, and the
 // kernels fold a-z to A-Z themselves (MQ_FLAG_FOLD_CASE).  Raw files are cut into chunks at record boundaries and read
 // with pread by N threads in parallel; compressed input is inflated by one thread straight into chunks (gzip and lz4
-// streams are sequential by nature) and parsed by the others.  Multi-line FASTA records are compacted in place.
+// streams are sequential by nature) and parsed by the others; BGZF (bgzip) files are the exception: their blocks are
+// independent deflate streams with their sizes in the headers, so the file is indexed once and then read like a raw file,
+// every reader thread inflating the blocks of its own chunk.  Multi-line FASTA records are compacted in place.
 #pragma once
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
@@ -205,7 +209,8 @@ class Feeder {
         struct stat st;
         fstat(fd_, &st);
         file_size_ = (uint64_t)st.st_size;
-        if (kind_ == 0) {
+        if (kind_ == 1 && index_bgzf()) kind_ = 3;  // logical (inflated) size from here on; chunked and read like a raw file
+        if (kind_ == 0 || kind_ == 3) {
             if (chunk_bytes_ > file_size_ + 1) chunk_bytes_ = file_size_ + 1;
             n_raw_chunks_ = (size_t)((file_size_ + chunk_bytes_ - 1) / chunk_bytes_);
         }
@@ -213,11 +218,12 @@ class Feeder {
     ~Feeder() {
         stop();
         for (auto &c : all_) release_(c->buf);
+        if (map_) munmap((void *)map_, map_size_);
         if (fd_ >= 0) close(fd_);
     }
 
     void start() {
-        if (kind_ == 0) {
+        if (kind_ == 0 || kind_ == 3) {
             for (int t = 0; t < n_threads_; ++t) threads_.emplace_back([this] { raw_worker(); });
         } else {
             threads_.emplace_back([this] { inflate_worker(); });
@@ -246,6 +252,7 @@ class Feeder {
     }
     size_t chunks_total() const { return produced_.load(); }
     uint64_t bytes_in() const { return file_size_; }
+    const char *kind_name() const { return kind_ == 0 ? "raw" : kind_ == 1 ? "gzip" : kind_ == 2 ? "lz4" : "bgzf"; }
 
   private:
     bool finished_locked() const { return done_workers_ == (int)threads_.size(); }
@@ -295,7 +302,14 @@ class Feeder {
     // raw file: chunk i owns the records whose first byte lies in [i*CH, (i+1)*CH)
     void raw_worker() {
         std::string err;
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        bool z_ok = false;
         try {
+            if (kind_ == 3) {
+                if (inflateInit2(&zs, -15) != Z_OK) throw FeederError("inflateInit2 failed");  // raw deflate: BGZF payloads
+                z_ok = true;
+            }
             for (;;) {
                 // buffer first, chunk number second: every numbered chunk then owns a buffer, so the consumer (which may hold
                 // later chunks while it waits for an earlier one) can never starve the earliest chunk of memory
@@ -319,11 +333,8 @@ class Feeder {
                         recycle(c);
                         c = big;
                     }
-                    while (got < want) {
-                        const ssize_t r = pread(fd_, c->buf + got, want - got, (off_t)(from + got));
-                        if (r <= 0) throw FeederError("read error: " + path_);
-                        got += (uint64_t)r;
-                    }
+                    fetch(c->buf + got, from + got, want - got, zs);
+                    got = want;
                     const uint64_t skip = lo ? 1 : 0;  // index of byte `lo` in the buffer
                     const bool at_eof = hi + tail >= file_size_;
                     const uint64_t first = lo ? next_record_start(c->buf, skip, got, fastq_, at_eof) : 0;
@@ -346,7 +357,88 @@ class Feeder {
                 publish(c);
             }
         } catch (const std::exception &e) { err = e.what(); }
+        if (z_ok) inflateEnd(&zs);
         worker_done(err);
+    }
+
+    // bytes [off, off + n) of the (logical) file into dst
+    void fetch(uint8_t *dst, uint64_t off, uint64_t n, z_stream &zs) {
+        if (kind_ == 0) {
+            uint64_t got = 0;
+            while (got < n) {
+                const ssize_t r = pread(fd_, dst + got, n - got, (off_t)(off + got));
+                if (r <= 0) throw FeederError("read error: " + path_);
+                got += (uint64_t)r;
+            }
+            return;
+        }
+        // BGZF: the blocks that overlap [off, off + n); a block wholly inside inflates straight into dst
+        size_t b = (size_t)(std::upper_bound(bg_uoff_.begin(), bg_uoff_.end(), off) - bg_uoff_.begin()) - 1;
+        uint8_t tmp[65536];
+        const uint64_t end = off + n;
+        for (; b + 1 < bg_uoff_.size() && bg_uoff_[b] < end; ++b) {
+            const uint64_t u0 = bg_uoff_[b], u1 = bg_uoff_[b + 1];
+            if (u1 == u0) continue;
+            const bool whole = u0 >= off && u1 <= end;
+            uint8_t *out = whole ? dst + (u0 - off) : tmp;
+            if (inflateReset(&zs) != Z_OK) throw FeederError("inflateReset failed");
+            zs.next_in = const_cast<Bytef *>(map_ + bg_coff_[b] + bg_hdr_[b]);
+            zs.avail_in = (uInt)(bg_coff_[b + 1] - bg_coff_[b] - bg_hdr_[b] - 8);
+            zs.next_out = out;
+            zs.avail_out = (uInt)(u1 - u0);
+            const int rc = inflate(&zs, Z_FINISH);
+            if (rc != Z_STREAM_END || zs.avail_out != 0) throw FeederError("BGZF block corrupt: " + path_);
+            if (!whole) {
+                const uint64_t a = std::max(u0, off), e = std::min(u1, end);
+                memcpy(dst + (a - off), tmp + (a - u0), e - a);
+            }
+        }
+    }
+
+    // BGZF (bgzip): every block is a gzip member whose extra field 'BC' holds the block size; the last four bytes of a block
+    // hold its inflated size.  Returns false (plain gzip) unless the WHOLE file parses as BGZF blocks.
+    bool index_bgzf() {
+        if (file_size_ < 28) return false;
+        const uint8_t *m = (const uint8_t *)mmap(nullptr, file_size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+        if (m == MAP_FAILED) return false;
+        std::vector<uint64_t> coff, uoff;
+        std::vector<uint16_t> hdr;
+        uint64_t p = 0, u = 0;
+        bool ok = true;
+        while (p < file_size_) {
+            if (p + 18 > file_size_ || m[p] != 0x1f || m[p + 1] != 0x8b || m[p + 2] != 8 || !(m[p + 3] & 4)) { ok = false; break; }
+            const uint32_t xlen = m[p + 10] | (m[p + 11] << 8);
+            uint32_t bsize = 0;
+            for (uint32_t q = 0; q + 4 <= xlen;) {  // subfields: SI1 SI2 SLEN(2) data
+                const uint8_t *f = m + p + 12 + q;
+                if (p + 12 + q + 4 > file_size_) break;
+                const uint32_t sl = f[2] | (f[3] << 8);
+                if (f[0] == 'B' && f[1] == 'C' && sl == 2 && p + 12 + q + 6 <= file_size_) bsize = (f[4] | (f[5] << 8)) + 1u;
+                q += 4 + sl;
+            }
+            if (!bsize || bsize < 12 + xlen + 8 || p + bsize > file_size_) { ok = false; break; }
+            const uint8_t *t = m + p + bsize - 4;
+            const uint32_t isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+            if (isize > 65536) { ok = false; break; }
+            coff.push_back(p);
+            uoff.push_back(u);
+            hdr.push_back((uint16_t)(12 + xlen));
+            p += bsize;
+            u += isize;
+        }
+        if (!ok || coff.empty()) {
+            munmap((void *)m, file_size_);
+            return false;
+        }
+        coff.push_back(p);
+        uoff.push_back(u);
+        map_ = m;
+        map_size_ = file_size_;
+        bg_coff_.swap(coff);
+        bg_uoff_.swap(uoff);
+        bg_hdr_.swap(hdr);
+        file_size_ = u;  // the logical file
+        return true;
     }
 
     // compressed input: one thread inflates into chunks cut at record boundaries; parse_worker threads parse them
@@ -480,7 +572,11 @@ class Feeder {
     int n_threads_, max_chunks_;
     std::function<void *(size_t)> alloc_;
     std::function<void(void *)> release_;
-    int kind_ = 0;  // 0 raw, 1 gzip, 2 lz4
+    int kind_ = 0;  // 0 raw, 1 gzip, 2 lz4, 3 BGZF (indexed, read like raw)
+    const uint8_t *map_ = nullptr;  // BGZF: the compressed file, mapped
+    uint64_t map_size_ = 0;
+    std::vector<uint64_t> bg_coff_, bg_uoff_;  // per block (+ end): compressed / inflated offsets
+    std::vector<uint16_t> bg_hdr_;             // per block: header bytes before the deflate data
     int fd_ = -1;
     uint64_t file_size_ = 0;
     size_t n_raw_chunks_ = 0;

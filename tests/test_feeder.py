@@ -91,3 +91,40 @@ def test_feeder_long_record_spanning_many_chunks(tool, tmp_path):
     got = _dump(tool, p, False, 100_000, 4)
     assert [(g[0], int(g[1])) for g in got] == [("c%d" % i, len(s)) for i, s in enumerate(seqs)]
     assert got[1][2] == seqs[1]
+
+
+def _bgzf(data, block=3000):
+    """BGZF (bgzip) writer: independent deflate blocks, block size in the gzip extra field 'BC', then the empty EOF block."""
+    import struct
+    import zlib
+    out = bytearray()
+    for i in list(range(0, len(data), block)) + [None]:
+        piece = b"" if i is None else data[i:i + block]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        d = c.compress(piece) + c.flush()
+        bsize = 18 + len(d) + 8
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize - 1) + d
+        out += struct.pack("<II", zlib.crc32(piece) & 0xFFFFFFFF, len(piece))
+    return bytes(out)
+
+
+@pytest.mark.parametrize("fastq", [False, True])
+def test_feeder_inflates_bgzf_blocks_in_parallel(tool, tmp_path, fastq):
+    """A bgzip'ed file is indexed by its block headers and read like a raw file: every reader thread inflates the blocks of
+    its own chunk (plain gzip streams stay on the single inflate thread).  Blocks of 3,000 bytes so that records, chunk
+    boundaries and block boundaries fall everywhere relative to each other."""
+    recs, text = _make(250, fastq, not fastq, False, random.Random(21 + fastq))
+    want = [[a, str(len(b)), b] for a, b in recs]
+    p = tmp_path / ("r.fq.gz" if fastq else "r.fa.gz")
+    p.write_bytes(_bgzf(text.encode()))
+    import gzip as _g
+    assert _g.decompress(p.read_bytes()).decode() == text  # a valid multi-member gzip file, too
+    for chunk, th in ((64, 4), (2500, 3), (40000, 4), (1 << 28, 2)):
+        assert _dump(tool, p, fastq, chunk, th) == want, (chunk, th)
+    import os
+    r = subprocess.run([tool, str(p), "fastq" if fastq else "fasta", "5000", "2"], capture_output=True, text=True, env=dict(os.environ, FEEDER_DUMP_KIND="1"))
+    assert "kind=bgzf" in r.stderr
+    plain = tmp_path / "plain.fx.gz"
+    plain.write_bytes(_g.compress(text.encode()))
+    r = subprocess.run([tool, str(plain), "fastq" if fastq else "fasta", "5000", "2"], capture_output=True, text=True, env=dict(os.environ, FEEDER_DUMP_KIND="1"))
+    assert "kind=gzip" in r.stderr and r.returncode == 0

@@ -39,6 +39,29 @@ with tempfile.TemporaryDirectory(dir=base) as wd:
         print("%-44s map phase %.3f s = %.2f Gbases/s   wall %.1f s  rc %d %s" % (tag, t, nb / t / 1e9, wall, r.returncode, r.stderr[-200:] if r.returncode else ""), flush=True)
 
     NP = {"MQ_DRIVER_NO_PREFETCH": "1"}
+    if os.environ.get("E2E_BGZF"):  # a bgzip'ed FASTA of a quarter of the reads: blocks inflated in parallel by the reader threads
+        import struct, zlib
+        from concurrent.futures import ThreadPoolExecutor
+        nq = n_reads // 4
+        raw = b"".join(b">r%d\n" % i + reads["bases"][int(o[i]):int(o[i + 1])].tobytes() + b"\n" for i in range(nq))
+
+        def blk(piece):
+            c = zlib.compressobj(1, zlib.DEFLATED, -15)
+            d = c.compress(piece) + c.flush()
+            return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", 18 + len(d) + 8 - 1) + d +
+                    struct.pack("<II", zlib.crc32(piece) & 0xFFFFFFFF, len(piece)))
+        pieces = [raw[i:i + 65280] for i in range(0, len(raw), 65280)] + [b""]
+        with ThreadPoolExecutor(16) as ex:
+            blocks = list(ex.map(blk, pieces))
+        bz = os.path.join(wd, "reads_q.fa.gz")
+        with open(bz, "wb") as f:
+            for b_ in blocks:
+                f.write(b_)
+        print("bgzf file: %.2f GB compressed, %.2f GB inflated" % (os.path.getsize(bz) / 1e9, len(raw) / 1e9), flush=True)
+        for th in (16, 8, 4):
+            run(bz, int(o[nq]), ["--threads", str(th)], "FASTA bgzf (quarter of the reads), %d threads, no prefetch" % th, NP)
+        run(bz, int(o[nq]), ["--threads", "16"], "FASTA bgzf (quarter of the reads), 16 threads, prefetch")
+        sys.exit(0)
     if os.environ.get("E2E_BIG"):  # steady state: an input several times the size of the feeder's buffer pool
         reps = int(os.environ["E2E_BIG"])
         big = os.path.join(wd, "big.fa")
