@@ -593,7 +593,7 @@ struct mq_ctx {
 
 struct KmmChunk {
     RefKmm *d = nullptr;
-    uint64_t n = 0;
+    uint64_t n = 0, cap = 0;  // k-min-mers of several references share a chunk (assemblies with 10^5 small contigs)
 };
 
 struct mq_index {
@@ -610,6 +610,15 @@ struct mq_index {
     uint64_t nslots = 0;
     uint64_t *d_ref_lens = nullptr;
     uint64_t n_unique = 0, n_keys = 0;
+    // grow-only scratch of mq_index_add_ref (freed by finalize): no allocation per reference once it has grown
+    uint8_t *bld_seq = nullptr;
+    uint64_t bld_seq_cap = 0;
+    Minimizer *bld_seg_lists = nullptr, *bld_dense = nullptr;
+    uint64_t bld_seg_lists_cap = 0, bld_dense_cap = 0;
+    uint32_t *bld_counts = nullptr;
+    uint64_t bld_counts_cap = 0;
+    uint64_t *bld_seg_off = nullptr;
+    uint64_t bld_seg_off_cap = 0;
     // launch geometry (workgroups) and scratch sizes, fixed at the first map call
     uint32_t grid_fused = 0, grid_seed = 0, grid_map = 0;  // map_kernel; seed_reads_kernel, map_lists_kernel (split)
     uint32_t cap_matches = 0;
@@ -817,6 +826,19 @@ static mq_ctx *ctx_create(mq_index *idx) {
     return c;
 }
 
+static void free_build_scratch(mq_index *idx) {
+    hipFree(idx->bld_seq);
+    hipFree(idx->bld_seg_lists);
+    hipFree(idx->bld_dense);
+    hipFree(idx->bld_counts);
+    hipFree(idx->bld_seg_off);
+    idx->bld_seq = nullptr;
+    idx->bld_seg_lists = idx->bld_dense = nullptr;
+    idx->bld_counts = nullptr;
+    idx->bld_seg_off = nullptr;
+    idx->bld_seq_cap = idx->bld_seg_lists_cap = idx->bld_dense_cap = idx->bld_counts_cap = idx->bld_seg_off_cap = 0;
+}
+
 extern "C" {
 
 mq_index *mq_index_new(const mq_params *params, int device) try {
@@ -886,6 +908,7 @@ void mq_index_free(mq_index *idx) {
     hipSetDevice(idx->device);
     for (auto &c : idx->chunks)
         if (c.d) hipFree(c.d);
+    free_build_scratch(idx);
     if (idx->table) hipFree(idx->table);
     if (idx->d_ref_lens) hipFree(idx->d_ref_lens);
     ctx_release(idx->def_ctx);
@@ -911,43 +934,19 @@ static int64_t add_ref_device_locked(mq_index *idx, uint32_t ref_id, const char 
     if (!(dens > 0)) dens = 0;
     if (dens > 1) dens = 1;
     uint32_t cap = (uint32_t)std::min<double>((double)seg_len, 3.0 * 2.0 * dens * (double)seg_len + 1024.0);
-    Minimizer *seg_lists = nullptr, *dense = nullptr;
-    uint32_t *d_counts = nullptr;
-    uint64_t *d_seg_off = nullptr;
     std::vector<uint32_t> counts(n_seg);
     std::vector<uint64_t> seg_off(n_seg + 1);
-    auto cleanup = [&]() {
-        if (seg_lists) hipFree(seg_lists);
-        if (dense) hipFree(dense);
-        if (d_counts) hipFree(d_counts);
-        if (d_seg_off) hipFree(d_seg_off);
-    };
-#define HIPCHK_C(expr)                                                                                       \
-    do {                                                                                                     \
-        hipError_t _e = (expr);                                                                              \
-        if (_e != hipSuccess) {                                                                              \
-            cleanup();                                                                                       \
-            char _b[512];                                                                                    \
-            snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
-            return set_err(_e == hipErrorOutOfMemory ? MQ_ENOMEM : MQ_EHIP, _b);                             \
-        }                                                                                                    \
-    } while (0)
-    HIPCHK_C(hipMalloc((void **)&d_counts, (size_t)n_seg * sizeof(uint32_t)));
+    if ((rc = grow(idx->bld_counts, idx->bld_counts_cap, n_seg))) return rc;
     const uint32_t grid = std::min<uint32_t>(n_seg, (uint32_t)idx->n_cu * 32u);
     for (int attempt = 0; attempt < 2; ++attempt) {
-        HIPCHK_C(hipMalloc((void **)&seg_lists, (size_t)n_seg * cap * sizeof(Minimizer)));
-        hipLaunchKernelGGL(seed_segments_kernel, dim3(grid), dim3(64), 0, 0, d_seq, len, seg_len, n_seg, P, seg_lists, cap, d_counts);
-        HIPCHK_C(hipGetLastError());
-        HIPCHK_C(hipMemcpy(counts.data(), d_counts, (size_t)n_seg * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if ((rc = grow(idx->bld_seg_lists, idx->bld_seg_lists_cap, (uint64_t)n_seg * cap))) return rc;
+        hipLaunchKernelGGL(seed_segments_kernel, dim3(grid), dim3(64), 0, 0, d_seq, len, seg_len, n_seg, P, idx->bld_seg_lists, cap, idx->bld_counts);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(counts.data(), idx->bld_counts, (size_t)n_seg * sizeof(uint32_t), hipMemcpyDeviceToHost));
         bool overflow = false;
         for (uint32_t s = 0; s < n_seg; ++s) overflow |= counts[s] > cap;
         if (!overflow) break;
-        if (attempt == 1) {
-            cleanup();
-            return set_err(MQ_EOVERFLOW, "minimizer list overflow at worst-case capacity (internal error)");
-        }
-        HIPCHK_C(hipFree(seg_lists));
-        seg_lists = nullptr;
+        if (attempt == 1) return set_err(MQ_EOVERFLOW, "minimizer list overflow at worst-case capacity (internal error)");
         cap = (uint32_t)seg_len;  // a segment cannot hold more run heads than bases
     }
     seg_off[0] = 0;
@@ -956,30 +955,27 @@ static int64_t add_ref_device_locked(mq_index *idx, uint32_t ref_id, const char 
     int64_t n_kmm = 0;
     if (n_mz >= P.k) {
         n_kmm = (int64_t)(n_mz - P.k + 1);
-        HIPCHK_C(hipMalloc((void **)&d_seg_off, (size_t)(n_seg + 1) * sizeof(uint64_t)));
-        HIPCHK_C(hipMemcpy(d_seg_off, seg_off.data(), (size_t)(n_seg + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-        HIPCHK_C(hipMalloc((void **)&dense, (size_t)n_mz * sizeof(Minimizer)));
-        hipLaunchKernelGGL(compact_minimizers_kernel, dim3(std::min<uint32_t>(n_seg, 65535u)), dim3(64), 0, 0, seg_lists, cap, d_counts,
-                           d_seg_off, n_seg, dense);
-        HIPCHK_C(hipGetLastError());
-        KmmChunk ch;
-        ch.n = (uint64_t)n_kmm;
-        HIPCHK_C(hipMalloc((void **)&ch.d, (size_t)n_kmm * sizeof(RefKmm)));
-        const uint32_t kb = (uint32_t)std::min<uint64_t>(((uint64_t)n_kmm + 255) / 256, 65535ull);
-        hipLaunchKernelGGL(ref_kminmers_kernel, dim3(kb), dim3(256), 0, 0, dense, n_mz, P, ref_id, ch.d);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-        if (e != hipSuccess) {
-            hipFree(ch.d);
-            cleanup();
-            return set_err(MQ_EHIP, std::string("ref_kminmers_kernel: ") + hipGetErrorString(e));
+        if ((rc = grow(idx->bld_seg_off, idx->bld_seg_off_cap, (uint64_t)n_seg + 1))) return rc;
+        if ((rc = grow(idx->bld_dense, idx->bld_dense_cap, n_mz))) return rc;
+        HIPCHK(hipMemcpy(idx->bld_seg_off, seg_off.data(), (size_t)(n_seg + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(compact_minimizers_kernel, dim3(std::min<uint32_t>(n_seg, 65535u)), dim3(64), 0, 0, idx->bld_seg_lists, cap,
+                           idx->bld_counts, idx->bld_seg_off, n_seg, idx->bld_dense);
+        HIPCHK(hipGetLastError());
+        // the reference's k-min-mers go behind those of the previous references in the current chunk while it has room
+        if (idx->chunks.empty() || idx->chunks.back().n + (uint64_t)n_kmm > idx->chunks.back().cap) {
+            KmmChunk ch;
+            ch.cap = std::max<uint64_t>((uint64_t)n_kmm, 4ull << 20);
+            HIPCHK(hipMalloc((void **)&ch.d, (size_t)ch.cap * sizeof(RefKmm)));
+            idx->chunks.push_back(ch);
         }
-        idx->chunks.push_back(ch);
+        KmmChunk &ch = idx->chunks.back();
+        const uint32_t kb = (uint32_t)std::min<uint64_t>(((uint64_t)n_kmm + 255) / 256, 65535ull);
+        hipLaunchKernelGGL(ref_kminmers_kernel, dim3(kb), dim3(256), 0, 0, idx->bld_dense, n_mz, P, ref_id, ch.d + ch.n);
+        HIPCHK(hipGetLastError());
+        ch.n += (uint64_t)n_kmm;
         idx->n_kmm_total += (uint64_t)n_kmm;
     }
-    cleanup();
-#undef HIPCHK_C
-    return n_kmm;
+    return n_kmm;  // everything above runs on the null stream: the next call's kernels (and finalize) are ordered behind it
 }
 
 int64_t mq_index_add_ref_device(mq_index *idx, uint32_t ref_id, const char *name, const uint8_t *d_seq, uint64_t len) try {
@@ -997,18 +993,10 @@ int64_t mq_index_add_ref(mq_index *idx, uint32_t ref_id, const char *name, const
     std::lock_guard<std::mutex> lk(idx->mu);
     int rc = use_device(idx);
     if (rc) return rc;
-    uint8_t *d = nullptr;
-    if (len) {
-        HIPCHK(hipMalloc((void **)&d, len));
-        hipError_t e = hipMemcpy(d, seq, len, hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            hipFree(d);
-            return set_err(MQ_EHIP, std::string("hipMemcpy H2D: ") + hipGetErrorString(e));
-        }
-    }
-    int64_t r = add_ref_device_locked(idx, ref_id, name, d, len);
-    if (d) hipFree(d);
-    return r;
+    if (len >= (1ull << 32)) return set_err(MQ_EINVAL, "sequence length must be < 2^32");
+    if ((rc = grow(idx->bld_seq, idx->bld_seq_cap, len + 64))) return rc;
+    if (len) HIPCHK(hipMemcpy(idx->bld_seq, seq, len, hipMemcpyHostToDevice));
+    return add_ref_device_locked(idx, ref_id, name, idx->bld_seq, len);
 } catch (const std::bad_alloc &) {
     return set_err(MQ_ENOMEM, "out of host memory");
 } catch (const std::exception &e) {
@@ -1051,6 +1039,7 @@ int64_t mq_index_finalize(mq_index *idx) try {
     for (auto &c : idx->chunks)
         if (c.d) hipFree(c.d);
     idx->chunks.clear();
+    free_build_scratch(idx);
     // ref_map lengths (src/closures.rs:49), dense by ref id
     uint32_t max_id = 0;
     for (auto &kv : idx->refs) max_id = std::max(max_id, kv.first);
