@@ -551,7 +551,7 @@ static int set_err(int code, const std::string &msg) {
 
 struct mq_index;
 
-// One stream slot: everything a map launch sequence writes (work counters, Match scratch, minimizer lists, seeder spill,
+// One stream slot: everything a map launch sequence writes (work counters, Match scratch, minimizer lists,
 // events) plus the staging buffers of the host-buffer entry points.  Launch sequences of DIFFERENT contexts of one index
 // may be in flight together (the index itself is read-only once finalized); one context runs one sequence at a time.
 struct mq_ctx {
