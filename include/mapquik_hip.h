@@ -143,7 +143,7 @@ int mq_map_batch_device(mq_index *idx, const uint8_t *d_bases, const uint64_t *d
  * stream slot of a pipelined feeder) its own mq_ctx: a context owns a stream, work counters, Match scratch, minimizer
  * lists, staging buffers and events, and the finalized table is only read.  One context runs one launch sequence at a time
  * (calls on one context must not overlap; successive device-form calls must be ordered by their streams).
- * mq_index_add_ref / mq_index_finalize must have returned before any context maps. */
+ * mq_index_add_ref / mq_index_finalize must have returned before any context maps; free every context before its index. */
 typedef struct mq_ctx mq_ctx;
 mq_ctx *mq_ctx_new(mq_index *idx);
 void mq_ctx_free(mq_ctx *ctx);

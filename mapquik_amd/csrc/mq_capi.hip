@@ -601,6 +601,8 @@ struct mq_index {
     DevParams dp;
     int device = 0;
     int n_cu = 0;
+    std::once_flag geometry_once;  // launch geometry is worked out once, by whichever context or entry point maps first
+    int geometry_rc = MQ_OK;
     std::mutex mu;  // serialises the index-level entry points (add_ref, finalize, and everything that uses the default context)
     std::map<uint32_t, std::pair<std::string, uint64_t>> refs;
     std::vector<KmmChunk> chunks;
@@ -705,8 +707,7 @@ static int grow_pinned(T *&p, uint64_t &cap, uint64_t need) {
 }
 
 // launch geometry: persistent waves, as many workgroups as stay resident
-static int ensure_geometry(mq_index *idx) {
-    if (idx->grid_seed) return MQ_OK;
+static int ensure_geometry_once(mq_index *idx) {
     auto occ_of = [&](const void *fn, int threads, int &occ) -> int {
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, threads, 0));
         if (occ < 1) occ = 1;
@@ -727,6 +728,11 @@ static int ensure_geometry(mq_index *idx) {
     idx->cap_matches = e ? (uint32_t)strtoul(e, nullptr, 10) : 2048u;
     if (idx->cap_matches < 1) idx->cap_matches = 1;
     return MQ_OK;
+}
+
+static int ensure_geometry(mq_index *idx) {
+    std::call_once(idx->geometry_once, [idx] { idx->geometry_rc = ensure_geometry_once(idx); });  // contexts of one index start concurrently
+    return idx->geometry_rc;
 }
 
 // list entries reserved per base, in 1/65536: 4 d + 1/512 -- canonical selection keeps 1-(1-d)^2 ~ 2 d of the l-mers, so this
