@@ -438,8 +438,8 @@ def test_native_cli_end_to_end_paf_identical(mq, oracle, simlib, tmp_path):
 
 def test_fuzz_params_and_sequences(mq, oracle, simlib):
     """Random (k, l, density, hpc, c, s, g) x random genomes/reads incl. N runs, lowercase, low-complexity stretches."""
-    rng = np.random.default_rng(20240)
-    for it in range(24):
+    rng = np.random.default_rng(int(os.environ.get("MQ_FUZZ_SEED", "20240")))  # MQ_FUZZ_ITERS / MQ_FUZZ_SEED: longer one-off campaigns
+    for it in range(int(os.environ.get("MQ_FUZZ_ITERS", "24"))):
         k = int(rng.integers(1, 13))
         l = int(rng.choice([1, 2, 5, 8, 12, 15, 16, 17, 24, 31, 32, 33, 47, 63, 64]))
         dens = float(rng.choice([0.002, 0.01, 0.03, 0.1, 0.3]))
