@@ -24,7 +24,7 @@ EXPORTS = ["mq_last_error", "mq_abi_version", "mq_device_count", "mq_params_defa
            "mq_index_add_ref", "mq_index_add_ref_device", "mq_index_finalize", "mq_index_get_stats", "mq_index_ref_info",
            "mq_map_batch", "mq_map_batch_device", "mq_map_reserve", "mq_kminmers_batch", "mq_index_lookup", "mq_format_paf",
            "mq_last_map_ms", "mq_last_map_path_counts", "mq_host_alloc", "mq_host_free", "mq_index_save", "mq_index_load", "mq_index_clone", "mq_map_probe_stats",
-           "mq_ctx_new", "mq_ctx_free", "mq_ctx_map_batch", "mq_ctx_submit", "mq_ctx_submit_spans", "mq_ctx_wait", "mq_ctx_reserve", "mq_ctx_map_batch_device", "mq_ctx_last_map_ms", "mq_probe_rate"]
+           "mq_ctx_new", "mq_ctx_free", "mq_ctx_map_batch", "mq_ctx_submit", "mq_ctx_submit_spans", "mq_ctx_wait", "mq_ctx_reserve", "mq_ctx_map_batch_device", "mq_ctx_last_map_ms", "mq_probe_rate", "mq_last_stage_clocks"]
 
 
 class MapquikError(RuntimeError):
@@ -98,6 +98,7 @@ def load_library(path=None):
     L.mq_index_lookup.argtypes = [vp, vp, u32, vp, vp, vp]
     L.mq_format_paf.argtypes = [vp, C.c_char_p, u64, vp, C.c_char_p, C.c_size_t]
     L.mq_last_map_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.mq_last_stage_clocks.argtypes = [vp, vp]
     L.mq_map_probe_stats.argtypes = [vp, vp, vp, u32, u64, vp, C.POINTER(u64), C.POINTER(u64)]
     L.mq_index_save.argtypes = [vp, C.c_char_p]
     L.mq_index_clone.restype = vp
@@ -257,6 +258,13 @@ class Index:
         if self._L.mq_last_map_ms(self._h, C.byref(ms)) != 0:
             raise _err(self._L, "mq_last_map_ms")
         return ms.value
+
+    def last_stage_clocks(self):
+        """Diagnostic (-DMQ_STAGE_CLOCKS builds): cycles per stage of the last launch, summed over waves (12 stages)."""
+        out = (C.c_uint64 * 12)()
+        if self._L.mq_last_stage_clocks(self._h, out) != 0:
+            raise _err(self._L, "mq_last_stage_clocks")
+        return [int(x) for x in out]
 
     def probe_stats(self, d_bases, d_offsets, n, total_bases, d_out):
         """(index lookups, slots visited beyond the home slot) of one instrumented launch: p-bar = 1 + extra / lookups."""

@@ -155,6 +155,7 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
                 S.p[i] = ld_sc1_u32(lp + g + i);
             }
             wave_sync();
+            mq_clk(5);
             sink.template consume_list<ML_NB>(S.h, S.p, have);
             wave_sync();
             g += have - (P.k - 1u);
@@ -166,6 +167,7 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
         } else if (sink.n_matches > 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Match records written by this wave are in L2
             wave_sync();
+            mq_clk(8);
             chain_stage<CH>(scratch, sink.n_matches, P, len, A.ref_lens, h);
         }
         if (TIMING) {
@@ -178,6 +180,7 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
         A.out[r] = h;
         if (A.dump_counts) A.dump_counts[r] = n_kmm;
     }
+    mq_clk(9);
 }
 
 #ifndef MQ_MAP_WAVES
@@ -216,6 +219,11 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
     const uint64_t o_base = A.offsets[0];
     uint32_t n_fast = 0, n_general = 0, n_moved = 0;
     unsigned long long t_steps = 0, t_lookups = 0;
+#ifdef MQ_STAGE_CLOCKS
+    if (lane == 0)
+        for (int i = 0; i < MQ_N_CLK; ++i) mq_clk_lds().acc[wv][i] = 0;
+    mq_clk(-1);
+#endif
     for (;;) {
         uint32_t r = 0;
         if (lane == 0) r = atomicAdd(&A.counters[0], 1u);
@@ -225,6 +233,7 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         const uint64_t len = A.lens ? (uint64_t)A.lens[r] : A.offsets[r + 1] - o0;
         uint32_t cnt = 0;
         uint64_t base = 0;
+        mq_clk(11);
         // extract(): len < l + k - 1 => None (src/mers.rs:44)
         if (len >> 32) {
             cnt = LIST_OVERFLOW;  // beyond the documented limit (checked on the host where the host sees the lengths): loud, not wrong
@@ -236,11 +245,13 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
                 n_general++;
                 wave_sync();
                 cnt = seed_read_general(A, S.general, A.bases + o0, len, base, cap, n_moved);
+                mq_clk(10);
             } else {
                 n_fast++;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have reached L2
             wave_sync();
+            mq_clk(4);
         }
         map_read<CH, TIMING>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups);
         wave_sync();
@@ -253,6 +264,9 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
             atomicAdd(&A.stats64[0], t_steps);
             atomicAdd(&A.stats64[1], t_lookups);
         }
+#ifdef MQ_STAGE_CLOCKS
+        for (int i = 0; i < MQ_N_CLK; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(A.counters + 16) + i, mq_clk_lds().acc[wv][i]);
+#endif
     }
 }
 
@@ -260,7 +274,10 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
 #ifndef MQ_SEED_MIN_WAVES
 #define MQ_SEED_MIN_WAVES 4
 #endif
-constexpr int SEED_WAVES = 8;
+#ifndef MQ_SEED_WAVES
+#define MQ_SEED_WAVES 8
+#endif
+constexpr int SEED_WAVES = MQ_SEED_WAVES;
 
 template <int STOP = 0>
 __global__ __launch_bounds__(64 * SEED_WAVES, MQ_SEED_MIN_WAVES) void seed_reads_kernel(const SplitArgs A) {
@@ -1740,6 +1757,24 @@ int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_
     HIPCHK(hipMemcpy(v, c->d_counter + 8, 16, hipMemcpyDeviceToHost));
     *extra_steps = v[0];
     *lookups = v[1];
+    return MQ_OK;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+}
+
+// Diagnostic (-DMQ_STAGE_CLOCKS builds; zeros otherwise): shader-clock cycles the waves of the last map_kernel launch of the default
+// context spent per stage, summed over waves (stage list: mq_device.hpp, mq_clk).
+int mq_last_stage_clocks(mq_index *idx, uint64_t *out12) try {
+    if (!idx || !out12) return set_err(MQ_EINVAL, "bad arguments");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    mq_ctx *c = idx->def_ctx;
+    if (!c->ev_valid) return set_err(MQ_ESTATE, "no map launch recorded");
+    int rc = use_device(idx);
+    if (rc) return rc;
+    HIPCHK(hipEventSynchronize(c->ev1));
+    HIPCHK(hipMemcpy(out12, c->d_counter + 16, MQ_N_CLK * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return MQ_OK;
 } catch (const std::bad_alloc &) {
     return set_err(MQ_ENOMEM, "out of host memory");

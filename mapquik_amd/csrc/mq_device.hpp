@@ -81,7 +81,39 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// The empty asm makes every call site compute its own copy: with a pure lane id the compiler hoists every lane-dependent address
+// and mask of EVERY phase out of the persistent per-read loop and keeps them all live (161 VGPRs for the fused kernel, 112 with this).
+__device__ __forceinline__ uint32_t lane_id() {
+    uint32_t x = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(x));
+    return x;
+}
+// Diagnostic builds only (-DMQ_STAGE_CLOCKS): wave time per stage.  mq_clk(i) charges the cycles since the wave's previous stamp
+// to stage i; map_kernel adds every wave's totals to counters[16..] at its end (read back by mq_last_stage_clocks).
+//   0 stage A  1 stage B  2 stage R  3 tile carry  4 list stores acknowledged  5 list -> LDS  6 tuple hashes + probe issue
+//   7 probe resolve + runs  8 runs finished, Match records in L2  9 chain + result  10 general seeder  11 next read (atomic, offsets)
+constexpr int MQ_N_CLK = 12;
+#ifdef MQ_STAGE_CLOCKS
+struct StageClkLds {
+    unsigned long long acc[12][MQ_N_CLK];  // workgroups of at most 12 waves
+    unsigned long long last[12];
+};
+__device__ __forceinline__ StageClkLds &mq_clk_lds() {
+    __shared__ StageClkLds C;
+    return C;
+}
+__device__ __forceinline__ void mq_clk(int i) {
+    StageClkLds &C = mq_clk_lds();
+    const uint32_t w = threadIdx.x >> 6;
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63u) == 0) {
+        if (i >= 0) C.acc[w][i] += now - C.last[w];
+        C.last[w] = now;
+    }
+}
+#else
+__device__ __forceinline__ void mq_clk(int) {}
+#endif
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
@@ -669,6 +701,7 @@ struct MapSink {
                 if (act) k0[c] = probe_issue(key[c]);
             }
         }
+        mq_clk(6);
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
             if ((uint32_t)c * 64u < K) {
@@ -685,6 +718,7 @@ struct MapSink {
                 batch_runs(n, key[c], ((revbits >> c) & 1u) != 0, qs, qe, hit, e);
             }
         }
+        mq_clk(7);
     }
 
     // the run still open after the last k-min-mer of the read ends there

@@ -38,7 +38,10 @@ constexpr uint32_t SD_FLAG_BLKS = 4 * ((SD_LC_MAX + 63) / 64);  // 16-step block
 constexpr uint32_t SD_CODES_DW = 4 * ((63 * SD_LC_MAX + 16 * ((SD_LC_MAX + 15) / 16) + MAX_L + 32) / 64 + 1);  // packed 2-bit codes + zero read-ahead padding (whole uint4s)
 static_assert((63 * SD_LC_MAX + 16 * ((SD_LC_MAX + 15) / 16) + MAX_L + 32) / 16 < SD_CODES_DW, "code stream read-ahead padding");
 static_assert((SD_LC_MAX + 15) / 16 <= SD_FLAG_BLKS && SD_FLAG_BLKS % 4 == 0, "flag words");
-constexpr uint32_t SD_OWNER_CAP = 256;                     // candidates listed per round of stage R (four lane-batches)
+#ifndef MQ_SD_OWNER_CAP
+#define MQ_SD_OWNER_CAP 256
+#endif
+constexpr uint32_t SD_OWNER_CAP = MQ_SD_OWNER_CAP;                     // candidates listed per round of stage R (four lane-batches)
 static_assert(SD_BLOCKS <= 256, "block_of holds block numbers in a byte");
 
 // workgroup-shared look-up tables (built once per workgroup)
@@ -148,17 +151,21 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
     uint32_t n_sr = (len - raw0 + SD_SR_RAW - 1u) / SD_SR_RAW;
     if (n_sr > SD_MAX_SR) n_sr = SD_MAX_SR;
     const uint32_t fill = (uint32_t)seq[len - 1] * 0x01010101u;
-    // 16 bases at pos; bytes past the end repeat the last base (never a run head under HPC; masked without HPC)
+    // 16 bases at pos; bytes past the end repeat the last base (never a run head under HPC; masked without HPC).  A piece that
+    // reaches past the end (only in the sequence's last super-row) is cut out of the 16 bytes that END at len (len >= 16 is the
+    // caller's precondition): one load, never a byte beyond the sequence.
     auto load_piece = [&](uint32_t pos) -> uint4 {
         if (pos + 16u <= len) return *reinterpret_cast<const uint4_unaligned *>(seq + pos);
-        unsigned long long lo = ((unsigned long long)fill << 32) | fill, hi = lo;
-        const uint32_t nv = pos < len ? len - pos : 0u;
-        for (uint32_t j = 0; j < nv; ++j) {
-            const unsigned long long b = seq[pos + j];
-            if (j < 8u) lo = (lo & ~(0xFFull << (8u * j))) | (b << (8u * j));
-            else hi = (hi & ~(0xFFull << (8u * (j - 8u)))) | (b << (8u * (j - 8u)));
-        }
-        return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+        const uint4 v = *reinterpret_cast<const uint4_unaligned *>(seq + (len - 16u));
+        const uint32_t nv = pos < len ? len - pos : 0u;  // valid bytes: 0..15
+        const uint32_t s = 16u - nv;                      // shift the 32-byte value [v, fill...] right by s bytes
+        uint32_t w0 = v.x, w1 = v.y, w2 = v.z, w3 = v.w;
+        if (s & 4u) { w0 = w1; w1 = w2; w2 = w3; w3 = fill; }
+        if (s & 8u) { w0 = w2; w1 = w3; w2 = fill; w3 = fill; }
+        if (s & 16u) { w0 = fill; w1 = fill; w2 = fill; w3 = fill; }
+        const uint32_t sb = s & 3u;
+        return make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sb), __builtin_amdgcn_alignbyte(w2, w1, sb),
+                          __builtin_amdgcn_alignbyte(w3, w2, sb), __builtin_amdgcn_alignbyte(fill, w3, sb));
     };
     uint4 nx0, nx1, nx2, nx3;
     {
@@ -179,26 +186,22 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
     constexpr uint32_t S1 = 0x00430041u, S0 = 0x00470054u;  // v_perm pool: selector 0,2 -> 'A','C' ; 4,6 -> 'T','G'
     for (uint32_t sr = 0; sr < n_sr; ++sr) {
         const uint32_t pos = raw0 + sr * SD_SR_RAW + lane * 64u;
-        const uint4 c0 = nx0, c1 = nx1, c2 = nx2, c3 = nx3;
-        if (sr + 1u < n_sr) {
-            const uint32_t np = pos + SD_SR_RAW;
-            nx0 = load_piece(np);
-            nx1 = load_piece(np + 16u);
-            nx2 = load_piece(np + 32u);
-            nx3 = load_piece(np + 48u);
-        }
+        const bool more_sr = sr + 1u < n_sr;
         uint32_t p[4];
-        {
-            const uint4 cc[4] = {c0, c1, c2, c3};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t t0 = cc[j].x & 0x06060606u, t1 = cc[j].y & 0x06060606u, t2 = cc[j].z & 0x06060606u, t3 = cc[j].w & 0x06060606u;
-                // reconstructs each byte iff it was A/C/G/T
-                bad |= (__builtin_amdgcn_perm(S0, S1, t0) ^ cc[j].x) | (__builtin_amdgcn_perm(S0, S1, t1) ^ cc[j].y) |
-                       (__builtin_amdgcn_perm(S0, S1, t2) ^ cc[j].z) | (__builtin_amdgcn_perm(S0, S1, t3) ^ cc[j].w);
-                p[j] = pack16(t0, t1, t2, t3);
-            }
-        }
+        // decode piece j, then send the load of the NEXT super-row's piece j into the registers just freed: 16 registers of
+        // bases in flight plus the piece being decoded, instead of two whole super-rows
+        auto decode = [&](uint4 &nx, uint32_t j) {
+            const uint32_t t0 = nx.x & 0x06060606u, t1 = nx.y & 0x06060606u, t2 = nx.z & 0x06060606u, t3 = nx.w & 0x06060606u;
+            // reconstructs each byte iff it was A/C/G/T
+            bad |= (__builtin_amdgcn_perm(S0, S1, t0) ^ nx.x) | (__builtin_amdgcn_perm(S0, S1, t1) ^ nx.y) |
+                   (__builtin_amdgcn_perm(S0, S1, t2) ^ nx.z) | (__builtin_amdgcn_perm(S0, S1, t3) ^ nx.w);
+            p[j] = pack16(t0, t1, t2, t3);
+            if (more_sr) nx = load_piece(pos + SD_SR_RAW + 16u * j);
+        };
+        decode(nx0, 0);
+        decode(nx1, 1);
+        decode(nx2, 2);
+        decode(nx3, 3);
         uint32_t out[4], n2[4], hb[4];
         if (use_hpc) {
             // code of the base before this lane's block: the previous lane's last base (DPP wave_shr:1), lane 0 takes the carry
@@ -512,17 +515,21 @@ __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict
                                                        uint32_t *__restrict__ mz_pos, uint32_t out_cap) {
     const uint32_t lane = lane_id();
     uint32_t raw0 = 0, carry_n = 0, carry_prev = 0, n_out = 0;
+    if (len < 16u) return SD_NOT_FAST;  // stage A reads whole 16-byte pieces (its tail piece is the 16 bytes that end at len)
     while (raw0 < len) {
         uint32_t n_codes = 0, n_blocks = 0, raw_end = 0;
         const bool ok = seed_stage_a(seq, len, raw0, carry_n, carry_prev, P.use_hpc != 0, P.fold != 0, T, S, n_codes, n_blocks, raw_end);
+        mq_clk(0);
         if (!ok) return SD_NOT_FAST;
         const bool more = raw_end < len;
         if (STOP != 1 && n_codes >= P.l) {
             const uint32_t w_eff = n_codes - P.l + 1u;
             seed_stage_b(T, S, P, w_eff);
+            mq_clk(1);
             if (STOP != 2) {
                 bool inexact = false;
                 n_out += seed_stage_r(T, S, P, w_eff, n_blocks, n_codes, raw0, carry_n, mz_hash, mz_pos, n_out, out_cap, inexact);
+                mq_clk(2);
                 if (inexact) return SD_NOT_FAST;
             }
         }
@@ -545,6 +552,7 @@ __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict
         }
         wave_sync();
         raw0 = raw_end;
+        mq_clk(3);
     }
     return n_out;
 }
