@@ -2,6 +2,9 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC (see mapquik_amd/build.py).  gfx950 only; no CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -49,7 +52,7 @@ struct SplitArgs {
     uint32_t *counters;    // [0] seed work, [1] map work, [2] queue length, [3] general work, [4] fast reads, [5] general reads,
                            // [6] lists moved to the pool, [12..13] 64-bit pool cursor
     uint32_t force_general;
-    const Slot *table;
+    const Bucket *table;
     uint64_t mask;
     const uint64_t *ref_lens;
     MatchRec *scratch_all;  // per mapping wave: cap_matches records
@@ -119,7 +122,7 @@ __device__ __forceinline__ uint32_t seed_read_general(const SplitArgs &A, WaveLd
 #define MQ_ML_NB 7
 #endif
 constexpr int ML_NB = MQ_ML_NB;                              // lane-batches of 64 k-min-mers hashed and probed together
-constexpr uint32_t ML_LIST_CAP = 64 * ML_NB + MAX_K;   // minimizers staged in LDS at a time
+constexpr uint32_t ML_LIST_CAP = 64 * ML_NB + 64;      // minimizers staged in LDS at a time (64 * ML_NB + k - 1 used)
 struct MapListLds {
     unsigned long long h[ML_LIST_CAP];
     uint32_t p[ML_LIST_CAP];
@@ -150,9 +153,28 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
         const uint32_t chunk = 64u * (uint32_t)ML_NB + P.k - 1u;
         for (uint32_t g = 0; g + P.k <= cnt;) {
             const uint32_t have = cnt - g < chunk ? cnt - g : chunk;
-            for (uint32_t i = lane; i < have; i += 64u) {  // L2-served loads: the list may have been written by this very wave
-                S.h[i] = ld_sc1_u64(lh + g + i);
-                S.p[i] = ld_sc1_u32(lp + g + i);
+            {  // L2-served loads (the list may have been written by this very wave), ALL in flight before the first is stored: one L2
+               // round trip per chunk (a loop that loads and stores 64 entries at a time exposes one per 64 entries)
+                unsigned long long hv[ML_NB + 1];
+                uint32_t pv[ML_NB + 1];
+#pragma unroll
+                for (int j = 0; j <= ML_NB; ++j) {
+                    const uint32_t i = lane + 64u * (uint32_t)j;
+                    hv[j] = 0;
+                    pv[j] = 0;
+                    if (i < have) {
+                        hv[j] = ld_sc1_u64(lh + g + i);
+                        pv[j] = ld_sc1_u32(lp + g + i);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j <= ML_NB; ++j) {
+                    const uint32_t i = lane + 64u * (uint32_t)j;
+                    if (i < have) {
+                        S.h[i] = hv[j];
+                        S.p[i] = pv[j];
+                    }
+                }
             }
             wave_sync();
             mq_clk(5);
@@ -224,13 +246,19 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         for (int i = 0; i < MQ_N_CLK; ++i) mq_clk_lds().acc[wv][i] = 0;
     mq_clk(-1);
 #endif
-    for (;;) {
-        uint32_t r = 0;
-        if (lane == 0) r = atomicAdd(&A.counters[0], 1u);
-        r = rdfirst(r);
-        if (r >= A.n) break;
-        const uint64_t o0 = A.offsets[r];
-        const uint64_t len = A.lens ? (uint64_t)A.lens[r] : A.offsets[r + 1] - o0;
+    // The work item after the current one is fetched while the current one is processed: its index (one atomic) during the seed
+    // phase, its offsets during the map phase -- two dependent memory round trips per read that no wave waits for.
+    uint32_t r = 0;
+    if (lane == 0) r = atomicAdd(&A.counters[0], 1u);
+    r = rdfirst(r);
+    uint64_t o0 = 0, len = 0;
+    if (r < A.n) {
+        o0 = A.offsets[r];
+        len = A.lens ? (uint64_t)A.lens[r] : A.offsets[r + 1] - o0;
+    }
+    while (r < A.n) {
+        uint32_t rn_v = 0;
+        if (lane == 0) rn_v = atomicAdd(&A.counters[0], 1u);
         uint32_t cnt = 0;
         uint64_t base = 0;
         mq_clk(11);
@@ -253,8 +281,19 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
             wave_sync();
             mq_clk(4);
         }
+        const uint32_t rn = rdfirst(rn_v);
+        unsigned long long n_o0 = 0, n_o1 = 0;
+        uint32_t n_len = 0;
+        if (lane == 0 && rn < A.n) {  // vector loads by one lane: in flight through the map phase (scalar loads would be waited for at its first LDS wait)
+            n_o0 = A.offsets[rn];
+            if (A.lens) n_len = A.lens[rn];
+            else n_o1 = A.offsets[rn + 1];
+        }
         map_read<CH, TIMING>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups);
         wave_sync();
+        r = rn;
+        o0 = rdlane64(n_o0, 0);
+        len = A.lens ? (uint64_t)rdfirst(n_len) : rdlane64(n_o1, 0) - o0;
     }
     if (lane == 0) {
         if (n_fast) atomicAdd(&A.counters[4], n_fast);
@@ -428,60 +467,128 @@ __global__ void ref_kminmers_kernel(const Minimizer *__restrict__ dense, uint64_
     }
 }
 
-// Index::add_with_mer (src/index.rs:100-104) made order independent: the first claimant of a slot stores the entry,
-// every insertion bumps the slot's count; a slot is live iff count == 1 (and end != 0, src/index.rs:67-69).
-__global__ void insert_kernel(const RefKmm *__restrict__ kmm, uint64_t n, Slot *__restrict__ table, uint64_t mask) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const RefKmm r = kmm[i];
-        uint64_t s;
-        bool won = false;
-        if (r.hash == 0) {
-            s = mask + 1;
-            won = atomicAdd(&table[s].pad, 1u) == 0;  // pad counts claims on the key-0 slot
-        } else {
-            s = r.hash & mask;
-            for (;;) {
-                unsigned long long prev = atomicCAS(&table[s].key, 0ull, r.hash);
-                if (prev == 0ull) { won = true; break; }
-                if (prev == r.hash) break;
-                s = (s + 1) & mask;
+// Index::add_with_mer (src/index.rs:100-104) made order independent: the first claimant of a slot stores the entry, every insertion
+// bumps the slot's count; finalize (count_kernel) turns "inserted more than once" into the tombstone form end = 0.
+// Walks the probe sequence of mq_device.hpp (home slot, other way of the home bucket, following buckets).
+__device__ __forceinline__ void table_insert(Bucket *__restrict__ table, uint64_t mask, unsigned long long key, const Entry &e, uint32_t times) {
+    const uint64_t nb = (mask + 1) >> 1;
+    uint64_t b;
+    uint32_t w = 0;
+    bool won = false;
+    if (key == 0) {
+        b = nb;
+        won = atomicAdd(&table[b].claims, 1u) == 0;
+    } else {
+        const uint64_t s0 = key & mask;
+        b = s0 >> 1;
+        w = (uint32_t)s0 & 1u;
+        for (uint32_t step = 0;; ++step) {
+            const unsigned long long prev = atomicCAS(&table[b].key[w], 0ull, key);
+            if (prev == 0ull) { won = true; break; }
+            if (prev == key) break;
+            if (step == 0) {
+                w ^= 1u;
+            } else if (step == 1 || w == 1u) {
+                b = b + 1 == nb ? 0 : b + 1;
+                w = 0;
+            } else {
+                w = 1u;
             }
         }
-        if (won) {
-            table[s].start = r.start;
-            table[s].end = r.end;
-            table[s].offset = r.offset;
-            table[s].id_rc = r.id_rc;
-        }
-        atomicAdd(&table[s].count, 1u);
+    }
+    if (won) table[b].pay[w] = e;
+    atomicAdd(&table[b].count[w], times);
+}
+
+__global__ void insert_kernel(const RefKmm *__restrict__ kmm, uint64_t n, Bucket *__restrict__ table, uint64_t mask) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const RefKmm r = kmm[i];
+        Entry e;
+        e.start = r.start;
+        e.end = r.end;
+        e.offset = r.offset;
+        e.id_rc = r.id_rc;
+        table_insert(table, mask, r.hash, e, 1u);
     }
 }
 
-// Index::get_count (src/index.rs:90-92) + number of distinct keys
-__global__ void count_kernel(const Slot *__restrict__ table, uint64_t nslots_plus1, unsigned long long *__restrict__ acc) {
-    unsigned long long live = 0, keys = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nslots_plus1; i += (uint64_t)gridDim.x * blockDim.x) {
-        const Slot v = table[i];
-        if (v.count != 0) {
+// One pass over the finished table: Index::get_count (src/index.rs:90-92) = live slots, the number of distinct keys, the largest
+// reference id stored -- and the tombstone form: a key inserted more than once gets end = 0 (is_empty, src/index.rs:67-69), so
+// that a lookup decides on the 16 payload bytes alone.  acc: [0] live, [1] keys, [2] max ref id + 1 over occupied slots.
+__global__ void count_kernel(Bucket *__restrict__ table, uint64_t n_buckets_plus1, unsigned long long *__restrict__ acc) {
+    unsigned long long live = 0, keys = 0, max_id1 = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n_buckets_plus1; i += (uint64_t)gridDim.x * blockDim.x) {
+        Bucket &B = table[i >> 1];
+        const uint32_t w = (uint32_t)i & 1u;
+        const uint32_t cnt = B.count[w];
+        if (cnt != 0) {
             keys++;
-            if (v.count == 1 && v.end != 0) live++;
+            const Entry e = B.pay[w];
+            const unsigned long long id1 = (unsigned long long)(e.id_rc >> 1) + 1ull;
+            max_id1 = id1 > max_id1 ? id1 : max_id1;
+            if (cnt == 1 && e.end != 0) live++;
+            else if (e.end != 0) B.pay[w].end = 0;
         }
     }
     for (int d = 32; d >= 1; d >>= 1) {
         live += __shfl_xor(live, d, 64);
         keys += __shfl_xor(keys, d, 64);
+        const unsigned long long o = __shfl_xor(max_id1, d, 64);
+        max_id1 = o > max_id1 ? o : max_id1;
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&acc[0], live);
         atomicAdd(&acc[1], keys);
+        atomicMax(&acc[2], max_id1);
     }
 }
 
-__global__ void lookup_kernel(const Slot *__restrict__ table, uint64_t mask, const uint64_t *__restrict__ keys, uint32_t n,
+// On-disk form (mq_index_save / mq_index_load): the occupied slots only, 32 bytes each, in no particular order.
+struct alignas(32) SavedSlot {
+    Entry e;
+    unsigned long long key;
+    uint32_t count;
+    uint32_t is_key0;  // 1: the entry of the key 0 (the extra bucket)
+};
+static_assert(sizeof(SavedSlot) == 32, "saved slot size");
+__global__ void pack_slots_kernel(const Bucket *__restrict__ table, uint64_t n_buckets_plus1, SavedSlot *__restrict__ out,
+                                  unsigned long long *__restrict__ cursor, uint64_t cap) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n_buckets_plus1; i += (uint64_t)gridDim.x * blockDim.x) {
+        const Bucket &B = table[i >> 1];
+        const uint32_t w = (uint32_t)i & 1u;
+        const uint32_t cnt = B.count[w];
+        if (cnt != 0) {
+            const unsigned long long at = atomicAdd(cursor, 1ull);
+            if (at < cap) {
+                SavedSlot v;
+                v.key = B.key[w];
+                v.e = B.pay[w];
+                v.count = cnt;
+                v.is_key0 = (i >> 1) == n_buckets_plus1 - 1 ? 1u : 0u;
+                out[at] = v;
+            }
+        }
+    }
+}
+// mq_index_load: saved slots back into an empty table (keys are distinct, so every insertion claims its slot); flags[0] is set
+// when an entry cannot be what mq_index_save wrote (a reference id beyond the file's reference table, a key 0 outside its slot).
+__global__ void unpack_slots_kernel(const SavedSlot *__restrict__ in, uint64_t n, Bucket *__restrict__ table, uint64_t mask, uint32_t max_id,
+                                    uint32_t *__restrict__ flags) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const SavedSlot v = in[i];
+        if (v.count == 0 || (v.e.id_rc >> 1) > max_id || (v.is_key0 != 0) != (v.key == 0) || v.is_key0 > 1u) {
+            atomicOr(flags, 1u);
+            continue;
+        }
+        table_insert(table, mask, v.key, v.e, v.count);
+    }
+}
+
+__global__ void lookup_kernel(const Bucket *__restrict__ table, uint64_t mask, const uint64_t *__restrict__ keys, uint32_t n,
                               uint8_t *__restrict__ found, mq_kminmer *__restrict__ entries, uint32_t *__restrict__ ref_ids) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Slot e = {};
+    Entry e = {};
     const bool hit = probe_table(table, mask, keys[i], e);
     found[i] = hit ? 1 : 0;
     mq_kminmer k;
@@ -497,10 +604,11 @@ __global__ void lookup_kernel(const Slot *__restrict__ table, uint64_t mask, con
 // Diagnostic (tools/probe_rate.py): how many random index probes per second the memory system sustains, detached from
 // everything else the map path does.  Every thread looks up `per_thread` pseudo-random keys (absent with probability ~1,
 // like ~85 % of a read's k-min-mers), `ilp` home-slot loads in flight per thread.
-__global__ void probe_rate_kernel(const Slot *__restrict__ table, uint64_t mask, uint32_t per_thread, uint64_t seed,
+__global__ void probe_rate_kernel(const Bucket *__restrict__ table, uint64_t mask, uint32_t per_thread, uint64_t seed,
                                   unsigned long long *__restrict__ acc, const uint32_t *__restrict__ bitmap, uint64_t bit_mask,
                                   uint32_t table_too) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nb = (mask + 1) >> 1;
     unsigned long long found = 0, steps = 0;
     auto mix = [](uint64_t z) {
         z += 0x9e3779b97f4a7c15ULL;
@@ -510,32 +618,50 @@ __global__ void probe_rate_kernel(const Slot *__restrict__ table, uint64_t mask,
     };
     for (uint32_t j = 0; j < per_thread; j += 4) {
         uint64_t key[4];
-        unsigned long long k0[4];
+        uint4 kk[4];
         uint32_t bw[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             key[u] = mix(seed + tid * per_thread + j + u) | 1ull;
             if (bitmap) bw[u] = bitmap[(key[u] & bit_mask) >> 5];
-            else k0[u] = table[key[u] & mask].key;
+            else kk[u] = ld_u4(&table[(key[u] & mask) >> 1].key[0]);
         }
         if (bitmap) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const bool maybe = (bw[u] >> (key[u] & 31u)) & 1u;
                 found += maybe;
-                k0[u] = (maybe && table_too) ? table[key[u] & mask].key : 0ull;
+                kk[u] = (maybe && table_too) ? ld_u4(&table[(key[u] & mask) >> 1].key[0]) : make_uint4(0, 0, 0, 0);
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            uint64_t sl = key[u] & mask;
-            unsigned long long k = k0[u];
-            while (k != 0 && k != key[u]) {
-                sl = (sl + 1) & mask;
-                k = table[sl].key;
+            // the probe sequence of mq_device.hpp: home way, other way, then the following buckets
+            const uint32_t w0 = (uint32_t)(key[u] & mask) & 1u;
+            uint64_t ka = u64_of(kk[u].x, kk[u].y), kb = u64_of(kk[u].z, kk[u].w);
+            uint64_t kh = w0 ? kb : ka, kp = w0 ? ka : kb;
+            uint64_t b = (key[u] & mask) >> 1;
+            bool hit = kh == key[u], go = !hit && kh != 0;
+            if (go) {
                 steps++;
+                hit = kp == key[u];
+                go = !hit && kp != 0;
             }
-            if (k == key[u]) found += table[sl].count;
+            while (go) {
+                b = b + 1 == nb ? 0 : b + 1;
+                const uint4 v = ld_u4(&table[b].key[0]);
+                ka = u64_of(v.x, v.y);
+                kb = u64_of(v.z, v.w);
+                steps++;
+                hit = ka == key[u];
+                go = !hit && ka != 0;
+                if (go) {
+                    steps++;
+                    hit = kb == key[u];
+                    go = !hit && kb != 0;
+                }
+            }
+            if (hit) found += table[b].count[0];
         }
     }
     for (int d = 32; d >= 1; d >>= 1) {
@@ -625,7 +751,7 @@ struct mq_index {
     std::vector<KmmChunk> chunks;
     uint64_t n_kmm_total = 0;
     bool finalized = false;
-    Slot *table = nullptr;  // nslots + 1
+    Bucket *table = nullptr;  // nslots / 2 buckets + the extra bucket of the key 0
     uint64_t nslots = 0;
     uint64_t *d_ref_lens = nullptr;
     uint64_t n_unique = 0, n_keys = 0;
@@ -689,13 +815,16 @@ static int use_device(const mq_index *idx) {
     return MQ_OK;
 }
 
+static size_t table_bytes_of(uint64_t nslots) { return (size_t)(nslots / 2 + 1) * sizeof(Bucket); }
+
 static int alloc_table(mq_index *idx, uint64_t nslots) {
     if (idx->table) {
         HIPCHK(hipFree(idx->table));
         idx->table = nullptr;
     }
-    HIPCHK(hipMalloc((void **)&idx->table, (nslots + 1) * sizeof(Slot)));
-    HIPCHK(hipMemset(idx->table, 0, (nslots + 1) * sizeof(Slot)));
+    if (nslots < 2) nslots = 2;  // whole buckets
+    HIPCHK(hipMalloc((void **)&idx->table, table_bytes_of(nslots)));
+    HIPCHK(hipMemset(idx->table, 0, table_bytes_of(nslots)));
     idx->nslots = nslots;
     return MQ_OK;
 }
@@ -906,8 +1035,8 @@ mq_index *mq_index_new(const mq_params *params, int device) try {
         return nullptr;
     }
     idx->n_cu = prop.multiProcessorCount;
-    // a 1-slot empty table so that seeding-only calls work before finalize
-    if (alloc_table(idx, 1) != MQ_OK) {
+    // an empty one-bucket table so that seeding-only calls work before finalize
+    if (alloc_table(idx, 2) != MQ_OK) {
         delete idx;
         return nullptr;
     }
@@ -1049,13 +1178,13 @@ int64_t mq_index_finalize(mq_index *idx) try {
         HIPCHK(hipGetLastError());
     }
     unsigned long long *d_acc = nullptr;
-    HIPCHK(hipMalloc((void **)&d_acc, 16));
-    HIPCHK(hipMemset(d_acc, 0, 16));
-    const uint32_t nb = (uint32_t)std::min<uint64_t>((nslots + 1 + 255) / 256, 1u << 16);
-    hipLaunchKernelGGL(count_kernel, dim3(nb), dim3(256), 0, 0, idx->table, nslots + 1, d_acc);
+    HIPCHK(hipMalloc((void **)&d_acc, 24));
+    HIPCHK(hipMemset(d_acc, 0, 24));
+    const uint32_t nb = (uint32_t)std::min<uint64_t>((nslots + 2 + 255) / 256, 1u << 16);
+    hipLaunchKernelGGL(count_kernel, dim3(nb), dim3(256), 0, 0, idx->table, nslots / 2 + 1, d_acc);
     HIPCHK(hipGetLastError());
-    unsigned long long acc[2] = {0, 0};
-    HIPCHK(hipMemcpy(acc, d_acc, 16, hipMemcpyDeviceToHost));
+    unsigned long long acc[3] = {0, 0, 0};
+    HIPCHK(hipMemcpy(acc, d_acc, 24, hipMemcpyDeviceToHost));
     HIPCHK(hipFree(d_acc));
     idx->n_unique = acc[0];
     idx->n_keys = acc[1];
@@ -1085,8 +1214,8 @@ int mq_index_get_stats(const mq_index *idx, mq_index_stats *out) try {
     out->n_keys = idx->n_keys;
     out->n_unique = idx->n_unique;
     out->table_slots = idx->nslots;
-    out->table_bytes = (idx->nslots + 1) * sizeof(Slot);
-    out->slot_bytes = sizeof(Slot);
+    out->table_bytes = table_bytes_of(idx->nslots);
+    out->slot_bytes = SLOT_BYTES;
     return MQ_OK;
 } catch (const std::bad_alloc &) {
     return set_err(MQ_ENOMEM, "out of host memory");
@@ -1094,37 +1223,105 @@ int mq_index_get_stats(const mq_index *idx, mq_index_stats *out) try {
     return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
-// On-disk index (the reference has none and rebuilds on every run, src/closures.rs:24-94): header, parameters, reference
-// table, then the finalized slot table verbatim.  Little-endian, this library's layout (MQ_INDEX_MAGIC names the version).
-static const char MQ_INDEX_MAGIC[8] = {'M', 'Q', 'H', 'I', 'P', 'I', 'X', '1'};
+// On-disk index (the reference has none and rebuilds on every run, src/closures.rs:24-94): header, parameters, reference table,
+// then the OCCUPIED slots only (32 bytes each: ~1.5 GB for a human genome instead of the 17 GB table at load 1/8); mq_index_load
+// scatters them into a fresh table on the device.  Little-endian, this library's layout (MQ_INDEX_MAGIC names the version).
+static const char MQ_INDEX_MAGIC[8] = {'M', 'Q', 'H', 'I', 'P', 'I', 'X', '2'};
+constexpr size_t IX_IO_CHUNK = 64u << 20;  // bytes per page-locked transfer buffer (two of them: the copy overlaps the file I/O)
+
+static bool write_all(int fd, const void *p, size_t n) {
+    const uint8_t *b = (const uint8_t *)p;
+    while (n) {
+        const ssize_t w = ::write(fd, b, n);
+        if (w <= 0) return false;
+        b += w;
+        n -= (size_t)w;
+    }
+    return true;
+}
+static bool read_all(int fd, void *p, size_t n) {
+    uint8_t *b = (uint8_t *)p;
+    while (n) {
+        const ssize_t r = ::read(fd, b, n);
+        if (r <= 0) return false;
+        b += r;
+        n -= (size_t)r;
+    }
+    return true;
+}
 
 int mq_index_save(const mq_index *idx, const char *path) try {
     if (!idx || !path) return set_err(MQ_EINVAL, "bad arguments");
     if (!idx->finalized) return set_err(MQ_ESTATE, "index not finalized");
     int rc = use_device(idx);
     if (rc) return rc;
-    FILE *f = fopen(path, "wb");
-    if (!f) return set_err(MQ_EINVAL, std::string("cannot open for writing: ") + path);
-    bool ok = fwrite(MQ_INDEX_MAGIC, 1, 8, f) == 8;
-    const uint64_t hdr[6] = {sizeof(Slot), idx->nslots, idx->n_kmm_total, idx->n_keys, idx->n_unique, (uint64_t)idx->refs.size()};
-    ok = ok && fwrite(&idx->params, sizeof(mq_params), 1, f) == 1 && fwrite(hdr, sizeof(hdr), 1, f) == 1;
+    // occupied slots, packed on the device
+    const uint64_t n_occ = idx->n_keys;
+    SavedSlot *d_pack = nullptr;
+    unsigned long long *d_cur = nullptr;
+    uint8_t *h_buf[2] = {nullptr, nullptr};
+    hipStream_t st = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int fd = -1;
+    auto cleanup = [&]() {
+        hipFree(d_pack);
+        hipFree(d_cur);
+        for (int i = 0; i < 2; ++i) {
+            if (h_buf[i]) hipHostFree(h_buf[i]);
+            if (ev[i]) hipEventDestroy(ev[i]);
+        }
+        if (st) hipStreamDestroy(st);
+        if (fd >= 0) ::close(fd);
+    };
+    auto fail = [&](int code, const std::string &msg) {
+        cleanup();
+        return set_err(code, msg);
+    };
+    if (hipMalloc((void **)&d_pack, (size_t)(n_occ + 1) * sizeof(SavedSlot)) != hipSuccess || hipMalloc((void **)&d_cur, 8) != hipSuccess ||
+        hipMemset(d_cur, 0, 8) != hipSuccess)
+        return fail(MQ_ENOMEM, "mq_index_save: no device memory for the packed slots");
+    const uint64_t nb1 = idx->nslots / 2 + 1;
+    hipLaunchKernelGGL(pack_slots_kernel, dim3((uint32_t)std::min<uint64_t>((2 * nb1 + 255) / 256, 1u << 16)), dim3(256), 0, 0, idx->table, nb1, d_pack,
+                       d_cur, n_occ);
+    unsigned long long packed = 0;
+    if (hipGetLastError() != hipSuccess || hipMemcpy(&packed, d_cur, 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(MQ_EHIP, "mq_index_save: packing the table failed");
+    if (packed != n_occ) return fail(MQ_ESTATE, "mq_index_save: the table holds another number of keys than the index records (internal error)");
+    fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return fail(MQ_EINVAL, std::string("cannot open for writing: ") + path);
+    bool ok = write_all(fd, MQ_INDEX_MAGIC, 8);
+    const uint64_t hdr[6] = {sizeof(SavedSlot), idx->nslots, idx->n_kmm_total, idx->n_keys, idx->n_unique, (uint64_t)idx->refs.size()};
+    ok = ok && write_all(fd, &idx->params, sizeof(mq_params)) && write_all(fd, hdr, sizeof(hdr));
     for (auto &kv : idx->refs) {
         const uint32_t id = kv.first, nl = (uint32_t)kv.second.first.size();
-        ok = ok && fwrite(&id, 4, 1, f) == 1 && fwrite(&nl, 4, 1, f) == 1 && fwrite(&kv.second.second, 8, 1, f) == 1 &&
-             (nl == 0 || fwrite(kv.second.first.data(), 1, nl, f) == nl);
+        ok = ok && write_all(fd, &id, 4) && write_all(fd, &nl, 4) && write_all(fd, &kv.second.second, 8) && (nl == 0 || write_all(fd, kv.second.first.data(), nl));
     }
-    const size_t total = (size_t)(idx->nslots + 1) * sizeof(Slot), chunk = 64u << 20;
-    std::vector<uint8_t> buf(std::min(total, chunk));
-    for (size_t o = 0; ok && o < total; o += chunk) {
-        const size_t n = std::min(chunk, total - o);
-        if (hipMemcpy(buf.data(), (const uint8_t *)idx->table + o, n, hipMemcpyDeviceToHost) != hipSuccess) {
-            fclose(f);
-            return set_err(MQ_EHIP, "hipMemcpy D2H failed while saving the index");
+    const size_t total = (size_t)n_occ * sizeof(SavedSlot);
+    if (ok && total) {
+        bool hip_ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; i < 2 && hip_ok; ++i)
+            hip_ok = hipHostMalloc((void **)&h_buf[i], std::min(total, IX_IO_CHUNK), hipHostMallocDefault) == hipSuccess && hipEventCreate(&ev[i]) == hipSuccess;
+        if (!hip_ok) return fail(MQ_EHIP, "mq_index_save: transfer buffers");
+        // chunk i+1 crosses PCIe while chunk i goes to the file
+        const size_t n_chunks = (total + IX_IO_CHUNK - 1) / IX_IO_CHUNK;
+        auto issue = [&](size_t c) {
+            const size_t o = c * IX_IO_CHUNK, n = std::min(IX_IO_CHUNK, total - o);
+            return hipMemcpyAsync(h_buf[c & 1], (const uint8_t *)d_pack + o, n, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                   hipEventRecord(ev[c & 1], st) == hipSuccess;
+        };
+        hip_ok = issue(0);
+        for (size_t c = 0; c < n_chunks && ok && hip_ok; ++c) {
+            if (c + 1 < n_chunks) hip_ok = issue(c + 1);
+            hip_ok = hip_ok && hipEventSynchronize(ev[c & 1]) == hipSuccess;
+            const size_t o = c * IX_IO_CHUNK, n = std::min(IX_IO_CHUNK, total - o);
+            ok = hip_ok && write_all(fd, h_buf[c & 1], n);
         }
-        ok = fwrite(buf.data(), 1, n, f) == n;
+        if (!hip_ok) return fail(MQ_EHIP, "mq_index_save: device-to-host copy failed");
     }
-    ok = (fclose(f) == 0) && ok;
-    return ok ? MQ_OK : set_err(MQ_EINVAL, std::string("short write: ") + path);
+    const bool closed = ::close(fd) == 0;
+    fd = -1;
+    cleanup();
+    return ok && closed ? MQ_OK : set_err(MQ_EINVAL, std::string("short write: ") + path);
 } catch (const std::bad_alloc &) {
     return set_err(MQ_ENOMEM, "out of host memory");
 } catch (const std::exception &e) {
@@ -1136,54 +1333,109 @@ mq_index *mq_index_load(const char *path, int device) try {
         set_err(MQ_EINVAL, "path is NULL");
         return nullptr;
     }
-    FILE *f = fopen(path, "rb");
-    if (!f) {
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) {
         set_err(MQ_EINVAL, std::string("cannot open: ") + path);
         return nullptr;
     }
     char magic[8];
     mq_params p;
     uint64_t hdr[6];
-    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, MQ_INDEX_MAGIC, 8) != 0 || fread(&p, sizeof(p), 1, f) != 1 ||
-        fread(hdr, sizeof(hdr), 1, f) != 1 || hdr[0] != sizeof(Slot) || hdr[1] == 0 || (hdr[1] & (hdr[1] - 1)) != 0 ||
-        hdr[1] > (1ull << 40) || hdr[3] >= hdr[1] /* a table without an empty slot would make a miss walk forever */ || hdr[5] > MQ_MAX_REF_ID) {
-        fclose(f);
+    if (!read_all(fd, magic, 8) || memcmp(magic, MQ_INDEX_MAGIC, 8) != 0 || !read_all(fd, &p, sizeof(p)) || !read_all(fd, hdr, sizeof(hdr)) ||
+        hdr[0] != sizeof(SavedSlot) || hdr[1] < 2 || (hdr[1] & (hdr[1] - 1)) != 0 || hdr[1] > (1ull << 40) ||
+        hdr[3] >= hdr[1] /* a table without an empty slot would make a miss walk forever */ || hdr[4] > hdr[3] || hdr[5] > MQ_MAX_REF_ID) {
+        ::close(fd);
         set_err(MQ_EINVAL, std::string("not a mapquik HIP index (or another layout version): ") + path);
         return nullptr;
     }
     mq_index *idx = mq_index_new(&p, device);
     if (!idx) {
-        fclose(f);
+        ::close(fd);
         return nullptr;
     }
     bool ok = true;
     for (uint64_t i = 0; ok && i < hdr[5]; ++i) {
         uint32_t id = 0, nl = 0;
         uint64_t len = 0;
-        ok = fread(&id, 4, 1, f) == 1 && fread(&nl, 4, 1, f) == 1 && fread(&len, 8, 1, f) == 1 && nl < (1u << 20) && id < MQ_MAX_REF_ID;
+        ok = read_all(fd, &id, 4) && read_all(fd, &nl, 4) && read_all(fd, &len, 8) && nl < (1u << 20) && id < MQ_MAX_REF_ID;
         std::string name(nl, '\0');
-        ok = ok && (nl == 0 || fread(&name[0], 1, nl, f) == nl);
+        ok = ok && (nl == 0 || read_all(fd, &name[0], nl));
         if (ok) idx->refs[id] = std::make_pair(name, len);
     }
+    uint32_t max_id = 0;
+    for (auto &kv : idx->refs) max_id = std::max(max_id, kv.first);
     if (ok && alloc_table(idx, hdr[1]) != MQ_OK) ok = false;
-    const size_t total = (size_t)(hdr[1] + 1) * sizeof(Slot), chunk = 64u << 20;
-    std::vector<uint8_t> buf(std::min(total, chunk));
-    for (size_t o = 0; ok && o < total; o += chunk) {
-        const size_t n = std::min(chunk, total - o);
-        ok = fread(buf.data(), 1, n, f) == n && hipMemcpy((uint8_t *)idx->table + o, buf.data(), n, hipMemcpyHostToDevice) == hipSuccess;
+    // file -> page-locked buffer -> device -> scatter kernel, two buffers deep
+    const size_t total = (size_t)hdr[3] * sizeof(SavedSlot);
+    uint8_t *h_buf[2] = {nullptr, nullptr}, *d_buf[2] = {nullptr, nullptr};
+    uint32_t *d_flags = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    const char *why = "truncated or unreadable index file: ";
+    if (ok && total) {
+        const size_t cb = std::min(total, IX_IO_CHUNK);
+        ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipMalloc((void **)&d_flags, 4) == hipSuccess &&
+             hipMemset(d_flags, 0, 4) == hipSuccess;
+        for (int i = 0; i < 2 && ok; ++i)
+            ok = hipHostMalloc((void **)&h_buf[i], cb, hipHostMallocDefault) == hipSuccess && hipMalloc((void **)&d_buf[i], cb) == hipSuccess &&
+                 hipEventCreate(&ev[i]) == hipSuccess;
+        const size_t n_chunks = (total + IX_IO_CHUNK - 1) / IX_IO_CHUNK;
+        for (size_t c = 0; c < n_chunks && ok; ++c) {
+            const size_t o = c * IX_IO_CHUNK, n = std::min(IX_IO_CHUNK, total - o);
+            if (c >= 2) ok = hipEventSynchronize(ev[c & 1]) == hipSuccess;  // the buffer's previous chunk has left it
+            ok = ok && read_all(fd, h_buf[c & 1], n);
+            if (!ok) break;
+            ok = hipMemcpyAsync(d_buf[c & 1], h_buf[c & 1], n, hipMemcpyHostToDevice, st) == hipSuccess;
+            const uint64_t ns = n / sizeof(SavedSlot);
+            hipLaunchKernelGGL(unpack_slots_kernel, dim3((uint32_t)std::min<uint64_t>((ns + 255) / 256, 1u << 16)), dim3(256), 0, st,
+                               (const SavedSlot *)d_buf[c & 1], ns, idx->table, hdr[1] - 1, max_id, d_flags);
+            ok = ok && hipGetLastError() == hipSuccess && hipEventRecord(ev[c & 1], st) == hipSuccess;
+        }
+        ok = ok && hipStreamSynchronize(st) == hipSuccess;
+        uint32_t flags = 1;
+        ok = ok && hipMemcpy(&flags, d_flags, 4, hipMemcpyDeviceToHost) == hipSuccess;
+        if (ok && flags) {
+            ok = false;
+            why = "corrupt index file (an entry names a reference the file does not have, or a malformed slot): ";
+        }
     }
-    fclose(f);
+    uint8_t extra = 0;
+    if (ok && ::read(fd, &extra, 1) != 0) {
+        ok = false;
+        why = "corrupt index file (bytes after the last slot): ";
+    }
+    ::close(fd);
+    // what the file says about its table must be what the rebuilt table holds
     if (ok) {
-        uint32_t max_id = 0;
-        for (auto &kv : idx->refs) max_id = std::max(max_id, kv.first);
+        unsigned long long *d_acc = nullptr, acc[3] = {0, 0, 0};
+        ok = hipMalloc((void **)&d_acc, 24) == hipSuccess && hipMemset(d_acc, 0, 24) == hipSuccess;
+        if (ok) {
+            const uint64_t nb1 = hdr[1] / 2 + 1;
+            hipLaunchKernelGGL(count_kernel, dim3((uint32_t)std::min<uint64_t>((2 * nb1 + 255) / 256, 1u << 16)), dim3(256), 0, 0, idx->table, nb1, d_acc);
+            ok = hipGetLastError() == hipSuccess && hipMemcpy(acc, d_acc, 24, hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        hipFree(d_acc);
+        if (ok && (acc[1] != hdr[3] || acc[0] != hdr[4] || (acc[2] != 0 && acc[2] - 1 > max_id))) {
+            ok = false;
+            why = "corrupt index file (key counts or reference ids disagree with its header): ";
+        }
+    }
+    if (ok) {
         std::vector<uint64_t> lens((size_t)max_id + 1, 0);
         for (auto &kv : idx->refs) lens[kv.first] = kv.second.second;
         ok = hipMalloc((void **)&idx->d_ref_lens, lens.size() * sizeof(uint64_t)) == hipSuccess &&
              hipMemcpy(idx->d_ref_lens, lens.data(), lens.size() * sizeof(uint64_t), hipMemcpyHostToDevice) == hipSuccess;
     }
+    for (int i = 0; i < 2; ++i) {
+        if (h_buf[i]) hipHostFree(h_buf[i]);
+        hipFree(d_buf[i]);
+        if (ev[i]) hipEventDestroy(ev[i]);
+    }
+    hipFree(d_flags);
+    if (st) hipStreamDestroy(st);
     if (!ok) {
         mq_index_free(idx);
-        set_err(MQ_EINVAL, std::string("truncated or unreadable index file: ") + path);
+        set_err(MQ_EINVAL, std::string(why) + path);
         return nullptr;
     }
     idx->n_kmm_total = hdr[2];
@@ -1217,7 +1469,7 @@ mq_index *mq_index_clone(const mq_index *src, int device) try {
     idx->n_keys = src->n_keys;
     idx->n_unique = src->n_unique;
     bool ok = alloc_table(idx, src->nslots) == MQ_OK;
-    if (ok) ok = hipMemcpyPeer(idx->table, device, src->table, src->device, (size_t)(src->nslots + 1) * sizeof(Slot)) == hipSuccess;
+    if (ok) ok = hipMemcpyPeer(idx->table, device, src->table, src->device, table_bytes_of(src->nslots)) == hipSuccess;
     uint32_t max_id = 0;
     for (auto &kv : idx->refs) max_id = std::max(max_id, kv.first);
     const size_t nl = (size_t)max_id + 1;

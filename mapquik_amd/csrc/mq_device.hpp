@@ -38,14 +38,25 @@ struct DevParams {
     uint32_t fold;  // 1: a-z count as A-Z (to_ascii_uppercase of src/closures.rs:63,106 done here instead of by the caller)
 };
 
-// 32-byte table slot: one aligned 32-B sector per probe.  key==0 <=> empty (a real key 0 lives in the extra slot).
-struct alignas(32) Slot {
-    unsigned long long key;
+// Index table: 64-byte buckets of two 32-byte slots, both keys first so that ONE 16-byte load decides most lookups.
+//   slot s = bucket s >> 1, way s & 1;  key == 0 <=> empty (a real key 0 lives in way 0 of one extra bucket behind the table).
+// Probe sequence of a key (insert and lookup walk the same one; src/index.rs:11-39's identity hasher gives the home slot):
+//   home slot (key & mask), the other way of the home bucket, then the following buckets way 0, way 1, ...
+// A slot is live iff its key matches and pay.end != 0: finalize zeroes `end` of every slot whose key was inserted more than once
+// (the order-independent form of "second insert => tombstone", src/index.rs:94-104; is_empty <=> end == 0, src/index.rs:67-69),
+// so a lookup needs the 16 payload bytes only, and only for a key that matched.
+struct alignas(16) Entry {
     uint32_t start, end, offset, id_rc;
-    uint32_t count;  // times this key was inserted; live iff count == 1 && end != 0 (src/index.rs:67-69,94-104)
+};
+struct alignas(64) Bucket {
+    unsigned long long key[2];
+    Entry pay[2];
+    uint32_t count[2];  // times the key was inserted (kept for the statistics and the on-disk form)
+    uint32_t claims;    // extra bucket only: insertions of the key 0 (its key field cannot tell "present" from "empty")
     uint32_t pad;
 };
-static_assert(sizeof(Slot) == 32, "slot size");
+static_assert(sizeof(Bucket) == 64, "bucket size");
+constexpr uint32_t SLOT_BYTES = 32;  // table bytes per slot
 
 // reference k-min-mer waiting for insertion (same layout as mq_kminmer, rev field = id<<1|rc)
 struct alignas(8) RefKmm {
@@ -233,21 +244,33 @@ __device__ __forceinline__ uint64_t kminmer_hash(uint32_t k, Get get, bool &rev)
 }
 
 // ------------------------------------------------------------------ index probe (ReadOnlyIndex::get, src/index.rs:118-126)
-// table has nslots = mask+1 slots plus one extra slot [nslots] for the key 0.
-__device__ __forceinline__ bool probe_table(const Slot *__restrict__ table, uint64_t mask, uint64_t key, Slot &out) {
+// table has nslots = mask + 1 slots (nslots / 2 buckets) plus one extra bucket [nslots / 2] for the key 0.
+__device__ __forceinline__ uint4 ld_u4(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
+__device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+__device__ __forceinline__ bool probe_table(const Bucket *__restrict__ table, uint64_t mask, uint64_t key, Entry &out) {
+    const uint64_t nb = (mask + 1) >> 1;
     if (key == 0) {
-        out = table[mask + 1];
-        return out.count == 1 && out.end != 0;
+        out = table[nb].pay[0];
+        return out.end != 0;
     }
-    uint64_t s = key & mask;  // identity hasher (src/index.rs:11-39): the key is the table hash
-    for (;;) {
-        Slot v = table[s];
-        if (v.key == key) {
-            out = v;
-            return v.count == 1 && v.end != 0;
+    const uint64_t s0 = key & mask;
+    uint64_t b = s0 >> 1;
+    uint32_t w = (uint32_t)s0 & 1u;
+    for (uint32_t step = 0;; ++step) {
+        const unsigned long long k = table[b].key[w];
+        if (k == key) {
+            out = table[b].pay[w];
+            return out.end != 0;
         }
-        if (v.key == 0) return false;
-        s = (s + 1) & mask;
+        if (k == 0) return false;
+        if (step == 0) {
+            w ^= 1u;  // the other way of the home bucket
+        } else if (step == 1 || w == 1u) {
+            b = b + 1 == nb ? 0 : b + 1;
+            w = 0;
+        } else {
+            w = 1u;
+        }
     }
 }
 
@@ -503,7 +526,7 @@ __device__ __forceinline__ void chain_stage(MatchRec *__restrict__ scratch, uint
 
 // ------------------------------------------------------------------ the map stage's consumer of an ordered minimizer list
 struct MapSink {
-    const Slot *__restrict__ table;
+    const Bucket *__restrict__ table;
     uint64_t mask;
     const DevParams &P;
     MatchRec *__restrict__ scratch;
@@ -518,7 +541,7 @@ struct MapSink {
     uint32_t c_hit = 0, c_id = 0, c_off = 0, c_sigma = 0;  // last element of the previous batch
     uint32_t probe_steps = 0;  // per lane: slots visited beyond the home slot (diagnostic: mean probes per lookup)
 
-    __device__ MapSink(const Slot *t, uint64_t m, const DevParams &p, MatchRec *s, uint32_t cap, mq_kminmer *d, uint32_t dc)
+    __device__ MapSink(const Bucket *t, uint64_t m, const DevParams &p, MatchRec *s, uint32_t cap, mq_kminmer *d, uint32_t dc)
         : table(t), mask(m), P(p), scratch(s), cap_matches(cap), dump(d), dump_cap(dc) {}
 
     // k-min-mer `base + lane` of a minimizer list: canonical orientation, tuple hash, query coordinates
@@ -535,31 +558,83 @@ struct MapSink {
         }
     }
 
-    // first-slot probe issued early (all batches of a read at once): returns the key stored in the home slot
-    __device__ __forceinline__ unsigned long long probe_issue(uint64_t key) const {
-        return table[key == 0 ? mask + 1 : (key & mask)].key;
+    // ---- index probes of a whole chunk of lane-batches, resolved together (ReadOnlyIndex::get, src/index.rs:118-126).
+    // Per (lane, batch) one 16-byte load fetches both keys of the home bucket; every batch's load is in flight before the first is
+    // looked at.  A key that matches gets its 16 payload bytes fetched at once (same 64-byte line: the L2 has it); the few lookups
+    // whose home bucket is full of other keys walk on bucket by bucket in rounds shared by all batches.  Memory latencies a chunk
+    // exposes: one for the keys, one for the payloads, one per extra round (rare) -- not one or more per batch.
+    // state of a lookup, two bits per batch in `st`: 0 = miss, 1 = key found (payload load issued into kk[c]), 3 = walking on
+    __device__ __forceinline__ const Bucket *home_bucket(uint64_t key) const {
+        return table + (key == 0 ? (mask + 1) >> 1 : (key & mask) >> 1);
     }
-    // ReadOnlyIndex::get (src/index.rs:118-126) continuing from an already loaded home-slot key
-    __device__ __forceinline__ bool probe_resolve(uint64_t key, unsigned long long k0, Slot &out) {
-        if (key == 0) {
-            out = table[mask + 1];
-            return out.count == 1 && out.end != 0;
-        }
-        uint64_t s = key & mask;
-        for (;;) {
-            if (k0 == key) {
-                out = table[s];
-                return out.count == 1 && out.end != 0;
+    template <int NB>
+    __device__ __forceinline__ void probe_all(const uint64_t (&key)[NB], uint4 (&kk)[NB], uint32_t actbits, uint32_t &st) {
+        st = 0;
+        const uint64_t nb = (mask + 1) >> 1;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            if ((actbits >> c) & 1u) {
+                const uint64_t k = key[c];
+                const Bucket *B = home_bucket(k);
+                uint32_t way, s2;
+                if (k == 0) {  // the extra bucket's way 0: its payload says whether the key 0 is present
+                    s2 = 1u;
+                    way = 0;
+                } else {
+                    const uint32_t w0 = (uint32_t)k & (uint32_t)mask & 1u;
+                    const uint64_t ka = u64_of(kk[c].x, kk[c].y), kb = u64_of(kk[c].z, kk[c].w);
+                    const uint64_t kh = w0 ? kb : ka, kp = w0 ? ka : kb;
+                    if (kh == k) { s2 = 1u; way = w0; }
+                    else if (kh == 0) { s2 = 0u; way = 0; }
+                    else if (kp == k) { s2 = 1u; way = w0 ^ 1u; probe_steps++; }
+                    else if (kp == 0) { s2 = 0u; way = 0; probe_steps++; }
+                    else { s2 = 3u; way = 0; probe_steps++; }
+                }
+                if (s2 == 1u) kk[c] = ld_u4(&B->pay[way]);
+                st |= s2 << (2 * c);
             }
-            if (k0 == 0) return false;
-            s = (s + 1) & mask;
-            k0 = table[s].key;
-            probe_steps++;
+        }
+        // walking on (about one lookup in a hundred: both ways of the home bucket hold other keys).  Every lane takes ONE of its
+        // walking lookups at a time -- its key by a select over the batches, a loop over the following buckets shared by all lanes,
+        // the outcome written back by a select -- so the rare path holds six registers instead of looping over all NB batches.
+        while (__ballot((st & 0xAAAAAAAAu) != 0)) {
+            const bool walking = (st & 0xAAAAAAAAu) != 0;
+            const uint32_t wc = walking ? ((uint32_t)__builtin_ctz(st & 0xAAAAAAAAu) >> 1) : 0xFFu;  // the lane's first batch in state 3
+            uint64_t k = 0;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) k = wc == (uint32_t)c ? key[c] : k;
+            uint64_t b = (k & mask) >> 1;
+            uint4 res = make_uint4(0, 0, 0, 0);
+            uint32_t s2 = walking ? 3u : 0u;
+            while (__ballot(s2 == 3u)) {
+                if (s2 == 3u) {
+                    b = (b + 1) & (nb - 1);  // a power of two of buckets
+                    const uint4 v = ld_u4(&table[b].key[0]);
+                    const uint64_t ka = u64_of(v.x, v.y), kb = u64_of(v.z, v.w);
+                    uint32_t way = 0;
+                    probe_steps++;
+                    if (ka == k) { s2 = 1u; }
+                    else if (ka == 0) { s2 = 0u; }
+                    else {
+                        probe_steps++;
+                        if (kb == k) { s2 = 1u; way = 1u; }
+                        else if (kb == 0) { s2 = 0u; }
+                    }
+                    if (s2 == 1u) res = ld_u4(&table[b].pay[way]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                if (wc == (uint32_t)c) {
+                    kk[c] = res;
+                    st = (st & ~(3u << (2 * c))) | (s2 << (2 * c));
+                }
+            }
         }
     }
 
     // one batch of n <= 64 consecutive k-min-mers (lane = k-min-mer) with their index entries: dump + Match runs
-    __device__ __forceinline__ void batch_runs(uint32_t n, uint64_t key, bool rev, uint32_t q_start, uint32_t q_end, bool hit, const Slot &e) {
+    __device__ __forceinline__ void batch_runs(uint32_t n, uint64_t key, bool rev, uint32_t q_start, uint32_t q_end, bool hit, const Entry &e) {
         const uint32_t lane = lane_id();
         if (dump && lane < n && kmm_count + lane < dump_cap) {
             mq_kminmer d;
@@ -678,30 +753,36 @@ struct MapSink {
         }
     }
 
-    // All k-min-mers of an ordered minimizer list (have <= 64*NB entries) in one go: every tuple hash first, then all
-    // home-slot probes in flight together (one exposed HBM latency per read instead of one per batch), then the runs.
+    // All k-min-mers of an ordered minimizer list (have <= 64*NB + k - 1 entries) in one go: every tuple hash first, every home
+    // bucket's keys in flight together, the probes resolved together (probe_all), then the runs batch by batch.
     template <int NB>
     __device__ __forceinline__ void consume_list(const unsigned long long *mzh, const uint32_t *mzp, uint32_t have) {
         if (have < P.k) return;
         const uint32_t lane = lane_id();
         const uint32_t K = have - P.k + 1u;
         uint64_t key[NB];
-        unsigned long long k0[NB];
-        uint32_t revbits = 0;
+        uint4 kk[NB];
+        uint32_t revbits = 0, actbits = 0;
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
             key[c] = 0;
-            k0[c] = 0;
+            kk[c] = make_uint4(0, 0, 0, 0);
             if ((uint32_t)c * 64u < K) {
                 const bool act = (uint32_t)c * 64u + lane < K;
                 bool rev;
                 uint32_t qs, qe;
                 batch_keys(mzh, mzp, (uint32_t)c * 64u, act, key[c], rev, qs, qe);
                 revbits |= (rev ? 1u : 0u) << c;
-                if (act) k0[c] = probe_issue(key[c]);
+                if (act) {
+                    actbits |= 1u << c;
+                    kk[c] = ld_u4(&home_bucket(key[c])->key[0]);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // one tuple hash at a time: interleaving NB of them costs ~10 registers each
             }
         }
         mq_clk(6);
+        uint32_t st;
+        probe_all<NB>(key, kk, actbits, st);
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
             if ((uint32_t)c * 64u < K) {
@@ -713,8 +794,12 @@ struct MapSink {
                     qs = mzp[i0];
                     qe = mzp[i0 + P.k - 1] + P.l - 1u;
                 }
-                Slot e = {};
-                const bool hit = act && probe_resolve(key[c], k0[c], e);
+                Entry e;
+                e.start = kk[c].x;
+                e.end = kk[c].y;
+                e.offset = kk[c].z;
+                e.id_rc = kk[c].w;
+                const bool hit = ((st >> (2 * c)) & 3u) == 1u && e.end != 0;
                 batch_runs(n, key[c], ((revbits >> c) & 1u) != 0, qs, qe, hit, e);
             }
         }

@@ -376,17 +376,35 @@ def test_index_save_load_roundtrip(mq, oracle, simlib, tmp_path):
     ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads, dict(k=4, l=20, density=0.02))
     p = str(tmp_path / "ix.mqx")
     ix.save(p)
-    assert os.path.getsize(p) > ix.stats()["table_bytes"]
+    st = ix.stats()
+    size = os.path.getsize(p)
+    # the file holds the occupied slots only (32 B each) behind a small header, not the table
+    assert 32 * st["n_keys"] < size < 32 * st["n_keys"] + 4096 and size < st["table_bytes"] // 4
     ix2 = mq.Index.load(p)
     assert ix2.stats() == ix.stats() and ix2.ref_info(1) == ix.ref_info(1)
     hits2 = ix2.map_batch(reads["bases"], reads["offsets"])
     assert np.array_equal(hits.view(np.uint8), hits2.view(np.uint8))
     rn = simlib.read_names(reads, names)
     assert ix2.paf_lines(rn, reads["offsets"], hits2) == oracle.paf_lines(ox, rn, want)
-    with open(p, "r+b") as f:
-        f.write(b"XXXX")
-    with pytest.raises(mq.MapquikError):
-        mq.Index.load(p)
+    blob = open(p, "rb").read()
+    body = size - 32 * st["n_keys"]  # header + reference table
+
+    def must_fail(data):
+        q = str(tmp_path / "bad.mqx")
+        with open(q, "wb") as f:
+            f.write(data)
+        with pytest.raises(mq.MapquikError):
+            mq.Index.load(q)
+
+    must_fail(b"XXXX" + blob[4:])                                   # not an index file
+    must_fail(blob[:size - 32 * 5])                                  # truncated: fewer slots than the header says
+    must_fail(blob + b"\0" * 32)                                     # bytes after the last slot
+    bad = bytearray(blob)                                            # a slot naming a reference the file does not have
+    bad[body + 12:body + 16] = (0x00FFFFFE).to_bytes(4, "little")    # id_rc of the first saved slot (Entry: start, end, offset, id_rc)
+    must_fail(bytes(bad))
+    dup = bytearray(blob)                                            # the same key twice: the table would hold fewer keys than the header says
+    dup[body + 32:body + 64] = dup[body:body + 32]
+    must_fail(bytes(dup))
 
 
 def test_native_cli_end_to_end_paf_identical(mq, oracle, simlib, tmp_path):
