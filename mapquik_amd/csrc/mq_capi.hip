@@ -82,11 +82,11 @@ __device__ __forceinline__ bool pool_take(const SplitArgs &A, uint32_t cnt, uint
 // seed phase, fast seeder: list length, SD_NOT_FAST (declined: non-ACGT byte, ...) or LIST_OVERFLOW; base moves with the list
 template <int STOP = 0>
 __device__ __forceinline__ uint32_t seed_read_fast(const SplitArgs &A, const SeedTables &T, SeedLds &S, const uint8_t *seq,
-                                                   uint32_t len, uint64_t &base, uint32_t cap, uint32_t &n_moved) {
-    uint32_t cnt = seed_sequence_fast<STOP>(seq, len, A.P, T, S, A.mz_hash + base, A.mz_pos + base, cap);
+                                                   uint32_t len, uint64_t &base, uint32_t cap, uint32_t &n_moved, APre &pre, bool pre_valid) {
+    uint32_t cnt = seed_sequence_fast<STOP>(seq, len, A.P, T, S, A.mz_hash + base, A.mz_pos + base, cap, pre, pre_valid);
     if (cnt != SD_NOT_FAST && cnt > cap) {  // denser than its region: once more, into an exact-size pool region
         if (pool_take(A, cnt, base)) {
-            seed_sequence_fast(seq, len, A.P, T, S, A.mz_hash + base, A.mz_pos + base, cnt);
+            seed_sequence_fast(seq, len, A.P, T, S, A.mz_hash + base, A.mz_pos + base, cnt, pre, false);
             n_moved++;
         } else {
             cnt = LIST_OVERFLOW;
@@ -129,12 +129,20 @@ struct MapListLds {
 };
 
 // map phase of read r: its list (cnt entries at base) -> mq_hit
+// the read's result is left in h (all lanes hold it); store_hit() writes it: the fused kernel does that after it has taken the
+// prefetched offsets of its next read out of their registers, so that this store's acknowledgement is nothing a wave waits for
+__device__ __forceinline__ void store_hit(const SplitArgs &A, uint32_t r, const mq_hit &h) {
+    if (lane_id() == 0) {
+        A.out[r] = h;
+        if (A.dump_counts) A.dump_counts[r] = h.n_kminmers;
+    }
+}
+
 template <int CH, bool TIMING>
 __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, MatchRec *scratch, uint32_t r, uint64_t len, uint32_t cnt,
-                                         uint64_t base, unsigned long long &t_steps, unsigned long long &t_lookups) {
+                                         uint64_t base, unsigned long long &t_steps, unsigned long long &t_lookups, mq_hit &h) {
     const uint32_t lane = lane_id();
     const DevParams &P = A.P;
-    mq_hit h;
     h.status = MQ_HIT_UNMAPPED;
     h.ref_id = h.rc = h.mapq = h.q_start = h.q_end = h.r_start = h.r_end = h.score = h.n_kminmers = 0;
     uint32_t n_kmm = 0;
@@ -198,10 +206,6 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
         }
     }
     h.n_kminmers = n_kmm;
-    if (lane == 0) {
-        A.out[r] = h;
-        if (A.dump_counts) A.dump_counts[r] = n_kmm;
-    }
     mq_clk(9);
 }
 
@@ -247,7 +251,9 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
     mq_clk(-1);
 #endif
     // The work item after the current one is fetched while the current one is processed: its index (one atomic) during the seed
-    // phase, its offsets during the map phase -- two dependent memory round trips per read that no wave waits for.
+    // phase, its offsets during the map phase -- two dependent memory round trips per read that no wave waits for.  (Requesting
+    // the next read's first super-row across the map phase as well was measured at -3 %: a wave's loads return in order, so the
+    // map phase's first wait -- an L2 round trip for the list -- then sits behind an HBM one.)
     uint32_t r = 0;
     if (lane == 0) r = atomicAdd(&A.counters[0], 1u);
     r = rdfirst(r);
@@ -268,7 +274,8 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         } else if (len >= (uint64_t)P.l + P.k - 1u) {
             uint32_t cap;
             list_region(A, o0 - o_base, len, r, base, cap);
-            cnt = A.force_general ? SD_NOT_FAST : seed_read_fast(A, T, S.seed, A.bases + o0, (uint32_t)len, base, cap, n_moved);
+            APre pre;
+            cnt = A.force_general ? SD_NOT_FAST : seed_read_fast(A, T, S.seed, A.bases + o0, (uint32_t)len, base, cap, n_moved, pre, false);
             if (cnt == SD_NOT_FAST) {
                 n_general++;
                 wave_sync();
@@ -289,11 +296,15 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
             if (A.lens) n_len = A.lens[rn];
             else n_o1 = A.offsets[rn + 1];
         }
-        map_read<CH, TIMING>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups);
+        mq_hit h;
+        map_read<CH, TIMING>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h);
         wave_sync();
+        const uint32_t r_done = r;
         r = rn;
         o0 = rdlane64(n_o0, 0);
         len = A.lens ? (uint64_t)rdfirst(n_len) : rdlane64(n_o1, 0) - o0;
+        asm volatile("" ::: "memory");  // the prefetched offsets are out of their registers before the result's store is issued
+        store_hit(A, r_done, h);
     }
     if (lane == 0) {
         if (n_fast) atomicAdd(&A.counters[4], n_fast);
@@ -349,7 +360,8 @@ __global__ __launch_bounds__(64 * SEED_WAVES, MQ_SEED_MIN_WAVES) void seed_reads
         } else if (len >= (uint64_t)P.l + P.k - 1u) {
             uint32_t cap;
             list_region(A, o0 - o_base, len, r, base, cap);
-            cnt = A.force_general ? SD_NOT_FAST : seed_read_fast<STOP>(A, T, S, A.bases + o0, (uint32_t)len, base, cap, n_moved);
+            APre pre;
+            cnt = A.force_general ? SD_NOT_FAST : seed_read_fast<STOP>(A, T, S, A.bases + o0, (uint32_t)len, base, cap, n_moved, pre, false);
             if (cnt == SD_NOT_FAST) n_general++;
             else n_fast++;
         }
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(64) void seed_general_kernel(const SplitArgs A) {
 }
 
 #ifndef MQ_ML_MIN_WAVES
-#define MQ_ML_MIN_WAVES 6
+#define MQ_ML_MIN_WAVES 5
 #endif
 constexpr int ML_WAVES = 4;
 
@@ -414,7 +426,9 @@ __global__ __launch_bounds__(64 * ML_WAVES, MQ_ML_MIN_WAVES) void map_lists_kern
         r = rdfirst(r);
         if (r >= A.n) break;
         const uint64_t len = A.lens ? (uint64_t)A.lens[r] : A.offsets[r + 1] - A.offsets[r];
-        map_read<CH, TIMING>(A, SS[wv], scratch, r, len, A.mz_count[r], A.mz_base[r], t_steps, t_lookups);
+        mq_hit h;
+        map_read<CH, TIMING>(A, SS[wv], scratch, r, len, A.mz_count[r], A.mz_base[r], t_steps, t_lookups, h);
+        store_hit(A, r, h);
         wave_sync();
     }
     if (TIMING && lane == 0) {

@@ -141,40 +141,49 @@ struct Hash2 {
 };
 
 // ------------------------------------------------------------------ stage A
-// One tile: raw bases [raw0, raw_end), raw_end = min(raw0 + 8192, len); the code stream opens with carry_n carried codes.
-// prev_code0: the code before the first base of the sequence when raw0 == 0 (4 = none: the first base is a head).
+// 16 bases at pos; bytes past the end repeat the last base (never a run head under HPC; masked without HPC).  A piece that
+// reaches past the end (only in the sequence's last super-row) is cut out of the 16 bytes that END at len (len >= 16 is the
+// caller's precondition): one load, never a byte beyond the sequence.
+__device__ __forceinline__ uint4 load_piece(const uint8_t *__restrict__ seq, uint32_t len, uint32_t pos) {
+    if (pos + 16u <= len) return *reinterpret_cast<const uint4_unaligned *>(seq + pos);
+    const uint4 v = *reinterpret_cast<const uint4_unaligned *>(seq + (len - 16u));
+    const uint32_t fill = (uint32_t)seq[len - 1] * 0x01010101u;
+    const uint32_t nv = pos < len ? len - pos : 0u;  // valid bytes: 0..15
+    const uint32_t s = 16u - nv;                      // shift the 32-byte value [v, fill...] right by s bytes
+    uint32_t w0 = v.x, w1 = v.y, w2 = v.z, w3 = v.w;
+    if (s & 4u) { w0 = w1; w1 = w2; w2 = w3; w3 = fill; }
+    if (s & 8u) { w0 = w2; w1 = w3; w2 = fill; w3 = fill; }
+    if (s & 16u) { w0 = fill; w1 = fill; w2 = fill; w3 = fill; }
+    const uint32_t sb = s & 3u;
+    return make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sb), __builtin_amdgcn_alignbyte(w2, w1, sb),
+                      __builtin_amdgcn_alignbyte(w3, w2, sb), __builtin_amdgcn_alignbyte(fill, w3, sb));
+}
+
+// The first super-row of a tile, on its way from HBM: requested by whoever ran before the tile's stage A (the previous tile's
+// stage A for the stages B and R in between, the previous read's seed phase for its map phase), so that no tile opens with an
+// exposed HBM round trip.  64 bases per lane = 16 registers.
+struct APre {
+    uint4 nx0, nx1, nx2, nx3;
+};
+__device__ __forceinline__ void stage_a_request(const uint8_t *__restrict__ seq, uint32_t len, uint32_t raw0, APre &pre) {
+    const uint32_t pos = raw0 + lane_id() * 64u;
+    pre.nx0 = load_piece(seq, len, pos);
+    pre.nx1 = load_piece(seq, len, pos + 16u);
+    pre.nx2 = load_piece(seq, len, pos + 32u);
+    pre.nx3 = load_piece(seq, len, pos + 48u);
+}
+
+// One tile: raw bases [raw0, raw_end), raw_end = min(raw0 + SD_TILE_RAW, len); the code stream opens with carry_n carried codes.
+// pre holds the tile's first super-row (stage_a_request) and leaves with the next tile's when the sequence goes on.
 // Returns false on a byte other than A C G T.
 __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, uint32_t len, uint32_t raw0, uint32_t carry_n,
                                              uint32_t &carry_prev, bool use_hpc, bool fold, const SeedTables &T, SeedLds &S, uint32_t &n_codes,
-                                             uint32_t &n_blocks, uint32_t &raw_end) {
+                                             uint32_t &n_blocks, uint32_t &raw_end, APre &pre) {
     const uint32_t lane = lane_id();
     uint32_t n_sr = (len - raw0 + SD_SR_RAW - 1u) / SD_SR_RAW;
     if (n_sr > SD_MAX_SR) n_sr = SD_MAX_SR;
-    const uint32_t fill = (uint32_t)seq[len - 1] * 0x01010101u;
-    // 16 bases at pos; bytes past the end repeat the last base (never a run head under HPC; masked without HPC).  A piece that
-    // reaches past the end (only in the sequence's last super-row) is cut out of the 16 bytes that END at len (len >= 16 is the
-    // caller's precondition): one load, never a byte beyond the sequence.
-    auto load_piece = [&](uint32_t pos) -> uint4 {
-        if (pos + 16u <= len) return *reinterpret_cast<const uint4_unaligned *>(seq + pos);
-        const uint4 v = *reinterpret_cast<const uint4_unaligned *>(seq + (len - 16u));
-        const uint32_t nv = pos < len ? len - pos : 0u;  // valid bytes: 0..15
-        const uint32_t s = 16u - nv;                      // shift the 32-byte value [v, fill...] right by s bytes
-        uint32_t w0 = v.x, w1 = v.y, w2 = v.z, w3 = v.w;
-        if (s & 4u) { w0 = w1; w1 = w2; w2 = w3; w3 = fill; }
-        if (s & 8u) { w0 = w2; w1 = w3; w2 = fill; w3 = fill; }
-        if (s & 16u) { w0 = fill; w1 = fill; w2 = fill; w3 = fill; }
-        const uint32_t sb = s & 3u;
-        return make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sb), __builtin_amdgcn_alignbyte(w2, w1, sb),
-                          __builtin_amdgcn_alignbyte(w3, w2, sb), __builtin_amdgcn_alignbyte(fill, w3, sb));
-    };
-    uint4 nx0, nx1, nx2, nx3;
-    {
-        const uint32_t pos = raw0 + lane * 64u;
-        nx0 = load_piece(pos);
-        nx1 = load_piece(pos + 16u);
-        nx2 = load_piece(pos + 32u);
-        nx3 = load_piece(pos + 48u);
-    }
+    const uint32_t tile_end = raw0 + n_sr * SD_SR_RAW;  // >= len in the sequence's last tile
+    uint4 &nx0 = pre.nx0, &nx1 = pre.nx1, &nx2 = pre.nx2, &nx3 = pre.nx3;
     for (uint32_t i = lane * 4u; i < SD_CODES_DW; i += 256u) *reinterpret_cast<uint4 *>(&S.codes[i]) = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (uint32_t w = 0; w < SD_FLAG_BLKS / 4u; ++w) S.flags[lane * (SD_FLAG_BLKS / 4u) + w] = 0ull;  // stage B sets bits in its own blocks only
@@ -186,7 +195,7 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
     constexpr uint32_t S1 = 0x00430041u, S0 = 0x00470054u;  // v_perm pool: selector 0,2 -> 'A','C' ; 4,6 -> 'T','G'
     for (uint32_t sr = 0; sr < n_sr; ++sr) {
         const uint32_t pos = raw0 + sr * SD_SR_RAW + lane * 64u;
-        const bool more_sr = sr + 1u < n_sr;
+        const bool more_sr = sr + 1u < n_sr || tile_end < len;  // the tile's last super-row requests the next tile's first
         uint32_t p[4];
         // decode piece j, then send the load of the NEXT super-row's piece j into the registers just freed: 16 registers of
         // bases in flight plus the piece being decoded, instead of two whole super-rows
@@ -196,7 +205,7 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
             bad |= (__builtin_amdgcn_perm(S0, S1, t0) ^ nx.x) | (__builtin_amdgcn_perm(S0, S1, t1) ^ nx.y) |
                    (__builtin_amdgcn_perm(S0, S1, t2) ^ nx.z) | (__builtin_amdgcn_perm(S0, S1, t3) ^ nx.w);
             p[j] = pack16(t0, t1, t2, t3);
-            if (more_sr) nx = load_piece(pos + SD_SR_RAW + 16u * j);
+            if (more_sr) nx = load_piece(seq, len, pos + SD_SR_RAW + 16u * j);
         };
         decode(nx0, 0);
         decode(nx1, 1);
@@ -509,16 +518,20 @@ __device__ __forceinline__ uint32_t seed_stage_r(const SeedTables &T, SeedLds &S
 // STOP (diagnostic builds of the split pipeline only, never a product path): 1 = stage A only, 2 = stages A and B; the lists are
 // then incomplete on purpose: a profiler attributes instructions and time to the stages by difference.
 constexpr uint32_t SD_NOT_FAST = 0xFFFFFFFFu;
+// a sequence the fast path takes at all (stage A reads whole 16-byte pieces; its tail piece is the 16 bytes that end at len)
+__device__ __forceinline__ bool seed_fast_eligible(uint64_t len) { return len >= 16u && (len >> 32) == 0; }
+// pre / pre_valid: the sequence's first super-row already requested by the caller (stage_a_request); else it is requested here.
 template <int STOP = 0>
 __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict__ seq, uint32_t len, const DevParams &P, const SeedTables &T,
                                                        SeedLds &S, unsigned long long *__restrict__ mz_hash,
-                                                       uint32_t *__restrict__ mz_pos, uint32_t out_cap) {
+                                                       uint32_t *__restrict__ mz_pos, uint32_t out_cap, APre &pre, bool pre_valid) {
     const uint32_t lane = lane_id();
     uint32_t raw0 = 0, carry_n = 0, carry_prev = 0, n_out = 0;
-    if (len < 16u) return SD_NOT_FAST;  // stage A reads whole 16-byte pieces (its tail piece is the 16 bytes that end at len)
+    if (!seed_fast_eligible(len)) return SD_NOT_FAST;
+    if (!pre_valid) stage_a_request(seq, len, 0, pre);
     while (raw0 < len) {
         uint32_t n_codes = 0, n_blocks = 0, raw_end = 0;
-        const bool ok = seed_stage_a(seq, len, raw0, carry_n, carry_prev, P.use_hpc != 0, P.fold != 0, T, S, n_codes, n_blocks, raw_end);
+        const bool ok = seed_stage_a(seq, len, raw0, carry_n, carry_prev, P.use_hpc != 0, P.fold != 0, T, S, n_codes, n_blocks, raw_end, pre);
         mq_clk(0);
         if (!ok) return SD_NOT_FAST;
         const bool more = raw_end < len;
