@@ -43,9 +43,14 @@ def parse():
                     help="weak (default, the BASELINE metric): every rank maps its own HBM-resident batch of --reads reads; strong: ONE fixed "
                          "read set of --reads reads in host memory is dealt to the ranks (mapquik_amd.shard) and mapped through the "
                          "host-buffer stream slots, PCIe included")
+    ap.add_argument("--k", type=int, default=5, help="k-min-mer order (BASELINE config 4, experiments/table1.sh:50, runs -k 7)")
+    ap.add_argument("--l", type=int, default=31)
+    ap.add_argument("--density", type=float, default=0.01)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end measurements (host buffers -> hits, file -> PAF)")
     ap.add_argument("--e2e-file-reads", type=int, default=196608, help="reads written to the FASTA the native driver maps")
+    ap.add_argument("--e2e-fastq-reads", type=int, default=786432,
+                    help="reads of the FASTQ + -k 7 leg (BASELINE config 4's shape, experiments/table1.sh:50-55): 786,432 reads = 18.5 Gbases; 0 = skip")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     return ap.parse_args()
 
@@ -109,34 +114,40 @@ def measure_host_buffers(mq, ix, reads, passes=2):
     return float(reads["offsets"][-1]) / dt / 1e9, hits
 
 
-def measure_file_to_paf(mq, genome, ctg_off, ctg_names, reads, n_reads, threads, workdir):
-    """End to end through the native driver (mapquik_amd/lib/mapquik): reference FASTA + reads FASTA on disk -> <prefix>.paf.
-    Returns dict(gbases_s over the driver's own 'Mapped query sequences' phase, seconds, paf_lines)."""
-    import re
-    import subprocess
-    from mapquik_amd import build as B
-    exe = B.build_cli()
-    ref = os.path.join(workdir, "ref.fa")
-    rd = os.path.join(workdir, "reads.fa")
-    with open(ref, "wb") as f:
+def write_reference(genome, ctg_off, ctg_names, path):
+    with open(path, "wb") as f:
         for r in range(len(ctg_names)):
             f.write(b">" + ctg_names[r].encode() + b"\n")
             genome[int(ctg_off[r]):int(ctg_off[r + 1])].tofile(f)
             f.write(b"\n")
+
+
+def measure_file_to_paf(ref, reads, n_reads, threads, workdir, fastq=False, extra_args=(), compress=None):
+    """End to end through the native driver (mapquik_amd/lib/mapquik): reference FASTA + reads file on disk -> <prefix>.paf.
+    fastq: the reads as a FASTQ file; compress="gz": as a plain gzip stream.  Three runs: one to bring the files into the page cache,
+    the driver's default (the read feeder starts while the reference is indexed) and the strict one (MQ_DRIVER_NO_PREFETCH=1:
+    nothing of the reads is touched before the index is ready).  Rates over the driver's own 'Mapped query sequences' phase."""
+    import re
+    import subprocess
+    from mapquik_amd import build as B
+    from tools import sim
+    exe = B.build_cli()
     offs = reads["offsets"]
     n_reads = min(n_reads, offs.size - 1)
-    with open(rd, "wb") as f:
-        for i in range(n_reads):
-            f.write(b">r%d\n" % i)
-            reads["bases"][int(offs[i]):int(offs[i + 1])].tofile(f)
-            f.write(b"\n")
+    rd = os.path.join(workdir, "reads.fastq" if fastq else "reads.fa")
+    file_bytes = sim.write_fastx(rd, reads["bases"], offs, n_reads, fastq=fastq, threads=threads)
+    if compress == "gz":
+        subprocess.run(["gzip", "-1", "-f", rd], check=True)
+        rd += ".gz"
     bases = int(offs[n_reads])
-    out = {"reads": n_reads, "bases": bases, "threads": threads}
+    out = {"reads": n_reads, "bases": bases, "file_bytes": file_bytes, "threads": threads, "format": ("FASTQ" if fastq else "FASTA") + (".gz" if compress else ""),
+           "args": " ".join(extra_args)}
+    prefix = os.path.join(workdir, "e2e")
 
     def run(env):
         t0 = time.perf_counter()
-        r = subprocess.run([exe, rd, "--reference", ref, "-p", os.path.join(workdir, "e2e"), "--threads", str(threads)],
-                           capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        r = subprocess.run([exe, rd, "--reference", ref, "-p", prefix, "--threads", str(threads)] + list(extra_args),
+                           capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
         wall = time.perf_counter() - t0
         if r.returncode != 0:
             raise RuntimeError((r.stderr or r.stdout)[-300:])
@@ -147,21 +158,39 @@ def measure_file_to_paf(mq, genome, ctg_off, ctg_names, reads, n_reads, threads,
         t_idx = float(mi.group(1)) * unit.get(mi.group(2), 1.0) if mi else float("nan")
         return t_map, t_idx, wall
 
-    run({})  # first run: files enter the page cache
-    t_map, t_idx, wall = run({})
-    # the driver's default behaviour: the read feeder starts while the reference is indexed, so the map phase finds parsed chunks waiting
-    out.update(gbases_s=round(bases / t_map / 1e9, 3), map_phase_s=round(t_map, 4), index_phase_s=round(t_idx, 3), driver_wall_s=round(wall, 2),
-               whole_job_gbases_s=round(bases / wall / 1e9, 3))
-    t_map2, _, wall2 = run({"MQ_DRIVER_NO_PREFETCH": "1"})  # strict: nothing of the reads is touched before the index is ready
-    out.update(no_prefetch_gbases_s=round(bases / t_map2 / 1e9, 3), no_prefetch_map_phase_s=round(t_map2, 4), no_prefetch_driver_wall_s=round(wall2, 2))
-    with open(os.path.join(workdir, "e2e.paf"), "rb") as f:
-        out["paf_lines"] = sum(1 for _ in f)
-    for fn in ("ref.fa", "reads.fa", "e2e.paf"):
-        try:
-            os.remove(os.path.join(workdir, fn))
-        except OSError:
-            pass
+    try:
+        run({})  # first run: files enter the page cache
+        t_map, t_idx, wall = run({})
+        out.update(gbases_s=round(bases / t_map / 1e9, 3), map_phase_s=round(t_map, 4), index_phase_s=round(t_idx, 3), driver_wall_s=round(wall, 2),
+                   whole_job_gbases_s=round(bases / wall / 1e9, 3))
+        t_map2, t_idx2, wall2 = run({"MQ_DRIVER_NO_PREFETCH": "1"})
+        out.update(no_prefetch_gbases_s=round(bases / t_map2 / 1e9, 3), no_prefetch_map_phase_s=round(t_map2, 4), no_prefetch_index_phase_s=round(t_idx2, 3),
+                   no_prefetch_driver_wall_s=round(wall2, 2))
+        with open(prefix + ".paf", "rb") as f:
+            out["paf_lines"] = sum(1 for _ in f)
+    finally:
+        for fn in (rd, prefix + ".paf"):
+            try:
+                os.remove(fn)
+            except OSError:
+                pass
     return out
+
+
+def measure_index_file(mq, ix, P, device, workdir):
+    """The on-disk index (occupied slots only): save, load (file in the page cache -> finalized table on the device), sizes."""
+    p = os.path.join(workdir, "index.mqx")
+    t0 = time.perf_counter()
+    ix.save(p)
+    t_save = time.perf_counter() - t0
+    size = os.path.getsize(p)
+    t0 = time.perf_counter()
+    ix2 = mq.Index.load(p, device=device)
+    t_load = time.perf_counter() - t0
+    same = ix2.stats() == ix.stats()
+    ix2.close()
+    os.remove(p)
+    return dict(file_bytes=size, save_s=round(t_save, 3), load_s=round(t_load, 3), stats_identical_after_load=bool(same))
 
 
 def main():
@@ -189,7 +218,7 @@ def main():
 
     ncpu = effective_cpus()
     threads = max(1, ncpu // world)
-    P = mq.Params()  # k=5 l=31 d=0.01 HPC on, c=4 s=11 g=2000 (src/main.rs:174-188)
+    P = mq.Params(k=args.k, l=args.l, density=args.density)  # defaults k=5 l=31 d=0.01, HPC on, c=4 s=11 g=2000 (src/main.rs:174-188)
 
     # ---- genome (same on every rank: the index is replicated)
     t0 = time.time()
@@ -326,7 +355,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        po = O.params()
+        po = O.params(k=args.k, l=args.l, density=args.density)
         t0 = time.time()
         ox = O.Index()
         ox.build_mt(genome, ctg_off, ctg_names, po, ncpu)
@@ -335,29 +364,34 @@ def main():
         sb = reads["bases"][:int(offs[ns])]
         so = offs[:ns + 1]
 
-        def timed(nthreads, budget_cpu_s):
-            t0 = time.time()
-            w = ox.map_batch(sb, so, po, threads=nthreads)
-            t_first = time.time() - t0
-            reps = max(1, min(50, int(budget_cpu_s / max(t_first * nthreads, 1e-3))))
-            t0 = time.time()
-            for _ in range(reps):
+        def timed(nthreads, min_wall_s=5.0, min_passes=3):
+            """>= min_passes passes and >= min_wall_s of wall time at this thread count: (median s/pass, min, max, passes, last result)."""
+            ts, w = [], None
+            ox.map_batch(sb, so, po, threads=nthreads)  # untimed: page in, thread start-up
+            while len(ts) < min_passes or sum(ts) < min_wall_s:
+                t0 = time.perf_counter()
                 w = ox.map_batch(sb, so, po, threads=nthreads)
-            return (time.time() - t0) / reps, reps, w
+                ts.append(time.perf_counter() - t0)
+                if len(ts) >= 60:
+                    break
+            return float(np.median(ts)), min(ts), max(ts), len(ts), w
 
         # all granted cores, and 10 threads (the reference's own benchmark setting, experiments/figure-k-l/get_mapstats.sh:6)
-        t_cpu, reps, want = timed(ncpu, 14.0)
-        t10, reps10, _ = timed(10, 8.0)
+        t_cpu, t_lo, t_hi, reps, want = timed(ncpu)
+        t10, t10_lo, t10_hi, reps10, _ = timed(10)
         m = want["mapped"] != 0
         same = bool(np.array_equal(hits["status"][:ns] == 1, m)) and all(
             np.array_equal(hits[a][:ns][m].astype(np.uint64), want[a][m].astype(np.uint64))
             for a in ("ref_id", "rc", "mapq", "q_start", "q_end", "r_start", "r_end", "score"))
-        cpu = dict(value=round(int(so[-1]) / t_cpu / 1e9, 4), unit="Gbases/s", cores=ncpu, kind="port",
-                   sample="first %d reads (%d bases) of the step batch x %d passes, C oracle with %d pthreads "
-                          "(cgroup CPU quota of the box), index build (%.1f s) excluded" % (ns, int(so[-1]), reps, ncpu, t_cpu_index),
+        sb_bases = int(so[-1])
+        cpu = dict(value=round(sb_bases / t_cpu / 1e9, 4), unit="Gbases/s", cores=ncpu, kind="port",
+                   sample="first %d reads (%d bases) of the step batch, C oracle with %d pthreads (cgroup CPU quota of the box), median of %d "
+                          "passes (%.1f s), index build (%.1f s) excluded" % (ns, sb_bases, ncpu, reps, t_cpu * reps, t_cpu_index),
+                   passes=reps, spread=dict(best=round(sb_bases / t_lo / 1e9, 4), worst=round(sb_bases / t_hi / 1e9, 4)),
                    seconds=round(t_cpu * reps, 2), paf_columns_identical_to_gpu=same, unique_kminmers_equal=bool(ox.count() == n_unique),
-                   at_10_threads=dict(value=round(int(so[-1]) / t10 / 1e9, 4), threads=10, passes=reps10,
-                                      note="10 pthreads on %d granted cores; mirrors --threads 10 of experiments/figure-k-l/get_mapstats.sh:6" % ncpu),
+                   at_10_threads=dict(value=round(sb_bases / t10 / 1e9, 4), threads=10, passes=reps10,
+                                      spread=dict(best=round(sb_bases / t10_lo / 1e9, 4), worst=round(sb_bases / t10_hi / 1e9, 4)),
+                                      note="median; 10 pthreads on %d granted cores; mirrors --threads 10 of experiments/figure-k-l/get_mapstats.sh:6" % ncpu),
                    published=dict(value=1.56, unit="Gbases/s", threads=10, seconds=19.98,
                                   source="experiments/figure-k-l/k_perf.csv:5 (k=5: 19.98 s for CHM13 10X, ~31.2 Gbases; the reference's own "
                                          "run on its authors' machine, Rust path, not measured here)"))
@@ -373,18 +407,44 @@ def main():
         e2e["host_buffers_hits_identical"] = bool(np.array_equal(h_e2e.view(np.uint8), hits.view(np.uint8)))
         e2e["host_buffers_note"] = "page-locked reads -> mq_ctx_submit/wait on 3 stream slots, 16,384-read sub-batches -> hits in host memory; PCIe-bound at 1 B/base"
         base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        kargs = ["-k", str(args.k), "-l", str(args.l), "-d", repr(args.density)]
         with tempfile.TemporaryDirectory(dir=base) as wd:
+            ref = os.path.join(wd, "ref.fa")
+            write_reference(genome, ctg_off, ctg_names, ref)
+
+            def leg(name, **kw):
+                try:
+                    e2e[name] = measure_file_to_paf(ref, **kw)
+                except Exception as ex:  # noqa: BLE001
+                    e2e[name] = {"error": repr(ex)[:300]}
+
+            # the step batch as a FASTA file, at the bench's own parameters
+            leg("file_to_paf", reads=reads, n_reads=args.e2e_file_reads, threads=ncpu, workdir=wd, extra_args=kargs)
+            e2e["file_to_paf_gbases_s"] = e2e["file_to_paf"].get("gbases_s")
+            # a plain gzip stream of a quarter of it (get_reader's .gz branch, src/main.rs:60-75)
+            leg("gz_to_paf", reads=reads, n_reads=max(1, args.e2e_file_reads // 4), threads=ncpu, workdir=wd, extra_args=kargs, compress="gz")
             try:
-                e2e["file_to_paf"] = measure_file_to_paf(mq, genome, ctg_off, ctg_names, reads, args.e2e_file_reads, ncpu, wd)
-                e2e["file_to_paf_gbases_s"] = e2e["file_to_paf"].get("gbases_s")
+                e2e["index_file"] = measure_index_file(mq, ix, P, local_rank, wd)
             except Exception as ex:  # noqa: BLE001
-                e2e["file_to_paf"] = {"error": repr(ex)[:300]}
-                e2e["file_to_paf_gbases_s"] = None
+                e2e["index_file"] = {"error": repr(ex)[:300]}
+            # BASELINE config 4's shape (experiments/table1.sh:50-55): uncompressed FASTQ reads, -k 7 -l 31 -d 0.01, and the same
+            # reads as FASTA for the ratio
+            if args.e2e_fastq_reads > 0:
+                try:
+                    big = reads if args.e2e_fastq_reads <= n else sim.make_reads(genome, ctg_off, args.e2e_fastq_reads, seed=args.seed + 5000, threads=threads)
+                    k7 = ["-k", "7", "-l", "31", "-d", "0.01"]
+                    leg("fastq_k7_to_paf", reads=big, n_reads=args.e2e_fastq_reads, threads=ncpu, workdir=wd, fastq=True, extra_args=k7)
+                    leg("fasta_k7_to_paf", reads=big, n_reads=args.e2e_fastq_reads, threads=ncpu, workdir=wd, fastq=False, extra_args=k7)
+                    a_, b_ = e2e["fastq_k7_to_paf"].get("no_prefetch_gbases_s"), e2e["fasta_k7_to_paf"].get("no_prefetch_gbases_s")
+                    e2e["fastq_over_fasta_rate"] = round(a_ / b_, 3) if a_ and b_ else None
+                    del big
+                except Exception as ex:  # noqa: BLE001
+                    e2e["fastq_k7_to_paf"] = {"error": repr(ex)[:300]}
 
     if rank == 0:
         value = all_bases * args.steps / elapsed / 1e9
         line = {
-            "metric": "Gbases/s mapped (sim CHM13v2-like HiFi, k=5 l=31 d=0.01)",
+            "metric": "Gbases/s mapped (sim CHM13v2-like HiFi, k=%d l=%d d=%g)" % (args.k, args.l, args.density),
             "value": round(value, 3),
             "unit": "Gbases/s",
             "n_gpus": world,
@@ -398,8 +458,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "CHM13v2.0-like synthetic genome (25 contigs, %.3f Gbp, scale %.3g, %g%% planted repeats) "
-                            "x pbsim-like HiFi reads (mean 24 kb, 1%% error); k=5 l=31 d=0.01 HPC"
-                            % (sum(lens) / 1e9, args.genome_scale, 100 * args.repeat_frac),
+                            "x pbsim-like HiFi reads (mean 24 kb, 1%% error); k=%d l=%d d=%g HPC"
+                            % (sum(lens) / 1e9, args.genome_scale, 100 * args.repeat_frac, args.k, args.l, args.density),
                 "reads_per_step_per_gpu": n,
                 "bases_per_step_per_gpu": total_bases,
                 "index_unique_kminmers": int(n_unique),

@@ -62,8 +62,7 @@ def read_fastx(path, fasta):
                 if line.startswith(b">"):
                     if name is not None:
                         yield name, b"".join(chunks).upper()
-                    hdr = line[1:].split()
-                    name, chunks = (hdr[0].decode() if hdr else ""), []
+                    name, chunks = line[1:].split(b" ", 1)[0].decode(), []  # seq_io's id(): up to the first SPACE (src/closures.rs:107)
                 elif name is not None:
                     chunks.append(line)
             if name is not None:
@@ -76,8 +75,7 @@ def read_fastx(path, fasta):
                 s = fh.readline().rstrip(b"\r\n")
                 fh.readline()
                 fh.readline()
-                hdr = h[1:].split()
-                yield (hdr[0].decode() if hdr else ""), s.upper()
+                yield h.rstrip(b"\r\n")[1:].split(b" ", 1)[0].decode(), s.upper()
 
 
 def build_parser():

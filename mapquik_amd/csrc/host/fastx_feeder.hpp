@@ -9,6 +9,9 @@
 // streams are sequential by nature) and parsed by the others; BGZF (bgzip) files are the exception: their blocks are
 // independent deflate streams with their sizes in the headers, so the file is indexed once and then read like a raw file,
 // every reader thread inflating the blocks of its own chunk.  Multi-line FASTA records are compacted in place.
+// Uncompressed FASTQ is the exception to "raw bytes as they are": half of such a file is quality values nobody reads, so the
+// file is mapped and every reader copies the header and sequence lines of its records only -- the quality lines are never
+// touched (not read from the page cache, not copied, not sent over PCIe).
 #pragma once
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -121,9 +124,10 @@ inline void parse_chunk(Chunk &c, bool fastq) {
         const uint8_t *e = (const uint8_t *)memchr(b + from, '\n', end - from);
         return e ? (uint64_t)(e - b) : end;
     };
-    auto add_id = [&](uint64_t h0, uint64_t h1) {  // first word after the marker (seq_io's id())
+    auto add_id = [&](uint64_t h0, uint64_t h1) {  // seq_io's id(): the header line up to its first SPACE (a TAB is part of the id)
+        if (h1 > h0 + 1 && b[h1 - 1] == '\r') --h1;  // CR-LF files: the CR is not part of the line
         uint64_t s = h0 + 1, e = s;
-        while (e < h1 && b[e] != ' ' && b[e] != '\t' && b[e] != '\r') ++e;
+        while (e < h1 && b[e] != ' ') ++e;
         c.ids.push_back({s, (uint32_t)(e - s)});
     };
     while (p < end) {
@@ -136,6 +140,7 @@ inline void parse_chunk(Chunk &c, bool fastq) {
             const uint64_t e2 = line_end(s);
             uint64_t sl = e2 - s;
             if (sl && b[s + sl - 1] == '\r') --sl;
+            if (sl >= (1ull << 32)) throw FeederError("sequence length must be < 2^32");
             c.starts.push_back(s);
             c.lens.push_back((uint32_t)sl);
             const uint64_t e3 = e2 < end ? line_end(e2 + 1) : end;                 // '+' line
@@ -210,6 +215,14 @@ class Feeder {
         fstat(fd_, &st);
         file_size_ = (uint64_t)st.st_size;
         if (kind_ == 1 && index_bgzf()) kind_ = 3;  // logical (inflated) size from here on; chunked and read like a raw file
+        if (kind_ == 0 && fastq_ && file_size_ > 0 && !getenv("MQ_FEEDER_NO_LEAN_FASTQ")) {
+            const uint8_t *m = (const uint8_t *)mmap(nullptr, file_size_, PROT_READ, MAP_SHARED, fd_, 0);
+            if (m != MAP_FAILED) {
+                map_ = m;
+                map_size_ = file_size_;
+                lean_fastq_ = true;
+            }
+        }
         if (kind_ == 0 || kind_ == 3) {
             if (chunk_bytes_ > file_size_ + 1) chunk_bytes_ = file_size_ + 1;
             n_raw_chunks_ = (size_t)((file_size_ + chunk_bytes_ - 1) / chunk_bytes_);
@@ -223,7 +236,9 @@ class Feeder {
     }
 
     void start() {
-        if (kind_ == 0 || kind_ == 3) {
+        if (lean_fastq_) {
+            for (int t = 0; t < n_threads_; ++t) threads_.emplace_back([this] { lean_fastq_worker(); });
+        } else if (kind_ == 0 || kind_ == 3) {
             for (int t = 0; t < n_threads_; ++t) threads_.emplace_back([this] { raw_worker(); });
         } else {
             threads_.emplace_back([this] { inflate_worker(); });
@@ -231,10 +246,22 @@ class Feeder {
         }
     }
 
+    // the consumer gives up (an error elsewhere in its pipeline): next() returns nullptr from now on, workers waiting for a buffer
+    // leave; chunks still held by the consumer need not be recycled
+    void abort() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            aborted_ = true;
+            stopping_ = true;
+        }
+        cv_.notify_all();
+    }
+
     // next parsed chunk (any order; seq_no says where it belongs) or nullptr at the end of the input
     Chunk *next() {
         std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return !ready_.empty() || finished_locked() || !error_.empty(); });
+        cv_.wait(lk, [&] { return aborted_ || !ready_.empty() || finished_locked() || !error_.empty(); });
+        if (aborted_) return nullptr;
         if (!error_.empty()) throw FeederError(error_);
         if (ready_.empty()) return nullptr;
         Chunk *c = ready_.front();
@@ -361,6 +388,79 @@ class Feeder {
         worker_done(err);
     }
 
+    // uncompressed FASTQ: chunk i owns the records whose first byte lies in [i*CH, (i+1)*CH) of the mapped file and copies their
+    // header and sequence lines ("@id ...\nSEQ\n") into its buffer; '+' and quality lines stay where they are, untouched
+    void lean_fastq_worker() {
+        std::string err;
+        try {
+            const uint8_t *m = map_;
+            const uint64_t end = file_size_;
+            auto line_end = [&](uint64_t from) -> uint64_t {
+                const uint8_t *e = (const uint8_t *)memchr(m + from, '\n', end - from);
+                return e ? (uint64_t)(e - m) : end;
+            };
+            for (;;) {
+                Chunk *c = get_buffer(std::min<uint64_t>(chunk_bytes_ / 2 + (1u << 20) + 2, file_size_ + 2));
+                const size_t i = next_raw_.fetch_add(1);
+                if (i >= n_raw_chunks_) {
+                    recycle(c);
+                    break;
+                }
+                const uint64_t lo = (uint64_t)i * chunk_bytes_, hi = std::min<uint64_t>(lo + chunk_bytes_, file_size_);
+                // [first, last): from the first record start at or after lo to the first one at or after hi -- the same cut as the
+                // chunked reader's, so that a last record the validator cannot vouch for (CR-LF file without a final newline)
+                // stays with its predecessor
+                uint64_t p = lo ? next_record_start(m, lo, end, true, true) : 0;
+                const uint64_t last = hi < end ? next_record_start(m, hi, end, true, true) : end;
+                if (p >= hi) p = last;  // no record starts in this chunk
+                uint64_t w = 0;  // bytes written to the chunk
+                while (p < last) {
+                    if (m[p] == '\n' || m[p] == '\r') { ++p; continue; }
+                    if (m[p] != '@') throw FeederError("malformed FASTQ record");
+                    const uint64_t e1 = line_end(p);                      // header
+                    const uint64_t s = e1 + 1 < end ? e1 + 1 : end;
+                    const uint64_t e2 = line_end(s);                      // sequence
+                    uint64_t sl = e2 - s;
+                    if (sl && m[s + sl - 1] == '\r') --sl;
+                    if (sl >= (1ull << 32)) throw FeederError("sequence length must be < 2^32");
+                    const uint64_t need = (e1 - p) + 1 + sl + 1;
+                    if (w + need > c->cap) {  // a record longer than the buffer: a private, larger one
+                        Chunk *big = get_buffer(std::max<uint64_t>(w + need, 2 * c->cap), true);
+                        if (w) memcpy(big->buf, c->buf, w);
+                        big->starts.swap(c->starts);
+                        big->lens.swap(c->lens);
+                        big->ids.swap(c->ids);
+                        recycle(c);
+                        c = big;
+                    }
+                    uint64_t h1 = e1;
+                    if (h1 > p + 1 && m[h1 - 1] == '\r') --h1;
+                    memcpy(c->buf + w, m + p, h1 - p);
+                    uint64_t ie = 1;
+                    while (ie < h1 - p && c->buf[w + ie] != ' ') ++ie;  // seq_io's id(): up to the first space
+                    c->ids.push_back({w + 1, (uint32_t)(ie - 1)});
+                    w += h1 - p;
+                    c->buf[w++] = '\n';
+                    memcpy(c->buf + w, m + s, sl);
+                    c->starts.push_back(w);
+                    c->lens.push_back((uint32_t)sl);
+                    w += sl;
+                    c->buf[w++] = '\n';
+                    // '+' line, then a quality line as long as the sequence line (else: to the next line end, like parse_chunk)
+                    const uint64_t e3 = e2 < end ? line_end(e2 + 1) : end;
+                    uint64_t e4 = e3 < end ? e3 + 1 + (e2 - s) : end;
+                    if (e4 > end || (e4 < end && m[e4] != '\n')) e4 = e3 < end ? line_end(e3 + 1) : end;
+                    p = e4 < end ? e4 + 1 : end;
+                }
+                c->begin = 0;
+                c->bytes = w;
+                c->seq_no = i;
+                publish(c);
+            }
+        } catch (const std::exception &e) { err = e.what(); }
+        worker_done(err);
+    }
+
     // bytes [off, off + n) of the (logical) file into dst
     void fetch(uint8_t *dst, uint64_t off, uint64_t n, z_stream &zs) {
         if (kind_ == 0) {
@@ -460,6 +560,7 @@ class Feeder {
             uint64_t file_pos = 0;
             size_t in_have = 0, in_pos = 0;
             bool eof = false;
+            bool mid_stream = false;  // inside a gzip member / an lz4 frame: the input may not end here (flate2's UnexpectedEof)
             auto cut_and_publish = [&](bool final) {
                 // keep whole records in c, carry the incomplete last one to a fresh chunk
                 Chunk *nxt = nullptr;
@@ -492,7 +593,10 @@ class Feeder {
                 if (in_pos == in_have) {
                     const ssize_t r = pread(fd_, in.data(), in.size(), (off_t)file_pos);
                     if (r < 0) throw FeederError("read error: " + path_);
-                    if (r == 0) break;
+                    if (r == 0) {
+                        if (mid_stream) throw FeederError(std::string(kind_ == 1 ? "gzip" : "lz4") + " stream truncated: " + path_);
+                        break;
+                    }
                     file_pos += (uint64_t)r;
                     in_have = (size_t)r;
                     in_pos = 0;
@@ -510,9 +614,12 @@ class Feeder {
                         consumed = (in_have - in_pos) - zs.avail_in;
                         produced = out0 - zs.avail_out;
                         if (rc == Z_STREAM_END) {
+                            mid_stream = false;
                             if (zs.avail_in > 0 || file_pos < file_size_) inflateReset(&zs);  // concatenated gzip members
                         } else if (rc != Z_OK && rc != Z_BUF_ERROR) {
                             throw FeederError("gzip stream corrupt: " + path_);
+                        } else if (consumed || produced) {
+                            mid_stream = true;
                         }
                     } else {
                         size_t dst = (size_t)(c->cap - 64 - c->bytes), src = in_have - in_pos;
@@ -520,6 +627,7 @@ class Feeder {
                         if (lz->is_error(rc)) throw FeederError("lz4 stream corrupt: " + path_);
                         consumed = src;
                         produced = dst;
+                        mid_stream = rc != 0;  // LZ4F_decompress returns 0 exactly when a frame is complete
                     }
                     in_pos += consumed;
                     c->bytes += produced;
@@ -573,6 +681,7 @@ class Feeder {
     std::function<void *(size_t)> alloc_;
     std::function<void(void *)> release_;
     int kind_ = 0;  // 0 raw, 1 gzip, 2 lz4, 3 BGZF (indexed, read like raw)
+    bool lean_fastq_ = false;  // raw FASTQ through the mapping: header and sequence lines only
     const uint8_t *map_ = nullptr;  // BGZF: the compressed file, mapped
     uint64_t map_size_ = 0;
     std::vector<uint64_t> bg_coff_, bg_uoff_;  // per block (+ end): compressed / inflated offsets
@@ -587,7 +696,7 @@ class Feeder {
     std::deque<Chunk *> free_, ready_, to_parse_;
     std::vector<std::thread> threads_;
     int done_workers_ = 0;
-    bool inflate_done_ = false, stopping_ = false;
+    bool inflate_done_ = false, stopping_ = false, aborted_ = false;
     std::string error_;
 };
 

@@ -1,25 +1,50 @@
 // feeder_dump -- test tool for fastx_feeder.hpp (no GPU needed: chunk buffers come from malloc).
-// usage: feeder_dump <file> <fasta|fastq> <chunk_bytes> <threads>   -> one line per read, in input order: id TAB length TAB sequence
+// usage: feeder_dump <file> <fasta|fastq|ref> <chunk_bytes> <threads>   -> one line per read, in input order: id TAB length TAB sequence
+//        (ref: through the reference loader, ref_loader.hpp; FEEDER_DUMP_QUIET=1 prints only "records bases" -- for timing)
 #include <cstdio>
 #include <cstdlib>
 #include <map>
 
 #include "fastx_feeder.hpp"
+#include "ref_loader.hpp"
 
 int main(int argc, char **argv) {
     if (argc < 5) return 2;
     using namespace mapquik::feeder;
     try {
+        if (std::string(argv[2]) == "ref") {
+            RefLoader rl(argv[1], atoi(argv[4]));
+            const bool quiet = getenv("FEEDER_DUMP_QUIET") != nullptr;
+            unsigned long long n = 0, bases = 0;
+            rl.for_each([&](const RefLoader::Record &r, const uint8_t *seq) {
+                ++n;
+                bases += r.len;
+                if (quiet) return;
+                fwrite(r.id.data(), 1, r.id.size(), stdout);
+                printf("\t%llu\t", (unsigned long long)r.len);
+                fwrite(seq, 1, r.len, stdout);
+                putchar('\n');
+            });
+            if (quiet) printf("%llu %llu\n", n, bases);
+            return 0;
+        }
         Feeder f(argv[1], std::string(argv[2]) == "fastq", strtoull(argv[3], nullptr, 10), atoi(argv[4]), atoi(argv[4]) + 4,
                  [](size_t n) { return malloc(n); }, [](void *p) { free(p); });
         if (getenv("FEEDER_DUMP_KIND")) fprintf(stderr, "kind=%s\n", f.kind_name());
         f.start();
         std::map<size_t, Chunk *> held;
         size_t next = 0;
+        const bool quiet = getenv("FEEDER_DUMP_QUIET") != nullptr;
+        unsigned long long n_rec = 0, n_bases = 0;
         auto flush = [&]() {
             for (auto it = held.find(next); it != held.end(); it = held.find(next)) {
                 Chunk *c = it->second;
                 for (size_t i = 0; i < c->starts.size(); ++i) {
+                    if (quiet) {
+                        ++n_rec;
+                        n_bases += c->lens[i];
+                        continue;
+                    }
                     fwrite(c->buf + c->ids[i].off, 1, c->ids[i].len, stdout);
                     printf("\t%u\t", c->lens[i]);
                     fwrite(c->buf + c->starts[i], 1, c->lens[i], stdout);
@@ -39,6 +64,7 @@ int main(int argc, char **argv) {
             fprintf(stderr, "missing chunk %zu\n", next);
             return 1;
         }
+        if (quiet) printf("%llu %llu\n", n_rec, n_bases);
     } catch (const std::exception &e) {
         fprintf(stderr, "feeder_dump: %s\n", e.what());
         return 1;

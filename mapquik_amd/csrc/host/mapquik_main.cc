@@ -25,6 +25,7 @@
 
 #include "fastx_feeder.hpp"
 #include "mapquik_host.hpp"
+#include "ref_loader.hpp"
 
 using namespace mapquik;
 using Clock = std::chrono::steady_clock;
@@ -138,9 +139,19 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         // copied device to device to the other GPUs (mq_index_clone).  The kernels fold soft-masked lower case.
         std::vector<std::unique_ptr<Index>> building(1);
         building[0].reset(new Index(P, dev_of(0)));
-        {
-            // pageable chunk buffers here: every reference byte is copied to the device exactly once, and pinning memory costs
-            // more than a pageable copy saves
+        const bool ref_plain = ref_fasta && !ends_with(o.reference, ".gz") && !ends_with(o.reference, ".lz4");
+        if (ref_plain) {
+            // an uncompressed FASTA: the whole file read once by all threads, records handed over whole and in order (ref_loader.hpp)
+            feeder::RefLoader rl(o.reference, n_parse);
+            size_t ref_idx = 0;
+            rl.for_each([&](const feeder::RefLoader::Record &r, const uint8_t *seq) {
+                const size_t cnt = mers::ref_extract(ref_idx, r.id, seq, r.len, P, *building[0]);
+                printf("Indexed reference %s: %zu k-min-mers.\n", r.id.c_str(), cnt);  // src/closures.rs:58
+                ++ref_idx;
+            });
+        } else {
+            // compressed (or FASTQ) reference: through the chunked feeder, pageable chunk buffers (every reference byte is copied to
+            // the device exactly once)
             feeder::Feeder rfeed(o.reference, !ref_fasta, 1ull << 28, n_parse, n_parse + 4, [](size_t n) { return malloc(n); },
                                  [](void *q) { free(q); });
             rfeed.start();
@@ -195,9 +206,18 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         int formatting = 0;                          // chunks a formatter is working on right now
         std::string werr;
         auto fail = [&](const std::string &m) {
-            std::lock_guard<std::mutex> lk(mu);
-            if (werr.empty()) werr = m;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (werr.empty()) werr = m;
+            }
+            cv.notify_all();
         };
+        auto failed = [&]() {
+            std::lock_guard<std::mutex> lk(mu);
+            return !werr.empty();
+        };
+        const char *fail_at_env = getenv("MQ_DRIVER_FAIL_AT");  // test hook: the worker that takes this chunk number reports a failure
+        const long fail_at = fail_at_env ? atol(fail_at_env) : -1;
         std::vector<std::thread> workers;
         for (int g = 0; g < o.gpus; ++g)
             workers.emplace_back([&, g]() {
@@ -222,8 +242,10 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                             throw Error(std::string("mq_ctx_reserve: ") + last_error());
                     }
                     for (size_t k = 0;; ++k) {
+                        if (failed()) break;  // somebody failed: stop pulling chunks
                         Chunk *c = feed.next();
                         if (!c) break;
+                        if (fail_at >= 0 && (long)c->seq_no == fail_at) throw Error("injected failure (MQ_DRIVER_FAIL_AT)");
                         const int sl = (int)(k % (size_t)n_slots);
                         finish_slot(sl);
                         c->hits.resize(c->starts.size());
@@ -315,6 +337,9 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             feed.recycle(c);
             ++next_out;
         }
+        // On a failure the chunks in flight are never recycled, so the feeder's workers (waiting for a buffer) and the GPU workers
+        // (waiting for a chunk) would wait forever: the feeder is told to give up, which wakes both.
+        if (failed()) feed.abort();
         for (auto &t : workers) t.join();
         cv.notify_all();
         for (auto &t : formatters) if (t.joinable()) t.join();

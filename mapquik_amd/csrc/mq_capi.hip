@@ -3,9 +3,11 @@
 #include <hip/hip_runtime.h>
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -13,6 +15,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mq_device.hpp"
@@ -783,7 +786,6 @@ struct mq_index {
     uint32_t cap_matches = 0;
     bool split = false;             // diagnostic MQ_PIPELINE=split: the two phases as separate launches (a profiler then prices each)
     bool force_general = false;     // test hook MQ_FORCE_GENERAL=1: never take the fast seeding path
-    bool timing_once = false;       // set by mq_map_probe_stats for one instrumented launch
     int chain_chunk = 64;           // test hook: MQ_CHAIN_CHUNK=4 exercises the multi-chunk chain path
     mq_ctx *def_ctx = nullptr;      // the context behind the index-level map entry points
 };
@@ -1379,39 +1381,60 @@ mq_index *mq_index_load(const char *path, int device) try {
     uint32_t max_id = 0;
     for (auto &kv : idx->refs) max_id = std::max(max_id, kv.first);
     if (ok && alloc_table(idx, hdr[1]) != MQ_OK) ok = false;
-    // file -> page-locked buffer -> device -> scatter kernel, two buffers deep
+    // file -> page-locked buffer -> device -> scatter kernel, by a few threads at once (each its own buffers and stream; the
+    // kernels of different chunks insert into the same table with atomics): the file read, not the copy, is what takes time
     const size_t total = (size_t)hdr[3] * sizeof(SavedSlot);
-    uint8_t *h_buf[2] = {nullptr, nullptr}, *d_buf[2] = {nullptr, nullptr};
+    const off_t slots_at = ::lseek(fd, 0, SEEK_CUR);
     uint32_t *d_flags = nullptr;
-    hipStream_t st = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};
     const char *why = "truncated or unreadable index file: ";
     if (ok && total) {
-        const size_t cb = std::min(total, IX_IO_CHUNK);
-        ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipMalloc((void **)&d_flags, 4) == hipSuccess &&
-             hipMemset(d_flags, 0, 4) == hipSuccess;
-        for (int i = 0; i < 2 && ok; ++i)
-            ok = hipHostMalloc((void **)&h_buf[i], cb, hipHostMallocDefault) == hipSuccess && hipMalloc((void **)&d_buf[i], cb) == hipSuccess &&
-                 hipEventCreate(&ev[i]) == hipSuccess;
+        ok = slots_at >= 0 && hipMalloc((void **)&d_flags, 4) == hipSuccess && hipMemset(d_flags, 0, 4) == hipSuccess &&
+             hipDeviceSynchronize() == hipSuccess;  // the table's memset (null stream) is done before other streams write to it
         const size_t n_chunks = (total + IX_IO_CHUNK - 1) / IX_IO_CHUNK;
-        for (size_t c = 0; c < n_chunks && ok; ++c) {
-            const size_t o = c * IX_IO_CHUNK, n = std::min(IX_IO_CHUNK, total - o);
-            if (c >= 2) ok = hipEventSynchronize(ev[c & 1]) == hipSuccess;  // the buffer's previous chunk has left it
-            ok = ok && read_all(fd, h_buf[c & 1], n);
-            if (!ok) break;
-            ok = hipMemcpyAsync(d_buf[c & 1], h_buf[c & 1], n, hipMemcpyHostToDevice, st) == hipSuccess;
-            const uint64_t ns = n / sizeof(SavedSlot);
-            hipLaunchKernelGGL(unpack_slots_kernel, dim3((uint32_t)std::min<uint64_t>((ns + 255) / 256, 1u << 16)), dim3(256), 0, st,
-                               (const SavedSlot *)d_buf[c & 1], ns, idx->table, hdr[1] - 1, max_id, d_flags);
-            ok = ok && hipGetLastError() == hipSuccess && hipEventRecord(ev[c & 1], st) == hipSuccess;
+        const int n_thr = (int)std::min<size_t>(8, n_chunks);
+        std::atomic<size_t> next{0};
+        std::atomic<int> bad{0};
+        auto work = [&]() {
+            uint8_t *h = nullptr, *d = nullptr;
+            hipStream_t st = nullptr;
+            const size_t cb = std::min(total, IX_IO_CHUNK);
+            bool good = hipSetDevice(device) == hipSuccess && (h = (uint8_t *)mq_host_alloc(cb)) != nullptr && hipMalloc((void **)&d, cb) == hipSuccess &&
+                        hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+            while (good) {
+                const size_t c = next.fetch_add(1);
+                if (c >= n_chunks) break;
+                const size_t o = c * IX_IO_CHUNK, n = std::min(IX_IO_CHUNK, total - o);
+                size_t got = 0;
+                while (got < n) {
+                    const ssize_t r = ::pread(fd, h + got, n - got, slots_at + (off_t)(o + got));
+                    if (r <= 0) break;
+                    got += (size_t)r;
+                }
+                if (got != n) { good = false; break; }
+                good = hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, st) == hipSuccess;
+                const uint64_t ns = n / sizeof(SavedSlot);
+                hipLaunchKernelGGL(unpack_slots_kernel, dim3((uint32_t)std::min<uint64_t>((ns + 255) / 256, 1u << 16)), dim3(256), 0, st,
+                                   (const SavedSlot *)d, ns, idx->table, hdr[1] - 1, max_id, d_flags);
+                good = good && hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+            }
+            if (!good) bad.store(1);
+            if (st) hipStreamDestroy(st);
+            hipFree(d);
+            mq_host_free(h);
+        };
+        if (ok) {
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_thr; ++t) th.emplace_back(work);
+            for (auto &t : th) t.join();
+            ok = bad.load() == 0;
         }
-        ok = ok && hipStreamSynchronize(st) == hipSuccess;
         uint32_t flags = 1;
         ok = ok && hipMemcpy(&flags, d_flags, 4, hipMemcpyDeviceToHost) == hipSuccess;
         if (ok && flags) {
             ok = false;
             why = "corrupt index file (an entry names a reference the file does not have, or a malformed slot): ";
         }
+        if (ok) ok = ::lseek(fd, slots_at + (off_t)total, SEEK_SET) >= 0;
     }
     uint8_t extra = 0;
     if (ok && ::read(fd, &extra, 1) != 0) {
@@ -1440,13 +1463,7 @@ mq_index *mq_index_load(const char *path, int device) try {
         ok = hipMalloc((void **)&idx->d_ref_lens, lens.size() * sizeof(uint64_t)) == hipSuccess &&
              hipMemcpy(idx->d_ref_lens, lens.data(), lens.size() * sizeof(uint64_t), hipMemcpyHostToDevice) == hipSuccess;
     }
-    for (int i = 0; i < 2; ++i) {
-        if (h_buf[i]) hipHostFree(h_buf[i]);
-        hipFree(d_buf[i]);
-        if (ev[i]) hipEventDestroy(ev[i]);
-    }
     hipFree(d_flags);
-    if (st) hipStreamDestroy(st);
     if (!ok) {
         mq_index_free(idx);
         set_err(MQ_EINVAL, std::string(why) + path);
@@ -1541,6 +1558,7 @@ struct LaunchOpt {
     uint32_t grid_override = 0;
     uint32_t f16 = 0;                      // 0 => list_f16(idx)
     const uint32_t *d_lens = nullptr;      // spans form: per-read lengths
+    bool instrumented = false;             // mq_map_probe_stats: the launch that counts lookups and probe steps (slower, never timed)
 };
 
 // One launch sequence on stream `st` using the context's scratch.  ctx_ensure(c, n, total_bases, f16) must have succeeded.
@@ -1581,7 +1599,7 @@ static int launch_map(mq_ctx *c, const uint8_t *d_bases, const uint64_t *d_offse
         uint32_t grid = std::min<uint32_t>(idx->grid_fused, (n + MAP_WAVES - 1) / MAP_WAVES);
         if (o.grid_override) grid = std::min(grid, o.grid_override);
         const dim3 blk(64 * MAP_WAVES);
-        if (idx->timing_once) hipLaunchKernelGGL((map_kernel<64, true>), dim3(grid), blk, 0, st, A);
+        if (o.instrumented) hipLaunchKernelGGL((map_kernel<64, true>), dim3(grid), blk, 0, st, A);
         else if (idx->chain_chunk == 4) hipLaunchKernelGGL((map_kernel<4, false>), dim3(grid), blk, 0, st, A);
         else hipLaunchKernelGGL((map_kernel<64, false>), dim3(grid), blk, 0, st, A);
         HIPCHK(hipGetLastError());
@@ -1601,7 +1619,7 @@ static int launch_map(mq_ctx *c, const uint8_t *d_bases, const uint64_t *d_offse
         uint32_t gm = std::min<uint32_t>(idx->grid_map, (n + ML_WAVES - 1) / ML_WAVES);
         if (o.grid_override) gm = std::min(gm, o.grid_override);
         const dim3 blk(64 * ML_WAVES);
-        if (idx->timing_once) hipLaunchKernelGGL((map_lists_kernel<64, true>), dim3(gm), blk, 0, st, A);
+        if (o.instrumented) hipLaunchKernelGGL((map_lists_kernel<64, true>), dim3(gm), blk, 0, st, A);
         else if (idx->chain_chunk == 4) hipLaunchKernelGGL((map_lists_kernel<4, false>), dim3(gm), blk, 0, st, A);
         else hipLaunchKernelGGL((map_lists_kernel<64, false>), dim3(gm), blk, 0, st, A);
         HIPCHK(hipGetLastError());
@@ -1735,7 +1753,7 @@ static int ctx_wait(mq_ctx *c) {
 }
 
 static int ctx_map_device(mq_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases, mq_hit *d_out,
-                          hipStream_t st) {
+                          hipStream_t st, bool instrumented = false) {
     mq_index *idx = c->idx;
     if (n && (!d_offsets || !d_out)) return set_err(MQ_EINVAL, "bad arguments");
     if (!idx->finalized) return set_err(MQ_ESTATE, "index not finalized");
@@ -1743,7 +1761,9 @@ static int ctx_map_device(mq_ctx *c, const uint8_t *d_bases, const uint64_t *d_o
     int rc = use_device(idx);
     if (rc) return rc;
     if ((rc = ctx_ensure(c, n, total_bases, list_f16(idx)))) return rc;
-    return launch_map(c, d_bases, d_offsets, n, d_out, st);
+    LaunchOpt o;
+    o.instrumented = instrumented;
+    return launch_map(c, d_bases, d_offsets, n, d_out, st, o);
 }
 
 extern "C" {
@@ -1976,18 +1996,58 @@ int mq_format_paf(const mq_index *idx, const char *q_id, uint64_t q_len, const m
     return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
+// Page-locked host memory.  hipHostMalloc pins at ~4 GB/s on this platform (and hipHostFree costs another 0.14 s per GB), which
+// made the feeder's chunk pool the start-up cost of the read phase; an anonymous mapping backed by transparent huge pages,
+// touched and then registered, is page-locked at ~15 GB/s and copies to the device at the full PCIe rate
+// (tools/pin_rate.hip, profiles/r03_pin_rate.txt).  Falls back to hipHostMalloc when the mapping or the registration fails.
+namespace {
+std::mutex g_host_mu;
+std::map<void *, std::pair<size_t, bool>> g_host_allocs;  // pointer -> (mapped bytes, true: mmap + hipHostRegister)
+}  // namespace
+
 void *mq_host_alloc(size_t bytes) {
-    void *p = nullptr;
-    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (!bytes) bytes = 1;
+    const size_t huge = 2u << 20;
+    const size_t mapped = (bytes + huge - 1) / huge * huge;
+    void *p = mmap(nullptr, mapped, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p != MAP_FAILED) {
+        madvise(p, mapped, MADV_HUGEPAGE);
+        for (size_t o = 0; o < mapped; o += 4096) ((volatile uint8_t *)p)[o] = 0;  // fault the pages in (2 MB at a time under THP)
+        if (hipHostRegister(p, mapped, hipHostRegisterDefault) == hipSuccess) {
+            std::lock_guard<std::mutex> lk(g_host_mu);
+            g_host_allocs[p] = std::make_pair(mapped, true);
+            return p;
+        }
+        (void)hipGetLastError();
+        munmap(p, mapped);
+    }
+    p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
     if (e != hipSuccess) {
         set_err(e == hipErrorOutOfMemory ? MQ_ENOMEM : MQ_EHIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
         return nullptr;
     }
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    g_host_allocs[p] = std::make_pair(bytes, false);
     return p;
 }
 
 void mq_host_free(void *p) {
-    if (p) hipHostFree(p);
+    if (!p) return;
+    std::pair<size_t, bool> info(0, false);
+    {
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        auto it = g_host_allocs.find(p);
+        if (it == g_host_allocs.end()) return;  // not ours
+        info = it->second;
+        g_host_allocs.erase(it);
+    }
+    if (info.second) {
+        hipHostUnregister(p);
+        munmap(p, info.first);
+    } else {
+        hipHostFree(p);
+    }
 }
 
 int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general) try {
@@ -2014,9 +2074,7 @@ int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_
     if (!idx || !lookups || !extra_steps) return set_err(MQ_EINVAL, "bad arguments");
     std::lock_guard<std::mutex> lk(idx->mu);
     mq_ctx *c = idx->def_ctx;
-    idx->timing_once = true;
-    int rc = ctx_map_device(c, d_bases, d_offsets, n, total_bases, d_out, nullptr);
-    idx->timing_once = false;
+    int rc = ctx_map_device(c, d_bases, d_offsets, n, total_bases, d_out, nullptr, true);  // the choice travels with this launch: contexts never see it
     if (rc) return rc;
     HIPCHK(hipEventSynchronize(c->ev1));
     uint64_t v[2];

@@ -73,10 +73,17 @@ uint64_t mqo_ntc64(const uint8_t *s, size_t i, size_t l) {
     return f < r ? f : r;
 }
 
-/* Hedge for the unpinned seeding decisions: the frozen reading is variant 0.  The other
- * variants exist only so that tools/check_against_upstream.sh can tell, on a machine that can build the real crate,
- * WHICH decision is wrong if the k-min-mer dumps differ: bit 0 = strict `<` on the density bound instead of `<=`,
- * bit 1 = FH is f32 (the bound is computed in single precision).  Never set by tests or by the product. */
+/* Hedge for the unpinned seeding decisions: the frozen reading is variant 0.  The other variants exist
+ * only so that tools/check_against_upstream.sh can tell, on a machine that can build the real crate, WHICH decision is wrong
+ * if the k-min-mer dumps differ.  Bits (any combination):
+ *    1  D3   strict `<` on the density bound instead of `<=`
+ *    2  D2   FH is f32: the bound is computed in single precision
+ *    4  D2/D12  H is u32: ntHash in 32-bit words (seeds = low halves of the 64-bit seeds, rotations mod 32) and a 32-bit bound
+ *            -- what a 16-lane AVX-512 implementation of the crate's SIMD modes may use
+ *    8  D5   a minimizer's position = raw index of the LAST base of its first base's homopolymer run (frozen: the run head)
+ *   16  D6   end = raw position of the last compressed base of the last minimizer's l-mer (frozen: pos[k-1] + l - 1, raw l)
+ *   32  D8   rev = reversed tuple <= forward tuple (frozen: strict <; differs on palindromic tuples only)
+ * Never set by tests of the product or by the product. */
 static int g_variant = 0;
 void mqo_set_variant(int v) { g_variant = v; }
 int mqo_get_variant(void) { return g_variant; }
@@ -84,6 +91,18 @@ static inline int keep_hash(uint64_t h, uint64_t bound) { return (g_variant & 1)
 
 /* hash_bound = ((density as FH) * (H::MAX as FH)) as H ; Rust float->int casts saturate, NaN -> 0 */
 uint64_t mqo_density_bound(double density) {
+    if (g_variant & 4) { /* H = u32 */
+        if (g_variant & 2) {
+            float f = (float)density * 4294967295.0f;
+            if (!(f > 0.0f)) return 0;
+            if (f >= 4294967296.0f) return 0xFFFFFFFFull;
+            return (uint64_t)(uint32_t)f;
+        }
+        double d = density * 4294967295.0;
+        if (!(d > 0.0)) return 0;
+        if (d >= 4294967296.0) return 0xFFFFFFFFull;
+        return (uint64_t)(uint32_t)d;
+    }
     if (g_variant & 2) {
         float f = (float)density * 18446744073709551615.0f;
         if (!(f > 0.0f)) return 0;
@@ -94,6 +113,17 @@ uint64_t mqo_density_bound(double density) {
     if (!(d > 0.0)) return 0;
     if (d >= 18446744073709551616.0) return UINT64_MAX;
     return (uint64_t)d;
+}
+
+/* variant 4: canonical ntHash of c[i, i+l) in 32-bit words, zero-extended */
+static inline uint32_t rol32(uint32_t x, unsigned r) { r &= 31; return r ? (x << r) | (x >> (32 - r)) : x; }
+static uint64_t ntc32(const uint8_t *c, size_t i, size_t l) {
+    uint32_t f = 0, r = 0;
+    for (size_t j = 0; j < l; j++) {
+        f ^= rol32((uint32_t)mqo_nt_seed(c[i + j]), (unsigned)(l - 1 - j));
+        r ^= rol32((uint32_t)nt_seed_rc(c[i + j]), (unsigned)j);
+    }
+    return f < r ? f : r;
 }
 
 /* ------------------------------------------------------------------ SipHash (Aumasson & Bernstein)
@@ -256,7 +286,7 @@ static void kminmer_from_window(const mqo_minimizer *w, size_t k, size_t l, uint
         fwd[i] = w[i].hash;
         rev[k - 1 - i] = w[i].hash;
     }
-    int is_rev = 0;
+    int is_rev = (g_variant & 32) ? 1 : 0; /* all elements equal: `<` says forward, `<=` says reversed */
     for (size_t i = 0; i < k; i++) {
         if (rev[i] < fwd[i]) { is_rev = 1; break; }
         if (rev[i] > fwd[i]) { is_rev = 0; break; }
@@ -269,18 +299,62 @@ static void kminmer_from_window(const mqo_minimizer *w, size_t k, size_t l, uint
     o->_pad = 0;
 }
 
+/* Diagnostic variants 4 / 8 / 16 (see mqo_set_variant): the minimizers by the naive form over the compressed sequence, with the
+ * raw position of each window's LAST compressed base beside them (last[]).  Returns the count; *m and *last are malloc'ed. */
+static size_t minimizers_variant(const uint8_t *seq, size_t len, const mqo_params *p, mqo_minimizer **m, uint64_t **last) {
+    const size_t l = (size_t)p->l;
+    const uint64_t bound = mqo_density_bound(p->density);
+    uint8_t *c = (uint8_t *)malloc(len ? len : 1);
+    uint64_t *head = (uint64_t *)malloc((len ? len : 1) * sizeof(uint64_t));
+    size_t n = 0;
+    for (size_t i = 0; i < len; i++) {
+        if (p->use_hpc && i > 0 && seq[i] == seq[i - 1]) continue;
+        c[n] = seq[i];
+        head[n] = i;
+        n++;
+    }
+    size_t cnt = 0, cap = 0;
+    *m = NULL;
+    *last = NULL;
+    if (l >= 1 && n >= l) {
+        for (size_t j = 0; j + l <= n; j++) {
+            const uint64_t h = (g_variant & 4) ? ntc32(c, j, l) : mqo_ntc64(c, j, l);
+            if (!keep_hash(h, bound)) continue;
+            if (cnt >= cap) {
+                cap = cap ? cap * 2 : 512;
+                *m = (mqo_minimizer *)realloc(*m, cap * sizeof(**m));
+                *last = (uint64_t *)realloc(*last, cap * sizeof(**last));
+            }
+            /* position: run head, or (variant 8) the run's last base = the base before the next run head */
+            (*m)[cnt].pos = (g_variant & 8) ? ((j + 1 < n ? head[j + 1] : (uint64_t)len) - 1) : head[j];
+            (*m)[cnt].hash = h;
+            (*last)[cnt] = head[j + l - 1];
+            cnt++;
+        }
+    }
+    free(c);
+    free(head);
+    return cnt;
+}
+
 /* returns a malloc'ed array (or NULL when empty) */
 static size_t kminmers_dyn(const uint8_t *seq, size_t len, const mqo_params *p, mqo_kminmer **out) {
     size_t k = (size_t)p->k, l = (size_t)p->l;
     *out = NULL;
     if (k < 1 || k > 64 || l < 1) return 0;
     mqo_minimizer *m = NULL;
-    size_t nmin = minimizers_core(seq, len, p, &m, 0, 1);
-    if (nmin < k) { free(m); return 0; }
+    uint64_t *last = NULL;
+    const int var = g_variant & (4 | 8 | 16);
+    size_t nmin = var ? minimizers_variant(seq, len, p, &m, &last) : minimizers_core(seq, len, p, &m, 0, 1);
+    if (nmin < k) { free(m); free(last); return 0; }
     size_t cnt = nmin - k + 1;
     mqo_kminmer *km = (mqo_kminmer *)malloc(cnt * sizeof(*km));
-    for (size_t i = 0; i < cnt; i++) kminmer_from_window(m + i, k, l, (uint64_t)i, km + i);
+    for (size_t i = 0; i < cnt; i++) {
+        kminmer_from_window(m + i, k, l, (uint64_t)i, km + i);
+        if (g_variant & 16) km[i].end = last[i + k - 1];
+    }
     free(m);
+    free(last);
     *out = km;
     return cnt;
 }

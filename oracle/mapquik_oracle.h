@@ -113,7 +113,8 @@ uint64_t mqo_nt_seed(uint8_t c);                                   /* ntHash-1 s
 uint64_t mqo_ntf64(const uint8_t *s, size_t i, size_t l);          /* forward hash of s[i..i+l) */
 uint64_t mqo_ntr64(const uint8_t *s, size_t i, size_t l);          /* reverse-complement hash */
 uint64_t mqo_ntc64(const uint8_t *s, size_t i, size_t l);          /* min(fwd, rev) */
-/* diagnostic variants of the unpinned seeding decisions (0 = the frozen reading; see mapquik_oracle.c) */
+/* diagnostic variants of the unpinned seeding decisions (0 = the frozen reading; bit list in mapquik_oracle.c; they apply to
+ * mqo_kminmers and everything built on it, bits 1 and 2 to mqo_minimizers as well) */
 void mqo_set_variant(int v);
 int mqo_get_variant(void);
 uint64_t mqo_density_bound(double density);                        /* (density * u64::MAX as f64) as u64 */

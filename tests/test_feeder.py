@@ -128,3 +128,69 @@ def test_feeder_inflates_bgzf_blocks_in_parallel(tool, tmp_path, fastq):
     plain.write_bytes(_g.compress(text.encode()))
     r = subprocess.run([tool, str(plain), "fastq" if fastq else "fasta", "5000", "2"], capture_output=True, text=True, env=dict(os.environ, FEEDER_DUMP_KIND="1"))
     assert "kind=gzip" in r.stderr and r.returncode == 0
+
+
+def test_feeder_rejects_truncated_compressed_input(tool, tmp_path):
+    """A .gz / .lz4 file cut in the middle of its stream is an error (flate2's GzDecoder returns UnexpectedEof and the reference
+    panics, src/main.rs:60-75), never a shorter list of reads."""
+    recs, text = _make(400, False, False, False, random.Random(31))
+    gz = gzip.compress(text.encode())
+    for name, blob in (("cut.fa.gz", gz[:len(gz) // 2]), ("cut2.fa.gz", gz[:-4]), ("cut.fa.lz4", None)):
+        if blob is None:
+            fr = _lz4_frame(text.encode())
+            blob = fr[:len(fr) // 2]
+        p = tmp_path / name
+        p.write_bytes(blob)
+        r = subprocess.run([tool, str(p), "fasta", "4096", "2"], capture_output=True, text=True, timeout=60)
+        assert r.returncode != 0 and "truncated" in r.stderr, (name, r.returncode, r.stderr[-200:])
+    # two whole members back to back are fine (concatenated gzip files), and so is an empty file
+    two = tmp_path / "two.fa.gz"
+    two.write_bytes(gz + gz)
+    assert len(_dump(tool, two, False, 4096, 2)) == 2 * len(recs)
+    empty = tmp_path / "empty.fa.gz"
+    empty.write_bytes(b"")
+    assert _dump(tool, empty, False, 4096, 2) == []
+
+
+def test_feeder_id_is_cut_at_the_first_space_only(tool, tmp_path):
+    """seq_io's id() (src/closures.rs:107,135) splits the header at the first SPACE: a TAB stays in the id; the CR of a CR-LF
+    header line does not."""
+    p = tmp_path / "ids.fa"
+    p.write_bytes(b">id1\tfoo bar\nACGT\n>id2\r\nAC\r\n>id3 x\ty\r\nA\r\n")
+    got = _dump_raw(tool, p)
+    assert got == [(b"id1\tfoo", b"4", b"ACGT"), (b"id2", b"2", b"AC"), (b"id3", b"1", b"A")]
+    q = tmp_path / "ids.fq"
+    q.write_bytes(b"@r1\tz w\nACG\n+\nIII\n@r2\r\nAC\r\n+\r\nII\r\n")
+    assert _dump_raw(tool, q, fastq=True) == [(b"r1\tz", b"3", b"ACG"), (b"r2", b"2", b"AC")]
+
+
+def _dump_raw(tool, path, fastq=False):
+    """feeder_dump's lines split at the LAST two TABs (ids may hold TABs)."""
+    r = subprocess.run([tool, str(path), "fastq" if fastq else "fasta", "4096", "2"], capture_output=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    return [tuple(ln.rsplit(b"\t", 2)) for ln in r.stdout.split(b"\n") if ln != b""]
+
+
+@pytest.mark.parametrize("multiline,crlf", [(False, False), (True, False), (True, True)])
+def test_reference_loader_matches_plain_parser(tool, tmp_path, multiline, crlf):
+    """ref_loader.hpp (whole file read once by all threads, records in file order) against the plain parser: single- and
+    multi-line records, CR-LF, a record far longer than a read block boundary would allow for, 1 and 5 threads."""
+    rng = random.Random(41 + multiline + 2 * crlf)
+    recs, text = _make(60, False, multiline, crlf, rng)
+    big = "".join(rng.choice("ACGTN") for _ in range(300_000))
+    nl = "\r\n" if crlf else "\n"
+    text += ">big one%s%s%s" % (nl, nl.join(big[j:j + 70] for j in range(0, len(big), 70)) if multiline else big, nl)
+    recs.append(("big", big))
+    for trailing in (True, False):
+        t = text if trailing else text.rstrip("\r\n")
+        p = tmp_path / "ref.fa"
+        p.write_text(t, newline="")
+        for th in (1, 5):
+            r = subprocess.run([tool, str(p), "ref", "0", str(th)], capture_output=True, text=True, timeout=60)
+            assert r.returncode == 0, r.stderr
+            got = [ln.split("\t") for ln in r.stdout.split("\n") if ln != ""]
+            got = [g if len(g) == 3 else g + [""] for g in got]
+            assert got == [[a, str(len(b)), b] for a, b in recs], (th, trailing)
+    bad = tmp_path / "bad.fa"
+    bad.write_text("ACGT\n>r\nAC\n")
+    assert subprocess.run([tool, str(bad), "ref", "0", "2"], capture_output=True).returncode != 0

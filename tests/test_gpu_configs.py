@@ -5,7 +5,9 @@
             idempotence on the full 196,608-read batch (the bench batch)
   config 5  maize-like: 2.13 Gbp, 10 contigs <= 308 Mbp, >= 80 % of the bases in transposon-like families (copies 1-5 %
             apart), runs of N in the reference, depth-30-shaped reads (experiments/simulate_maize.sh:1-12)
-Config 4 (DeepConsensus HG002 real reads on 8 GPUs) has no data in the image and no node to run on.
+  config 4  its SHAPE (experiments/table1.sh:50-55: uncompressed FASTQ reads, -k 7 -l 31 -d 0.01, human-scale reference) through
+            the native driver: CHM13v2.0-like scale 1.0, 50 k reads as a FASTQ file, <prefix>.paf byte-identical to the oracle's.
+            The real DeepConsensus HG002 reads are not in the image, and there is no 8-GPU node to run on.
 """
 import numpy as np
 import pytest
@@ -151,3 +153,54 @@ def test_config5_maize_like_repetitive(mq, oracle, simlib):
     assert diag2["n_hits"].sum() < 0.3 * diag2["n_kminmers"].sum()  # miss-dominated probes
     print("maize-like young repeats: unique/keys %d/%d, mapped %.4f, >1 candidate %d, ties %d"
           % (ox2.count(), ox2.keys(), (want2["mapped"] != 0).mean(), int((diag2["n_candidates"] > 1).sum()), int(diag2["tie"].sum())))
+
+
+def test_config4_shape_fastq_k7_native_driver(mq, oracle, simlib, tmp_path):
+    """BASELINE config 4's shape: FASTQ file + -k 7 (experiments/table1.sh:50-55) against a human-scale reference, file -> PAF
+    through the native driver (feeder, spans form, stream slots, formatter pool), PAF bytes identical to the oracle's."""
+    import os
+    import subprocess
+    import tempfile
+    from mapquik_amd import build
+    exe = build.build_cli()
+    T = _ncpu()
+    lens = list(simlib.CHM13_LIKE)
+    g, off, names = simlib.make_genome(lens, seed=2013, threads=T, repeat_frac=0.05, tandem_frac=0.01)
+    ps = dict(k=7, l=31, density=0.01)
+    po = oracle.params(**ps)
+    ox = oracle.Index()
+    ox.build_mt(g, off, names, po, T)
+    ns = 50000
+    reads = simlib.make_reads(g, off, ns, seed=4013, threads=T)
+    bases, offs = reads["bases"], reads["offsets"]
+    want = ox.map_batch(bases, offs, po, threads=T)
+    rn = simlib.read_names(reads, names)
+    want_paf = "".join(x + "\n" for x in oracle.paf_lines(ox, rn, want)).encode()
+    assert (want["mapped"] != 0).sum() > 0.9 * ns
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    with tempfile.TemporaryDirectory(dir=base) as wd:
+        ref, rd = os.path.join(wd, "ref.fa"), os.path.join(wd, "reads.fastq")
+        with open(ref, "wb") as f:
+            for r in range(len(lens)):
+                f.write(b">" + names[r].encode() + b"\n")
+                g[int(off[r]):int(off[r + 1])].tofile(f)
+                f.write(b"\n")
+        del g
+        qual = np.full(int((offs[1:] - offs[:-1]).max()), ord("I"), dtype=np.uint8)
+        with open(rd, "wb") as f:
+            for i in range(ns):
+                f.write(b"@" + rn[i].encode() + b" np:i:12\n")
+                L = int(offs[i + 1] - offs[i])
+                bases[int(offs[i]):int(offs[i + 1])].tofile(f)
+                f.write(b"\n+\n")
+                qual[:L].tofile(f)
+                f.write(b"\n")
+        prefix = os.path.join(wd, "c4")
+        r = subprocess.run([exe, rd, "--reference", ref, "-p", prefix, "-k", "7", "-l", "31", "-d", "0.01", "--threads", str(min(T, 16))],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-400:]
+        assert "Format: FASTA" in r.stdout and "Mapped query sequences in" in r.stdout
+        got = open(prefix + ".paf", "rb").read()
+    assert got == want_paf and len(want_paf) > 4_000_000
+    n_m, n_q60, n_wrong = simlib.mapeval({k: v for k, v in reads.items() if k not in ("bases", "offsets")}, want)
+    assert n_q60 > 0.95 * ns and n_wrong <= 5

@@ -407,6 +407,32 @@ def test_index_save_load_roundtrip(mq, oracle, simlib, tmp_path):
     must_fail(bytes(dup))
 
 
+def test_native_driver_fails_loudly_mid_run(mq, simlib, tmp_path):
+    """A failure in the middle of an input far larger than the feeder's chunk pool (here: a worker reports one on chunk 30 of
+    ~70, test hook MQ_DRIVER_FAIL_AT) ends the run with the reference's panic code 101 and no PAF -- it used to hang: nobody
+    recycled the chunks in flight, so the feeder's workers waited for buffers and the GPU workers for chunks, forever."""
+    import subprocess
+    from mapquik_amd import build
+    exe = build.build_cli()
+    g, off, names = simlib.make_genome([300000], seed=5)
+    reads = simlib.make_reads(g, off, 800, seed=8, len_mean=9000)
+    rn = simlib.read_names(reads, names)
+    ref, rd = tmp_path / "ref.fa", tmp_path / "reads.fa"
+    ref.write_bytes(b">" + names[0].encode() + b"\n" + g.tobytes() + b"\n")
+    with open(rd, "wb") as w:
+        for i, n in enumerate(rn):
+            w.write(b">" + n.encode() + b"\n" + reads["bases"][int(reads["offsets"][i]):int(reads["offsets"][i + 1])].tobytes() + b"\n")
+    for extra, env in (([], {}), (["--gpus", "2"], {"MQ_FAKE_MULTI": "1"})):
+        prefix = str(tmp_path / "fail")
+        r = subprocess.run([exe, str(rd), "--reference", str(ref), "-p", prefix, "--batch-bases", "100000", "--threads", "2"] + extra,
+                           capture_output=True, text=True, timeout=120, env=dict(os.environ, MQ_DRIVER_FAIL_AT="30", **env))
+        assert r.returncode == 101 and "injected failure" in r.stderr, (r.returncode, r.stderr[-300:])
+        assert not os.path.exists(prefix + ".paf")
+    ok = subprocess.run([exe, str(rd), "--reference", str(ref), "-p", str(tmp_path / "ok"), "--batch-bases", "100000", "--threads", "2"],
+                        capture_output=True, text=True, timeout=120)
+    assert ok.returncode == 0 and os.path.getsize(str(tmp_path / "ok.paf")) > 0
+
+
 def test_native_cli_end_to_end_paf_identical(mq, oracle, simlib, tmp_path):
     """The C++ `mapquik` driver: gzip'ed multi-line mixed-case reference, FASTQ reads, `<prefix>.paf` identical to the oracle."""
     import gzip

@@ -7,11 +7,16 @@
 #
 # Step 1 (localises a divergence): the reference is patched to print every reference k-min-mer it indexes
 #   (src/mers.rs:29: the commented `println!("{:?}", kminmer)` becomes a tab-separated line under MQ_DUMP), the same tuples
-#   are produced by this repo's CPU oracle in its frozen reading (variant 0) and in the diagnostic variants of the unpinned
-#   decisions (D2/D3 of DESIGN.md: 1 = strict `<` on the density bound, 2 = f32 bound, 3 = both), and the first differing
-#   tuple per variant is shown: start/end wrong => D5-D7 (HPC positions); a missing/extra tuple => D2/D3 (bound) or D1
-#   (ntHash); only `rev`/hash wrong => D8/D9 (orientation, tuple hash).  With --nosimd as an extra flag the scalar HashMode of
-#   the crate is exercised instead of the SIMD one (D12).
+#   are produced by this repo's CPU oracle in its frozen reading (variant 0) and in twelve combinations of the diagnostic
+#   variants of the unpinned decisions (oracle/mapquik_oracle.c, mqo_set_variant; DESIGN.md section 2 says which kernel constant
+#   each one would change):
+#      bit 1  D3  strict `<` on the density bound      bit 8   D5  position = end of the homopolymer run (not its head)
+#      bit 2  D2  the bound computed in f32            bit 16  D6  end = raw position of the window's last compressed base
+#      bit 4  D2/D12  32-bit ntHash and bound          bit 32  D8  rev on `<=` (palindromic tuples)
+#   The matching variant is printed; with none, the first differing tuple per variant says where to look: start/end wrong =>
+#   D5-D7 (HPC positions); a missing/extra tuple => D2/D3 (bound) or D1 (ntHash); only `rev`/hash wrong => D8/D9 (orientation,
+#   tuple hash).  With --nosimd as an extra flag the scalar HashMode of the crate is exercised instead of the SIMD one (D12):
+#   run both -- if they match different variants, the reference's results depend on the CPU it runs on.
 # Step 2: maps the reads with the reference and with this repo's native driver using the same flags and diffs the PAFs byte
 #   for byte in input order (the reference's default seq_io path writes in input order, src/closures.rs:117-123).
 # The resolved revision of rust-seq2kminmers is recorded so that a divergence can be tied to a crate version.
@@ -40,7 +45,7 @@ while [ $i -lt ${#args[@]} ]; do
   esac
 done
 best=""
-for v in 0 1 2 3; do
+for v in 0 1 2 3 4 5 6 7 8 16 24 32; do
   python3 "$HERE/tools/dump_kminmers.py" "$REF" --variant $v "${OFLAGS[@]}" > "$WORK/oracle.v$v.kmm"
   if cmp -s "$WORK/upstream.kmm" "$WORK/oracle.v$v.kmm"; then
     echo "k-min-mer tuples: oracle variant $v IDENTICAL to the reference ($(wc -l < "$WORK/upstream.kmm") tuples)"; best=$v
@@ -49,7 +54,7 @@ for v in 0 1 2 3; do
     diff "$WORK/upstream.kmm" "$WORK/oracle.v$v.kmm" | head -4 || true
   fi
 done
-[ "$best" = "0" ] && echo "seeding stage PINNED: the frozen reading (variant 0) reproduces the crate" || echo "seeding stage NOT pinned by variant 0 (matching variant: '${best:-none}'): see DESIGN.md section 2 for which decision each field belongs to"
+[ "$best" = "0" ] && echo "seeding stage PINNED: the frozen reading (variant 0) reproduces the crate" || echo "seeding stage NOT pinned by variant 0 (matching variant: '${best:-none}'): DESIGN.md section 2 names the kernel constant behind each bit"
 
 # ---- step 2: PAF identity
 "$WORK/mapquik/target/release/mapquik" "$READS" --reference "$REF" -p "$WORK/upstream" "$@"

@@ -2,8 +2,9 @@
 """dump_kminmers.py -- the k-min-mers of every record of a FASTA file as the CPU oracle yields them, one per line:
     KMM <TAB> start <TAB> end <TAB> offset <TAB> rev <TAB> hash
 the same line the patched reference prints under MQ_DUMP (tools/check_against_upstream.sh).  --variant selects one of the
-oracle's diagnostic readings of the unpinned seeding decisions (0 = the frozen one; bit 0: strict `<` on the density bound;
-bit 1: the bound computed in f32).  Test/diagnostic infrastructure: imports oracle/."""
+oracle's diagnostic readings of the unpinned seeding decisions (0 = the frozen one; bits 1 `<` on the bound, 2 f32 bound,
+4 32-bit ntHash, 8 position = run end, 16 end from the compressed window, 32 rev on `<=`: oracle/mapquik_oracle.c).
+Test/diagnostic infrastructure: imports oracle/."""
 import argparse
 import gzip
 import os
@@ -21,7 +22,7 @@ def records(path):
             if ln.startswith(b">"):
                 if name is not None:
                     yield name, b"".join(seq).upper()
-                name, seq = ln[1:].split()[0].decode() if len(ln) > 1 else "", []
+                name, seq = ln[1:].split(b" ", 1)[0].decode(), []
             elif name is not None:
                 seq.append(ln)
     if name is not None:

@@ -296,3 +296,121 @@ void mqsim_compact(const uint8_t *src, const uint64_t *src_off, const uint64_t *
         dst_off[r + 1] = dst_off[r] + read_len[r];
     }
 }
+
+/* ---- FASTA / FASTQ file writer (bench.py's end-to-end legs): read i becomes ">r<i>\n<bases>\n" or
+ * "@r<i>\n<bases>\n+\n<quality 'I' x len>\n"; the file is laid out first (sizes are known), then written by `threads`
+ * threads with pwrite, each its own range of reads.  Returns the file size, 0 on failure. */
+#include <fcntl.h>
+#include <stdio.h>
+#include <unistd.h>
+typedef struct {
+    int fd;
+    const uint8_t *bases;
+    const uint64_t *off;
+    const uint64_t *fpos;
+    uint32_t lo, hi;
+    int fastq;
+    int ok;
+} fx_job;
+static int pwrite_all(int fd, const uint8_t *p, uint64_t n, uint64_t at) {
+    while (n) {
+        ssize_t w = pwrite(fd, p, n, (off_t)at);
+        if (w <= 0) return 0;
+        p += w;
+        n -= (uint64_t)w;
+        at += (uint64_t)w;
+    }
+    return 1;
+}
+static void *fx_worker(void *a) {
+    fx_job *j = (fx_job *)a;
+    const uint64_t cap = 8u << 20;
+    uint8_t *buf = (uint8_t *)malloc(cap + 64);
+    uint64_t fill = 0, at = j->fpos[j->lo];
+    j->ok = buf != NULL;
+    for (uint32_t r = j->lo; j->ok && r < j->hi; ++r) {
+        const uint64_t L = j->off[r + 1] - j->off[r];
+        char hdr[32];
+        const int hl = snprintf(hdr, sizeof(hdr), "%cr%u\n", j->fastq ? '@' : '>', r);
+        const uint64_t need = (uint64_t)hl + L + 1 + (j->fastq ? 2 + L + 1 : 0);
+        if (fill + need > cap) {  /* flush; a record larger than the buffer is written piecewise below */
+            j->ok = pwrite_all(j->fd, buf, fill, at);
+            at += fill;
+            fill = 0;
+        }
+        if (need > cap) {
+            j->ok = j->ok && pwrite_all(j->fd, (const uint8_t *)hdr, (uint64_t)hl, at) && pwrite_all(j->fd, j->bases + j->off[r], L, at + hl) &&
+                    pwrite_all(j->fd, (const uint8_t *)"\n", 1, at + hl + L);
+            at += (uint64_t)hl + L + 1;
+            if (j->fastq) {
+                uint8_t *q = (uint8_t *)malloc(L + 3);
+                j->ok = j->ok && q != NULL;
+                if (q) {
+                    q[0] = '+';
+                    q[1] = '\n';
+                    memset(q + 2, 'I', L);
+                    q[2 + L] = '\n';
+                    j->ok = j->ok && pwrite_all(j->fd, q, L + 3, at);
+                    free(q);
+                }
+                at += L + 3;
+            }
+            continue;
+        }
+        memcpy(buf + fill, hdr, (size_t)hl);
+        fill += (uint64_t)hl;
+        memcpy(buf + fill, j->bases + j->off[r], L);
+        fill += L;
+        buf[fill++] = '\n';
+        if (j->fastq) {
+            buf[fill++] = '+';
+            buf[fill++] = '\n';
+            memset(buf + fill, 'I', L);
+            fill += L;
+            buf[fill++] = '\n';
+        }
+    }
+    if (j->ok && fill) j->ok = pwrite_all(j->fd, buf, fill, at);
+    free(buf);
+    return NULL;
+}
+uint64_t mqsim_write_fastx(const char *path, const uint8_t *bases, const uint64_t *off, uint32_t n, int fastq, int threads) {
+    uint64_t *fpos = (uint64_t *)malloc(((size_t)n + 1) * sizeof(uint64_t));
+    if (!fpos) return 0;
+    fpos[0] = 0;
+    for (uint32_t r = 0; r < n; ++r) {
+        char hdr[32];
+        const int hl = snprintf(hdr, sizeof(hdr), "%cr%u\n", '>', r);
+        const uint64_t L = off[r + 1] - off[r];
+        fpos[r + 1] = fpos[r] + (uint64_t)hl + L + 1 + (fastq ? 2 + L + 1 : 0);
+    }
+    int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) {
+        free(fpos);
+        return 0;
+    }
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    pthread_t th[64];
+    fx_job jobs[64];
+    int ok = 1;
+    for (int t = 0; t < threads; ++t) {
+        jobs[t].fd = fd;
+        jobs[t].bases = bases;
+        jobs[t].off = off;
+        jobs[t].fpos = fpos;
+        jobs[t].lo = (uint32_t)((uint64_t)n * t / threads);
+        jobs[t].hi = (uint32_t)((uint64_t)n * (t + 1) / threads);
+        jobs[t].fastq = fastq;
+        jobs[t].ok = 0;
+        pthread_create(&th[t], NULL, fx_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; ++t) {
+        pthread_join(th[t], NULL);
+        ok = ok && jobs[t].ok;
+    }
+    const uint64_t size = fpos[n];
+    free(fpos);
+    ok = (close(fd) == 0) && ok;
+    return ok ? size : 0;
+}

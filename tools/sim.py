@@ -36,6 +36,8 @@ def lib():
         L.mqsim_read_caps.argtypes = [vp, u32, u32, dbl, dbl, u64, u64, u64, vp]
         L.mqsim_reads.argtypes = [vp, vp, u32, u32, dbl, dbl, u64, u64, dbl, dbl, dbl, u64, C.c_int, vp, vp, vp, vp, vp, vp, vp]
         L.mqsim_compact.argtypes = [vp, vp, vp, u32, vp, vp]
+        L.mqsim_write_fastx.restype = u64
+        L.mqsim_write_fastx.argtypes = [C.c_char_p, vp, vp, u32, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -100,6 +102,16 @@ def make_reads(genome, ctg_off, n_reads, seed=1, len_mean=24000.0, len_sd=2300.0
     offsets = np.zeros(n_reads + 1, dtype=np.uint64)
     lib().mqsim_compact(_p(tmp), _p(caps), _p(rl), n_reads, _p(bases), _p(offsets))
     return dict(bases=bases, offsets=offsets, ctg=t_ctg, start=t_start, end=t_end, strand=t_strand)
+
+
+def write_fastx(path, bases, offsets, n_reads, fastq=False, threads=8):
+    """Reads 0..n_reads-1 as a FASTA / FASTQ file (ids r<i>, quality 'I'), written by `threads` threads.  Returns the file size."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    size = lib().mqsim_write_fastx(os.fsencode(path), _p(bases), _p(offsets), int(n_reads), 1 if fastq else 0, int(threads))
+    if not size:
+        raise OSError("could not write " + str(path))
+    return int(size)
 
 
 def read_names(reads, ctg_names):
