@@ -65,6 +65,21 @@ def build_feeder_dump(force=False):
     return FEEDER_DUMP
 
 
+SEAM_TEST = os.path.join(LIBDIR, "seam_test")
+
+
+def build_seam_test(force=False):
+    """Test program for the C++ mirror of the reference's seam (tests/cpp/seam_test.cc over mapquik_host.hpp): lib/seam_test."""
+    build(force=False)
+    src = os.path.join(os.path.dirname(_HERE), "tests", "cpp", "seam_test.cc")
+    deps = [src, os.path.join(HOST_DIR, "mapquik_host.hpp"), LIB]
+    if not force and os.path.exists(SEAM_TEST) and all(os.path.getmtime(SEAM_TEST) >= os.path.getmtime(d) for d in deps):
+        return SEAM_TEST
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", SEAM_TEST, src, "-L" + LIBDIR, "-lmapquik_hip", "-lpthread", "-ldl",
+                           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + "/opt/rocm/lib"])
+    return SEAM_TEST
+
+
 def is_fresh():
     return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in _deps())
 

@@ -549,8 +549,13 @@ class Feeder {
             z_stream zs;
             memset(&zs, 0, sizeof(zs));
             std::unique_ptr<Lz4> lz;
+            struct ZEnd {  // inflateEnd on every way out (an exception on a corrupt or truncated stream included)
+                z_stream *z = nullptr;
+                ~ZEnd() { if (z) inflateEnd(z); }
+            } zend;
             if (kind_ == 1) {
                 if (inflateInit2(&zs, 15 + 32) != Z_OK) throw FeederError("inflateInit2 failed");
+                zend.z = &zs;
             } else {
                 lz.reset(new Lz4());
             }
@@ -634,7 +639,6 @@ class Feeder {
                     if (!consumed && !produced) break;
                 }
             }
-            if (kind_ == 1) inflateEnd(&zs);
             cut_and_publish(true);
         } catch (const std::exception &e) { err = e.what(); }
         {

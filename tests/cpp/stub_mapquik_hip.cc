@@ -1,0 +1,128 @@
+// stub_mapquik_hip.cc -- a HOST-ONLY stand-in for libmapquik_hip.so with canned results, for the sanitizer builds of the native
+// driver (make asan / make tsan): ASan, UBSan and TSan cannot run on the GPU build, and what they are wanted for is the driver's
+// threads (feeder readers, inflate thread, per-GPU submitters, formatter pool, ordered writer), not the kernels.
+// Every read "maps" to reference 0 with coordinates derived from its length and first bases; submit hands the batch to a worker
+// thread per context so that mq_ctx_wait really waits.  Test infrastructure only: never linked into the product.
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mapquik_hip.h"
+
+struct mq_index {
+    mq_params p;
+    int device;
+    std::map<uint32_t, std::pair<std::string, uint64_t>> refs;
+    bool finalized = false;
+    uint64_t n_kmm = 0;
+};
+struct mq_ctx {
+    mq_index *idx;
+    std::thread worker;
+    bool pending = false;
+};
+static thread_local std::string g_err;
+
+static void canned(const mq_index *idx, const uint8_t *buf, uint64_t start, uint32_t len, mq_hit *h) {
+    memset(h, 0, sizeof(*h));
+    uint32_t x = len;
+    for (uint32_t i = 0; i < len && i < 8; ++i) x = x * 131u + buf[start + i];
+    if (len < 50 || idx->refs.empty()) {
+        h->status = MQ_HIT_UNMAPPED;
+        return;
+    }
+    const uint64_t rl = idx->refs.begin()->second.second;
+    h->status = MQ_HIT_MAPPED;
+    h->ref_id = idx->refs.begin()->first;
+    h->rc = x & 1u;
+    h->mapq = 60;
+    h->q_start = 0;
+    h->q_end = len - 1;
+    h->r_start = (uint32_t)(rl > len ? x % (rl - len) : 0);
+    h->r_end = h->r_start + len - 1;
+    h->score = len / 100 + 1;
+    h->n_kminmers = len / 80;
+}
+
+extern "C" {
+const char *mq_last_error(void) { return g_err.c_str(); }
+int mq_abi_version(void) { return MQ_ABI_VERSION; }
+int mq_device_count(void) {
+    const char *e = getenv("MQ_STUB_DEVICES");
+    return e ? atoi(e) : 1;
+}
+void mq_params_default(mq_params *p) {
+    p->k = 5; p->l = 31; p->density = 0.01; p->use_hpc = 1; p->c = 4; p->s = 11; p->g = 2000; p->flags = 0;
+}
+mq_index *mq_index_new(const mq_params *p, int device) {
+    mq_index *i = new mq_index();
+    i->p = *p;
+    i->device = device;
+    return i;
+}
+void mq_index_free(mq_index *i) { delete i; }
+int64_t mq_index_add_ref(mq_index *i, uint32_t id, const char *name, const uint8_t *seq, uint64_t len) {
+    if (!i || (!seq && len)) { g_err = "bad arguments"; return MQ_EINVAL; }
+    uint64_t sum = 0;
+    for (uint64_t j = 0; j < len; j += 4096) sum += seq[j];  // touch the caller's buffer (use-after-free shows under ASan)
+    i->refs[id] = std::make_pair(std::string(name ? name : ""), len);
+    i->n_kmm += len / 100 + (sum & 1);
+    return (int64_t)(len / 100);
+}
+int64_t mq_index_finalize(mq_index *i) { i->finalized = true; return (int64_t)i->n_kmm; }
+mq_index *mq_index_clone(const mq_index *s, int device) {
+    mq_index *i = new mq_index(*s);
+    i->device = device;
+    return i;
+}
+int mq_index_get_stats(const mq_index *i, mq_index_stats *o) {
+    memset(o, 0, sizeof(*o));
+    o->n_refs = i->refs.size();
+    o->n_unique = i->n_kmm;
+    return MQ_OK;
+}
+int mq_index_save(const mq_index *, const char *) { g_err = "stub"; return MQ_EINVAL; }
+mq_index *mq_index_load(const char *, int) { g_err = "stub"; return nullptr; }
+mq_ctx *mq_ctx_new(mq_index *i) {
+    mq_ctx *c = new mq_ctx();
+    c->idx = i;
+    return c;
+}
+void mq_ctx_free(mq_ctx *c) {
+    if (!c) return;
+    if (c->worker.joinable()) c->worker.join();
+    delete c;
+}
+int mq_ctx_reserve(mq_ctx *, uint32_t, uint64_t) { return MQ_OK; }
+int mq_ctx_submit_spans(mq_ctx *c, const uint8_t *buf, uint64_t bytes, const uint64_t *starts, const uint32_t *lens, uint32_t n, mq_hit *out) {
+    if (c->pending) { g_err = "context has a submitted batch"; return MQ_ESTATE; }
+    for (uint32_t i = 0; i < n; ++i)
+        if (starts[i] + lens[i] > bytes) { g_err = "span outside the buffer"; return MQ_EINVAL; }
+    c->pending = true;
+    c->worker = std::thread([=]() {
+        for (uint32_t i = 0; i < n; ++i) canned(c->idx, buf, starts[i], lens[i], &out[i]);
+    });
+    return MQ_OK;
+}
+int mq_ctx_wait(mq_ctx *c) {
+    if (c->worker.joinable()) c->worker.join();
+    c->pending = false;
+    return MQ_OK;
+}
+int mq_format_paf(const mq_index *i, const char *q_id, uint64_t q_len, const mq_hit *h, char *buf, size_t cap) {
+    auto it = i->refs.find(h->ref_id);
+    if (it == i->refs.end()) { g_err = "unknown ref"; return MQ_EINVAL; }
+    const unsigned long long rl = it->second.second;
+    return snprintf(buf, cap, "%s\t%llu\t%u\t%u\t%s\t%s\t%llu\t%u\t%u\t%u\t%llu\t%u", q_id, (unsigned long long)q_len, h->q_start, h->q_end,
+                    h->rc ? "-" : "+", it->second.first.c_str(), rl, h->r_start, h->r_end, h->score, rl, h->mapq);
+}
+void *mq_host_alloc(size_t n) { return malloc(n ? n : 1); }
+void mq_host_free(void *p) { free(p); }
+}

@@ -195,6 +195,47 @@ def test_index_clone_is_a_deep_replica(mq, oracle, simlib, small):
     assert rep.ref_info(1)[0] == names[1]
 
 
+def test_cloned_replicas_map_from_two_threads_at_once(mq, oracle, simlib, small):
+    """What `--gpus N` does with N real devices, as far as one device can show it: the finalized index cloned (device-to-device
+    copy of the table), the source and the replica mapping the SAME batch from two threads at the same time, each through its own
+    stream slots, several rounds -- both give the oracle's result every time, and the source can be freed while the replica works."""
+    import threading
+    g, off, names = small
+    ix, ox, po = _index_both(mq, oracle, small, dict())
+    reads = simlib.make_reads(g, off, 600, seed=18)
+    want = ox.map_batch(reads["bases"], reads["offsets"], po, threads=4)
+    rep = ix.clone(0)
+    assert rep.stats() == ix.stats()
+    out, errs = {}, []
+
+    def work(tag, index, rounds):
+        try:
+            ctxs = [index.context() for _ in range(2)]
+            res = []
+            for k in range(rounds):
+                c = ctxs[k % 2]
+                c.submit(reads["bases"], reads["offsets"])
+                res.append(c.wait().copy())
+            for c in ctxs:
+                c.close()
+            out[tag] = res
+        except Exception as e:  # noqa: BLE001
+            errs.append((tag, repr(e)))
+
+    th = [threading.Thread(target=work, args=("src", ix, 6)), threading.Thread(target=work, args=("rep", rep, 6))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for tag in ("src", "rep"):
+        for h in out[tag]:
+            _cmp(h, want)
+    ix.close()  # the replica owns its own table
+    h = rep.map_batch(reads["bases"], reads["offsets"])
+    assert np.array_equal(h.view(np.uint8), out["rep"][0].view(np.uint8))
+
+
 def test_native_driver_second_pass(mq, oracle, simlib, tmp_path):
     """--second-pass k2,l2,d2 (experiments/chm13/run_chm13_mapquik_unmapped.sh:8-24 in one process): the reads the first pass
     leaves unmapped are written as FASTA and mapped again with the second parameter set; both PAFs equal the oracle's."""

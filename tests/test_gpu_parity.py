@@ -407,6 +407,37 @@ def test_index_save_load_roundtrip(mq, oracle, simlib, tmp_path):
     must_fail(bytes(dup))
 
 
+def test_cpp_seam_find_matches_matches_oracle_paf(mq, oracle, simlib, tmp_path):
+    """The C++ mirror of the reference's seam -- mers::ref_extract, Index::into_read_only, mers::find_matches (one read per call,
+    src/mers.rs:77) and find_matches_batch (mapquik_host.hpp) -- driven the way src/closures.rs drives the Rust functions:
+    the lines it returns are the oracle's PAF, for the defaults and for -k 7."""
+    import subprocess
+    from mapquik_amd import build
+    exe = build.build_seam_test()
+    g, off, names = simlib.make_genome([400000, 250000], seed=77, repeat_frac=0.1)
+    reads = simlib.make_reads(g, off, 120, seed=12, len_mean=10000, len_sd=3000)
+    rn = simlib.read_names(reads, names)
+    ref, rd = tmp_path / "ref.fa", tmp_path / "reads.fa"
+    with open(ref, "wb") as w:
+        for r in range(2):
+            w.write(b">" + names[r].encode() + b"\n" + g[int(off[r]):int(off[r + 1])].tobytes() + b"\n")
+    with open(rd, "wb") as w:
+        for i, n in enumerate(rn):
+            w.write(b">" + n.encode() + b"\n" + reads["bases"][int(reads["offsets"][i]):int(reads["offsets"][i + 1])].tobytes() + b"\n")
+    for ps, extra in ((dict(), []), (dict(k=7, l=31, density=0.01), ["7", "31", "0.01"])):
+        po = oracle.params(**ps)
+        ox = oracle.Index()
+        for r in range(2):
+            ox.add_ref(r, names[r], g[int(off[r]):int(off[r + 1])], po)
+        want = oracle.paf_lines(ox, rn, ox.map_batch(reads["bases"], reads["offsets"], po, threads=2))
+        assert len(want) > 100
+        for mode in ("single", "batch"):
+            r = subprocess.run([exe, str(ref), str(rd), mode] + extra, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-300:]
+            assert r.stdout.splitlines() == want, (mode, ps)
+            assert ("unique %d" % ox.count()) in r.stderr
+
+
 def test_native_driver_fails_loudly_mid_run(mq, simlib, tmp_path):
     """A failure in the middle of an input far larger than the feeder's chunk pool (here: a worker reports one on chunk 30 of
     ~70, test hook MQ_DRIVER_FAIL_AT) ends the run with the reference's panic code 101 and no PAF -- it used to hang: nobody
