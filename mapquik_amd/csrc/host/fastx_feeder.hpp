@@ -407,6 +407,12 @@ class Feeder {
                     break;
                 }
                 const uint64_t lo = (uint64_t)i * chunk_bytes_, hi = std::min<uint64_t>(lo + chunk_bytes_, file_size_);
+#ifdef MADV_POPULATE_READ
+                {  // map the chunk's pages in one call instead of one fault per 4 KB from every thread at once (they all share one mm)
+                    const uint64_t a = lo & ~4095ull, e = std::min<uint64_t>(file_size_, hi + (1u << 20));
+                    madvise(const_cast<uint8_t *>(m) + a, e - a, MADV_POPULATE_READ);
+                }
+#endif
                 // [first, last): from the first record start at or after lo to the first one at or after hi -- the same cut as the
                 // chunked reader's, so that a last record the validator cannot vouch for (CR-LF file without a final newline)
                 // stays with its predecessor
