@@ -88,7 +88,11 @@ def build(force=False, verbose=False):
     if not force and is_fresh():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Wno-align-mismatch", "-o", LIB] + SOURCES
+    # -amdgpu-atomic-optimizer-strategy=None: the optimizer rewrites `if (lane == 0) r = atomicAdd(counter, 1)` into a wave reduction
+    # whose result is read back (s_waitcnt vmcnt(0) + v_readfirstlane) right behind the atomic -- which turns map_kernel's prefetch of
+    # the next work item (issued a whole seed phase before it is needed) into a memory round trip every wave waits for, per read
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Wno-align-mismatch",
+           "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-o", LIB] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
