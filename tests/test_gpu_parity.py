@@ -91,6 +91,48 @@ def test_index_matches_oracle(mq, oracle, simlib, ps):
                    (int(e["id"]), int(e["start"]), int(e["end"]), int(e["offset"]), int(e["rc"]))
 
 
+def test_crowded_table_long_probe_walks(mq, oracle, simlib, monkeypatch, tmp_path):
+    """The bucket table at half load (MQ_TABLE_FACTOR=2: two slots per inserted k-min-mer, rounded up to a power of two), where a
+    lookup often finds both ways of its home bucket taken and walks on for several buckets (the product default, load <= 1/8, walks
+    for about one lookup in a hundred, and then one bucket): every key of the reference, absent keys and the key 0 answer like the
+    oracle's map (src/index.rs:118-126), the reads map identically, the index survives save -> load, and probes per lookup are
+    well above the default's."""
+    monkeypatch.setenv("MQ_TABLE_FACTOR", "2")
+    ps = dict(k=3, l=12, density=0.05)
+    g, off, names = simlib.make_genome([700000, 500000], seed=23, repeat_frac=0.2, tandem_frac=0.03)
+    reads = simlib.make_reads(g, off, 500, seed=4, len_mean=9000, len_sd=3000)
+    ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads, ps)
+    _cmp_hits(hits, want)
+    st = ix.stats()
+    assert st["n_keys"] == ox.keys() and st["table_slots"] <= 4 * st["n_kminmers"] and st["n_keys"] > 0.2 * st["table_slots"]
+    po = oracle.params(**ps)
+    hs = np.unique(np.concatenate([oracle.kminmers(g[int(off[r]):int(off[r + 1])], po)["hash"] for r in range(2)]))
+    rng = np.random.default_rng(2)
+    q = np.concatenate([hs, rng.integers(0, 2**63, size=5000, dtype=np.uint64), np.zeros(1, np.uint64)])
+    for index in (ix,):
+        found, ent, ids = index.lookup(q)
+        want_found = np.array([ox.get(int(h)) is not None for h in q])
+        assert np.array_equal(found.astype(bool), want_found)
+        for i in np.flatnonzero(want_found)[::37]:
+            e = ox.get(int(q[i]))
+            assert (int(ids[i]), int(ent[i]["start"]), int(ent[i]["end"]), int(ent[i]["offset"]), int(ent[i]["rev"])) == \
+                   (int(e["id"]), int(e["start"]), int(e["end"]), int(e["offset"]), int(e["rc"]))
+    p = str(tmp_path / "crowded.mqx")
+    ix.save(p)
+    ix2 = mq.Index.load(p)
+    assert ix2.stats() == st
+    assert np.array_equal(ix2.map_batch(reads["bases"], reads["offsets"]).view(np.uint8), hits.view(np.uint8))
+    found2, _, _ = ix2.lookup(q)
+    assert np.array_equal(found2, found)
+    # probes per lookup on this batch (instrumented launch): a crowded table makes the walk visible
+    from hipmem import DevBuf
+    offs = reads["offsets"]
+    d_b, d_o, d_h = DevBuf.from_numpy(reads["bases"]), DevBuf.from_numpy(offs), DevBuf((offs.size - 1) * 40)
+    lookups, extra = ix.probe_stats(d_b.ptr, d_o.ptr, offs.size - 1, int(offs[-1]), d_h.ptr)
+    assert lookups > 10000 and extra / lookups > 0.15  # the default table: 0.085
+    assert np.array_equal(d_h.to_numpy(mq.hit_dtype, offs.size - 1).view(np.uint8), hits.view(np.uint8))
+
+
 def _map_both(mq, oracle, g, off, names, reads, ps):
     P, po = mq.Params(**ps), oracle.params(**ps)
     ix, ox = mq.Index(P), oracle.Index()

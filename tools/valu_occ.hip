@@ -50,6 +50,31 @@ constexpr int ITER = 1500;
     }
 DEF_KERNEL(k_alignbit, I_ALIGNBIT)
 DEF_KERNEL(k_xor, I_XOR)
+// selects: v_cndmask with vcc (as the compiler emits it for ?:), with an SGPR-pair mask, and the arithmetic select v_bfi
+#define I_CND_VCC(r) "v_cndmask_b32 " r ", " r ", %8, vcc\n"
+#define I_CND_SGPR(r) "v_cndmask_b32_e64 " r ", " r ", %8, s[20:21]\n"
+#define I_BFI(r) "v_bfi_b32 " r ", %8, " r ", %8\n"
+__global__ void k_cnd_vcc(uint32_t seed, uint32_t other, unsigned long long *out) {
+    extern __shared__ uint32_t lds[];
+    OPS_DECL;
+    lds[threadIdx.x] = seed;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < ITER; ++it) asm volatile("v_cmp_lt_u32 vcc, %0, %8\n" BODY64(I_CND_VCC) : OPS_IO : "v"(other) : "memory", "vcc");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    STAMP(t0)
+}
+__global__ void k_cnd_sgpr(uint32_t seed, uint32_t other, unsigned long long *out) {
+    extern __shared__ uint32_t lds[];
+    OPS_DECL;
+    lds[threadIdx.x] = seed;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < ITER; ++it) asm volatile("v_cmp_lt_u32 s[20:21], %0, %8\n" BODY64(I_CND_SGPR) : OPS_IO : "v"(other) : "memory", "s20", "s21");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    STAMP(t0)
+}
+DEF_KERNEL(k_bfi, I_BFI)
 
 // a stage-B step without its table read: 4 xor, 2 alignbit, min, cmp + addc, shift, and = 11 VALU on a 4-register state
 #define STEP_MIX                                   \
@@ -122,6 +147,9 @@ int main() {
     const std::vector<Test> tests = {
         {"v_alignbit_b32 (VOP3)", k_alignbit, 64},
         {"v_xor_b32 (VOP2)", k_xor, 64},
+        {"v_cndmask_b32 with vcc (one v_cmp per 64)", k_cnd_vcc, 64},
+        {"v_cndmask_b32_e64 with an SGPR-pair mask", k_cnd_sgpr, 64},
+        {"v_bfi_b32 (arithmetic select)", k_bfi, 64},
         {"stage-B mix, 11 VALU per step, no LDS", k_mix, 88},
         {"stage-B step with ds_read_b128 ring (per VALU, 11 per step)", k_step_lds, 16 * 11},
     };
