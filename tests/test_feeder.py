@@ -31,8 +31,10 @@ def _make(n, fastq, multiline, crlf, rng):
     return recs, "".join(out)
 
 
-def _dump(tool, path, fastq, chunk, threads):
-    r = subprocess.run([tool, str(path), "fastq" if fastq else "fasta", str(chunk), str(threads)], capture_output=True, text=True, timeout=60)
+def _dump(tool, path, fastq, chunk, threads, env=None):
+    import os
+    r = subprocess.run([tool, str(path), "fastq" if fastq else "fasta", str(chunk), str(threads)], capture_output=True, text=True, timeout=60,
+                       env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr
     got = [ln.split("\t") for ln in r.stdout.split("\n") if ln != ""]
     return [g if len(g) == 3 else g + [""] for g in got]
@@ -74,6 +76,13 @@ def test_feeder_matches_plain_parser(tool, tmp_path, fastq, multiline, crlf):
         for path in (raw, gz):
             for chunk, th in ((64, 4), (1000, 1), (5000, 4), (1 << 28, 2)):
                 assert _dump(tool, path, fastq, chunk, th) == want, (str(path), chunk, th, trailing)
+        # the other reader of each form: gzip streamed through zlib (default: members inflated whole by libdeflate), FASTQ read
+        # with pread as it is (default: header and sequence lines copied out of the mapped file)
+        for chunk, th in ((64, 3), (5000, 4)):
+            assert _dump(tool, gz, fastq, chunk, th, {"MQ_FEEDER_NO_LIBDEFLATE": "1"}) == want
+            assert _dump(tool, gz, fastq, chunk, th, {"MQ_GZ_WHOLE_LIMIT": "0"}) == want
+            if fastq:
+                assert _dump(tool, raw, fastq, chunk, th, {"MQ_FEEDER_NO_LEAN_FASTQ": "1"}) == want
 
 
 def test_feeder_reads_lz4_frames(tool, tmp_path):
@@ -141,8 +150,10 @@ def test_feeder_rejects_truncated_compressed_input(tool, tmp_path):
             blob = fr[:len(fr) // 2]
         p = tmp_path / name
         p.write_bytes(blob)
-        r = subprocess.run([tool, str(p), "fasta", "4096", "2"], capture_output=True, text=True, timeout=60)
-        assert r.returncode != 0 and "truncated" in r.stderr, (name, r.returncode, r.stderr[-200:])
+        import os
+        for env in ({}, {"MQ_FEEDER_NO_LIBDEFLATE": "1"}):
+            r = subprocess.run([tool, str(p), "fasta", "4096", "2"], capture_output=True, text=True, timeout=60, env=dict(os.environ, **env))
+            assert r.returncode != 0 and "truncated" in r.stderr, (name, env, r.returncode, r.stderr[-200:])
     # two whole members back to back are fine (concatenated gzip files), and so is an empty file
     two = tmp_path / "two.fa.gz"
     two.write_bytes(gz + gz)
@@ -194,3 +205,21 @@ def test_reference_loader_matches_plain_parser(tool, tmp_path, multiline, crlf):
     bad = tmp_path / "bad.fa"
     bad.write_text("ACGT\n>r\nAC\n")
     assert subprocess.run([tool, str(bad), "ref", "0", "2"], capture_output=True).returncode != 0
+
+
+def test_feeder_gzip_members_cut_anywhere(tool, tmp_path):
+    """Concatenated gzip members whose boundaries fall in the middle of records and lines (what `cat a.gz b.gz` of arbitrary
+    pieces gives): the whole-member reader carries the unfinished record into the next member; identical to the plain parser, to
+    the zlib reader, for FASTA and FASTQ."""
+    for fastq in (False, True):
+        recs, text = _make(300, fastq, not fastq, False, random.Random(51 + fastq))
+        data = text.encode()
+        rng = random.Random(7)
+        cuts = sorted(rng.sample(range(1, len(data)), 9))
+        blob = b"".join(gzip.compress(data[a:b]) for a, b in zip([0] + cuts, cuts + [len(data)]))
+        p = tmp_path / ("m.fq.gz" if fastq else "m.fa.gz")
+        p.write_bytes(blob)
+        want = [[a, str(len(b)), b] for a, b in recs]
+        for chunk, th in ((64, 4), (3000, 2), (1 << 26, 3)):
+            assert _dump(tool, p, fastq, chunk, th) == want, (fastq, chunk)
+            assert _dump(tool, p, fastq, chunk, th, {"MQ_FEEDER_NO_LIBDEFLATE": "1"}) == want
