@@ -327,7 +327,7 @@ def main():
     torch.cuda.synchronize()
     assert torch.equal(d_out, d_out2), "instrumented launch disagrees with the timed one"
     p_bar = 1.0 + extra / max(lookups, 1)
-    alg_bytes = total_bases * 1 + n_kmm * st["slot_bytes"] * p_bar + n * (8 + 40)
+    alg_bytes = total_bases * 1 + n_kmm * st["slot_bytes"] * p_bar + n * (8 + 40)  # SURVEY 8(d)'s S_out = 40 B (the result record is 48 B since ABI 3)
     achieved = alg_bytes / avg_kern_s / 1e9
     traffic = None
     traffic_commit = None
@@ -381,7 +381,7 @@ def main():
         t10, t10_lo, t10_hi, reps10, _ = timed(10)
         m = want["mapped"] != 0
         same = bool(np.array_equal(hits["status"][:ns] == 1, m)) and all(
-            np.array_equal(hits[a][:ns][m].astype(np.uint64), want[a][m].astype(np.uint64))
+            np.array_equal(mq.hit_column(hits[:ns], a)[m], want[a][m].astype(np.uint64))
             for a in ("ref_id", "rc", "mapq", "q_start", "q_end", "r_start", "r_end", "score"))
         sb_bases = int(so[-1])
         cpu = dict(value=round(sb_bases / t_cpu / 1e9, 4), unit="Gbases/s", cores=ncpu, kind="port",

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MQ_ABI_VERSION 2
+#define MQ_ABI_VERSION 3
 
 #define MQ_OK 0
 #define MQ_EINVAL (-1)
@@ -64,8 +64,11 @@ typedef struct mq_kminmer {
     uint32_t rev;
 } mq_kminmer;
 
-/* Result of find_matches for one read: the numeric PAF columns of src/mers.rs:181.  40 bytes.
- * status 0 => the reference returns None (no line is written, src/closures.rs:119-121). */
+/* Result of find_matches for one read: the numeric PAF columns of src/mers.rs:181.  48 bytes.
+ * status 0 => the reference returns None (no line is written, src/closures.rs:119-121).
+ * Columns 3 and 4 are 64-bit (low word, high word): find_coords computes in usize and a run that the Match::check precedence
+ * quirk (src/match.rs:39-43) extended onto ANOTHER, longer reference makes `r_len - r_end - 1` wrap (src/mers.rs:131-183; release
+ * builds wrap silently), so the reference prints values like 18446744073709547279 there -- and so does mq_format_paf. */
 #define MQ_HIT_UNMAPPED 0u
 #define MQ_HIT_MAPPED 1u
 #define MQ_HIT_OVERFLOW 2u /* more Match runs than the per-read scratch holds: result NOT computed (loud, never silent) */
@@ -74,12 +77,14 @@ typedef struct mq_hit {
     uint32_t ref_id;     /* index passed to mq_index_add_ref */
     uint32_t rc;         /* 1 => '-' */
     uint32_t mapq;       /* 0 or 60 */
-    uint32_t q_start;    /* column 3 */
-    uint32_t q_end;      /* column 4 (inclusive, as the reference prints it) */
+    uint32_t q_start;    /* column 3, low 32 bits */
+    uint32_t q_end;      /* column 4 (inclusive, as the reference prints it), low 32 bits */
     uint32_t r_start;    /* column 8 */
     uint32_t r_end;      /* column 9 (inclusive) */
     uint32_t score;      /* column 10: number of matching k-min-mers */
     uint32_t n_kminmers; /* k-min-mers extracted from the read (diagnostic) */
+    uint32_t q_start_hi; /* column 3, high 32 bits (0 unless the usize arithmetic of find_coords wrapped) */
+    uint32_t q_end_hi;   /* column 4, high 32 bits */
 } mq_hit;
 
 typedef struct mq_index mq_index; /* opaque: Index / ReadOnlyIndex (src/index.rs:73-128) + ref_map (src/closures.rs:30) */

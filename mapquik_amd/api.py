@@ -15,9 +15,17 @@ MQ_HIT_UNMAPPED, MQ_HIT_MAPPED, MQ_HIT_OVERFLOW = 0, 1, 2
 MQ_FLAG_FOLD_CASE = 1
 
 hit_dtype = np.dtype([("status", "<u4"), ("ref_id", "<u4"), ("rc", "<u4"), ("mapq", "<u4"), ("q_start", "<u4"), ("q_end", "<u4"),
-                      ("r_start", "<u4"), ("r_end", "<u4"), ("score", "<u4"), ("n_kminmers", "<u4")])
+                      ("r_start", "<u4"), ("r_end", "<u4"), ("score", "<u4"), ("n_kminmers", "<u4"), ("q_start_hi", "<u4"), ("q_end_hi", "<u4")])
 kminmer_dtype = np.dtype([("hash", "<u8"), ("start", "<u4"), ("end", "<u4"), ("offset", "<u4"), ("rev", "<u4")])
-assert hit_dtype.itemsize == 40 and kminmer_dtype.itemsize == 24
+assert hit_dtype.itemsize == 48 and kminmer_dtype.itemsize == 24
+
+
+def hit_column(hits, name):
+    """A PAF column of a hits array as uint64: columns 3 and 4 (q_start, q_end) are 64-bit in mq_hit (low word + *_hi)."""
+    v = hits[name].astype(np.uint64)
+    if name in ("q_start", "q_end"):
+        v = v | (hits[name + "_hi"].astype(np.uint64) << np.uint64(32))
+    return v
 
 # every symbol include/mapquik_hip.h declares
 EXPORTS = ["mq_last_error", "mq_abi_version", "mq_device_count", "mq_params_default", "mq_index_new", "mq_index_free",

@@ -147,7 +147,7 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
     const uint32_t lane = lane_id();
     const DevParams &P = A.P;
     h.status = MQ_HIT_UNMAPPED;
-    h.ref_id = h.rc = h.mapq = h.q_start = h.q_end = h.r_start = h.r_end = h.score = h.n_kminmers = 0;
+    h.ref_id = h.rc = h.mapq = h.q_start = h.q_end = h.r_start = h.r_end = h.score = h.n_kminmers = h.q_start_hi = h.q_end_hi = 0;
     uint32_t n_kmm = 0;
     if (cnt == LIST_OVERFLOW) {
         h.status = MQ_HIT_OVERFLOW;  // the list fits neither its region nor the pool: nothing was computed for this read
@@ -1986,8 +1986,9 @@ int mq_format_paf(const mq_index *idx, const char *q_id, uint64_t q_len, const m
     if (it == idx->refs.end()) return set_err(MQ_EINVAL, "unknown ref_id in hit");
     const unsigned long long r_len = it->second.second;
     // src/mers.rs:181: column 11 repeats r_len, column 10 is the score
-    int w = snprintf(buf, cap, "%s\t%llu\t%u\t%u\t%s\t%s\t%llu\t%u\t%u\t%u\t%llu\t%u", q_id, (unsigned long long)q_len, hit->q_start,
-                     hit->q_end, hit->rc ? "-" : "+", it->second.first.c_str(), r_len, hit->r_start, hit->r_end, hit->score, r_len,
+    const unsigned long long qs = ((unsigned long long)hit->q_start_hi << 32) | hit->q_start, qe = ((unsigned long long)hit->q_end_hi << 32) | hit->q_end;
+    int w = snprintf(buf, cap, "%s\t%llu\t%llu\t%llu\t%s\t%s\t%llu\t%u\t%u\t%u\t%llu\t%u", q_id, (unsigned long long)q_len, qs, qe,
+                     hit->rc ? "-" : "+", it->second.first.c_str(), r_len, hit->r_start, hit->r_end, hit->score, r_len,
                      hit->mapq);
     return w;
 } catch (const std::bad_alloc &) {

@@ -483,7 +483,7 @@ __device__ __forceinline__ void chain_stage(MatchRec *__restrict__ scratch, uint
     out.ref_id = 0;
     out.rc = 0;
     out.mapq = 0;
-    out.q_start = out.q_end = out.r_start = out.r_end = out.score = 0;
+    out.q_start = out.q_end = out.r_start = out.r_end = out.score = out.q_start_hi = out.q_end_hi = 0;
     if (n_cand == 0) return;
     if (n_cand > 1 && max_count == second_count) return;  // determine_best_match: tie => None (src/mers.rs:106)
     // get_match coordinates (src/chain.rs:162-168), usize arithmetic
@@ -517,8 +517,13 @@ __device__ __forceinline__ void chain_stage(MatchRec *__restrict__ scratch, uint
     out.ref_id = b_ref;
     out.rc = rc ? 1u : 0u;
     out.mapq = b_mapq;
-    out.q_start = (uint32_t)(q_start - exc_s);
-    out.q_end = (uint32_t)(q_end + exc_e);
+    // usize arithmetic, wrapping like a release build: exc_s / exc_e wrap when the run's r_end lies beyond THIS reference's end
+    // (a run the precedence quirk extended onto another, longer reference); all 64 bits go out
+    const uint64_t qs64 = q_start - exc_s, qe64 = q_end + exc_e;
+    out.q_start = (uint32_t)qs64;
+    out.q_end = (uint32_t)qe64;
+    out.q_start_hi = (uint32_t)(qs64 >> 32);
+    out.q_end_hi = (uint32_t)(qe64 >> 32);
     out.r_start = (uint32_t)frs;
     out.r_end = (uint32_t)fre;
     out.score = b_score;

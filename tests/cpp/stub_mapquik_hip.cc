@@ -120,7 +120,8 @@ int mq_format_paf(const mq_index *i, const char *q_id, uint64_t q_len, const mq_
     auto it = i->refs.find(h->ref_id);
     if (it == i->refs.end()) { g_err = "unknown ref"; return MQ_EINVAL; }
     const unsigned long long rl = it->second.second;
-    return snprintf(buf, cap, "%s\t%llu\t%u\t%u\t%s\t%s\t%llu\t%u\t%u\t%u\t%llu\t%u", q_id, (unsigned long long)q_len, h->q_start, h->q_end,
+    return snprintf(buf, cap, "%s\t%llu\t%llu\t%llu\t%s\t%s\t%llu\t%u\t%u\t%u\t%llu\t%u", q_id, (unsigned long long)q_len,
+                    ((unsigned long long)h->q_start_hi << 32) | h->q_start, ((unsigned long long)h->q_end_hi << 32) | h->q_end,
                     h->rc ? "-" : "+", it->second.first.c_str(), rl, h->r_start, h->r_end, h->score, rl, h->mapq);
 }
 void *mq_host_alloc(size_t n) { return malloc(n ? n : 1); }

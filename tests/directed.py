@@ -8,6 +8,9 @@ tests (the HIP path agrees with the oracle on exactly those reads).
   tie     two candidate references with equal scores => None (src/mers.rs:104-108): a chimeric read with as many
           matching k-min-mers on A as on B.
   wrap    `as i32` casts in the gap tests (src/chain.rs:132-142): reads on a contig longer than 2^31 bases.
+  usize   find_coords (src/mers.rs:131-183) computes in usize and wraps in a release build: a forward run that the quirk
+          extended onto ANOTHER reference, at a position beyond the end of the reference the run is keyed under, makes
+          `r_len - r_end - 1` wrap, and the reference prints q_end = 2^64 - something in column 4.
 """
 import numpy as np
 
@@ -40,6 +43,39 @@ def quirk_case(O, sim, n_want=24, seed=101):
         if a_hi > int(ka[o + 1]["start"]):
             continue
         b_lo = int(kb[o + 1]["start"])                        # the B part opens with B's minimizer of offset o + 1
+        b_hi = int(kb[o + 14]["end"]) + 2 * l
+        seqs.append(np.concatenate([A[a_lo:a_hi], B[b_lo:b_hi]]))
+        if len(seqs) >= 6 * n_want:
+            break
+    bases, offs = _concat(seqs)
+    return g, off, names, bases, offs, dict(QUIRK_PARAMS)
+
+
+def usize_wrap_case(O, sim, n_want=24, seed=404):
+    """quirk_case with the second reference B = 200 kb homopolymer run (one compressed base: no minimizer) + random sequence, so
+    that B's minimizer of offset o + 1 lies beyond the END of reference A (150 kb): the run keyed under A ends with B's
+    coordinates and find_coords' `r_len - r_end - 1` wraps."""
+    ga, _, _ = sim.make_genome([150000], seed=seed)
+    gb, _, _ = sim.make_genome([150000], seed=seed + 1)
+    head = np.full(200000, ord("A"), dtype=np.uint8)
+    if gb[0] == ord("A"):
+        gb[0] = ord("C")
+    A, B = ga, np.concatenate([head, gb])
+    g = np.concatenate([A, B])
+    off = np.array([0, A.size, A.size + B.size], dtype=np.uint64)
+    names = ["short", "long"]
+    po = O.params(**QUIRK_PARAMS)
+    ka, kb = O.kminmers(A, po), O.kminmers(B, po)
+    l = QUIRK_PARAMS["l"]
+    seqs = []
+    rng = np.random.default_rng(seed)
+    for o in rng.permutation(np.arange(40, min(len(ka), len(kb)) - 40))[:40 * n_want]:
+        o = int(o)
+        a_lo = int(ka[o - 12]["start"])
+        a_hi = max(int(ka[o]["end"]) + 1, int(ka[o]["start"]) + 2 * l)
+        if a_hi > int(ka[o + 1]["start"]):
+            continue
+        b_lo = int(kb[o + 1]["start"])
         b_hi = int(kb[o + 14]["end"]) + 2 * l
         seqs.append(np.concatenate([A[a_lo:a_hi], B[b_lo:b_hi]]))
         if len(seqs) >= 6 * n_want:

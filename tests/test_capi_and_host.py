@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_abi_version_and_defaults(lib):
     import mapquik_amd
-    assert lib.mq_abi_version() == 2
+    assert lib.mq_abi_version() == 3  # 3: mq_hit carries columns 3 and 4 as 64 bits (48-byte records)
     p = mapquik_amd.Params()
     q = mapquik_amd.Params(0, 0, 0.0, False, 0, 0, 0)
     lib.mq_params_default(C.byref(q))
@@ -45,9 +45,9 @@ def test_abi_version_and_defaults(lib):
 
 def test_record_layouts_match_header():
     import mapquik_amd
-    assert mapquik_amd.hit_dtype.itemsize == 40 and mapquik_amd.kminmer_dtype.itemsize == 24
+    assert mapquik_amd.hit_dtype.itemsize == 48 and mapquik_amd.kminmer_dtype.itemsize == 24
     assert [n for n in mapquik_amd.hit_dtype.names] == ["status", "ref_id", "rc", "mapq", "q_start", "q_end", "r_start", "r_end",
-                                                       "score", "n_kminmers"]
+                                                       "score", "n_kminmers", "q_start_hi", "q_end_hi"]
 
 
 def test_no_cpu_fallback_without_gpu(lib):

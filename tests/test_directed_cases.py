@@ -33,3 +33,19 @@ def test_tie_reads_are_unmapped(oracle, simlib):
     assert (out["mapped"][ties] == 0).all() and (diag["n_candidates"][ties] == 2).all()
     assert (diag["n_candidates"] > 1).sum() > 1000  # every chimeric read offers two candidate references
     assert (out["mapped"][diag["tie"] == 0] != 0).mean() > 0.99
+
+
+def test_usize_wrap_reads_print_a_wrapped_column(oracle, simlib):
+    """find_coords in usize (src/mers.rs:131-183): a forward run keyed under the SHORT reference that ends on the long one has
+    r_end beyond the short reference's end, `r_len - r_end - 1` wraps (release build) and column 4 becomes 2^64 - something."""
+    g, off, names, bases, offs, ps = D.usize_wrap_case(oracle, simlib)
+    po = oracle.params(**ps)
+    ox = oracle.Index()
+    ox.build_mt(g, off, names, po, 2)
+    out, diag = ox.map_batch_diag(bases, offs, po, threads=4)
+    wrapped = np.nonzero((out["mapped"] != 0) & (out["q_end"] >= (1 << 63)))[0]
+    assert wrapped.size >= 10 and (diag["quirk_cross_ref"][wrapped] > 0).all() and (out["ref_id"][wrapped] == 0).all()
+    i = int(wrapped[0])
+    assert int(out["r_end"][i]) == int(off[1]) - 1          # clipped at the short reference's end
+    line = oracle.paf_lines(ox, ["q%d" % j for j in range(offs.size - 1)], out)
+    assert any(int(ln.split("\t")[3]) >= (1 << 63) for ln in line)

@@ -30,8 +30,27 @@ def _build(mq, oracle, g, off, names, ps, threads=8):
 def _cmp(hits, want):
     assert np.array_equal(hits["status"] == 1, want["mapped"] != 0)
     m = want["mapped"] != 0
+    import mapquik_amd
     for a in ("ref_id", "rc", "mapq", "q_start", "q_end", "r_start", "r_end", "score"):
-        assert np.array_equal(hits[a][m].astype(np.uint64), want[a][m].astype(np.uint64)), a
+        assert np.array_equal(mapquik_amd.hit_column(hits, a)[m], want[a][m].astype(np.uint64)), a
+
+
+def test_usize_wrap_in_find_coords_on_gpu(mq, oracle, simlib):
+    """Columns 3 and 4 are usize in the reference and wrap (src/mers.rs:131-183, release build) when a run the precedence quirk
+    extended onto another, longer reference ends beyond the end of the reference it is keyed under: mq_hit carries all 64 bits
+    and the PAF text is the reference's (found by the fuzz test, seed 22 case 1469)."""
+    g, off, names, bases, offs, ps = D.usize_wrap_case(oracle, simlib)
+    ix, ox, po = _build(mq, oracle, g, off, names, ps)
+    want = ox.map_batch(bases, offs, po, threads=4)
+    n_wrapped = int(((want["mapped"] != 0) & (want["q_end"] >= (1 << 63))).sum())
+    assert n_wrapped >= 10
+    hits = ix.map_batch(bases, offs)
+    _cmp(hits, want)
+    assert int((hits["q_end_hi"] == 0xFFFFFFFF).sum()) == n_wrapped
+    names_q = ["q%d" % i for i in range(offs.size - 1)]
+    got = ix.paf_lines(names_q, offs, hits)
+    assert got == oracle.paf_lines(ox, names_q, want)
+    assert sum(1 for ln in got if int(ln.split("\t")[3]) >= (1 << 63)) == n_wrapped
 
 
 def test_match_check_precedence_quirk_on_gpu(mq, oracle, simlib):
