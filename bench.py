@@ -39,6 +39,10 @@ def parse():
                     "(0.8 = maize-like stress: most k-min-mers are tombstoned, lookups miss, Matches are short)")
     ap.add_argument("--tandem-frac", type=float, default=0.01)
     ap.add_argument("--repeat-div", type=float, default=0.01, help="per-base divergence of the planted copies")
+    ap.add_argument("--genome-preset", choices=("planted-repeats", "human-like"), default="planted-repeats",
+                    help="planted-repeats (default, the BASELINE stand-in of rounds 1-3): --repeat-frac / --tandem-frac / --repeat-div; human-like: "
+                         "tools/sim.py HUMAN_LIKE (6 %% satellite arrays, 5 %% segmental duplications, young interspersed copies) -- reads from "
+                         "inside satellites and recent duplications do not map uniquely, as on a real genome")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default, the BASELINE metric): every rank maps its own HBM-resident batch of --reads reads; strong: ONE fixed "
                          "read set of --reads reads in host memory is dealt to the ranks (mapquik_amd.shard) and mapped through the "
@@ -223,8 +227,11 @@ def main():
     # ---- genome (same on every rank: the index is replicated)
     t0 = time.time()
     lens = [max(40, int(x * args.genome_scale)) for x in sim.CHM13_LIKE]
-    genome, ctg_off, ctg_names = sim.make_genome(lens, seed=args.seed, threads=threads, repeat_frac=args.repeat_frac,
-                                                 tandem_frac=args.tandem_frac, div=args.repeat_div)
+    if args.genome_preset == "human-like":
+        genome, ctg_off, ctg_names = sim.make_genome(lens, seed=args.seed, threads=threads, **sim.HUMAN_LIKE)
+    else:
+        genome, ctg_off, ctg_names = sim.make_genome(lens, seed=args.seed, threads=threads, repeat_frac=args.repeat_frac,
+                                                     tandem_frac=args.tandem_frac, div=args.repeat_div)
     t_genome = time.time() - t0
 
     # ---- index on this rank's GPU (Index::add_with_mer + into_read_only on device)
@@ -457,6 +464,7 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {
+                "genome_preset": args.genome_preset,
                 "workload": "CHM13v2.0-like synthetic genome (25 contigs, %.3f Gbp, scale %.3g, %g%% planted repeats) "
                             "x pbsim-like HiFi reads (mean 24 kb, 1%% error); k=%d l=%d d=%g HPC"
                             % (sum(lens) / 1e9, args.genome_scale, 100 * args.repeat_frac, args.k, args.l, args.density),

@@ -334,6 +334,24 @@ class Feeder {
         ready_.pop_front();
         return c;
     }
+    // next(), without waiting: a parsed chunk if one is ready, else nullptr -- `end` says whether the input is exhausted (or the
+    // consumer aborted).  For consumers that hold chunks of their own and must not sit on them while nothing new arrives.
+    Chunk *poll(bool &end) {
+        std::lock_guard<std::mutex> lk(mu_);
+        end = false;
+        if (aborted_) {
+            end = true;
+            return nullptr;
+        }
+        if (!error_.empty()) throw FeederError(error_);
+        if (ready_.empty()) {
+            end = finished_locked();
+            return nullptr;
+        }
+        Chunk *c = ready_.front();
+        ready_.pop_front();
+        return c;
+    }
     // hand a chunk back for re-use
     void recycle(Chunk *c) {
         c->clear();

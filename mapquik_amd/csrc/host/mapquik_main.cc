@@ -223,6 +223,8 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             workers.emplace_back([&, g]() {
                 std::vector<mq_ctx *> ctx((size_t)n_slots, nullptr);
                 std::vector<Chunk *> inflight((size_t)n_slots, nullptr);
+                std::vector<size_t> age((size_t)n_slots, 0);  // submit order of the chunk in the slot
+                size_t submitted = 0;
                 auto finish_slot = [&](int sl) {
                     if (!inflight[sl]) return;
                     if (mq_ctx_wait(ctx[sl]) != MQ_OK) fail(std::string("mq_ctx_wait: ") + last_error());
@@ -233,6 +235,13 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                     inflight[sl] = nullptr;
                     cv.notify_all();
                 };
+                // the slot to use next: a free one, else the one submitted longest ago (-1 with free_only when none is free)
+                auto oldest_busy = [&]() {
+                    int best = -1;
+                    for (int sl = 0; sl < n_slots; ++sl)
+                        if (inflight[sl] && (best < 0 || age[sl] < age[best])) best = sl;
+                    return best;
+                };
                 try {
                     for (int sl = 0; sl < n_slots; ++sl) {
                         ctx[sl] = mq_ctx_new(ro[g]->handle());
@@ -241,13 +250,31 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                         if (mq_ctx_reserve(ctx[sl], (uint32_t)std::min<uint64_t>(cb / 2000 + 1024, 1u << 24), cb) != MQ_OK)
                             throw Error(std::string("mq_ctx_reserve: ") + last_error());
                     }
-                    for (size_t k = 0;; ++k) {
+                    for (;;) {
                         if (failed()) break;  // somebody failed: stop pulling chunks
-                        Chunk *c = feed.next();
-                        if (!c) break;
+                        // Never wait for a new chunk while holding submitted ones: the writer may be waiting for exactly one of
+                        // them while every other buffer of the pool sits behind the writer (formatted, out of turn) -- then no
+                        // new chunk can ever be parsed.  With nothing ready, the oldest submitted chunk is passed on first.
+                        bool end = false;
+                        Chunk *c = feed.poll(end);
+                        if (!c) {
+                            if (end) break;
+                            const int busy = oldest_busy();
+                            if (busy >= 0) {
+                                finish_slot(busy);
+                                continue;
+                            }
+                            c = feed.next();
+                            if (!c) break;
+                        }
                         if (fail_at >= 0 && (long)c->seq_no == fail_at) throw Error("injected failure (MQ_DRIVER_FAIL_AT)");
-                        const int sl = (int)(k % (size_t)n_slots);
-                        finish_slot(sl);
+                        int sl = -1;
+                        for (int q = 0; q < n_slots; ++q)
+                            if (!inflight[q]) { sl = q; break; }
+                        if (sl < 0) {
+                            sl = oldest_busy();
+                            finish_slot(sl);
+                        }
                         c->hits.resize(c->starts.size());
                         if (c->starts.empty()) {  // nothing to map in this chunk (the middle of a very long record)
                             std::lock_guard<std::mutex> lk(mu);
@@ -259,8 +286,9 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                                                 c->hits.data()) != MQ_OK)
                             throw Error(std::string("mq_ctx_submit_spans: ") + last_error());
                         inflight[sl] = c;
+                        age[sl] = submitted++;
                     }
-                    for (int sl = 0; sl < n_slots; ++sl) finish_slot(sl);
+                    for (int q = oldest_busy(); q >= 0; q = oldest_busy()) finish_slot(q);
                 } catch (const std::exception &e) { fail(e.what()); }
                 for (auto c : ctx) mq_ctx_free(c);
                 {

@@ -87,3 +87,19 @@ def test_driver_pipeline_under_sanitizers(built, tmp_path, san):
     r = subprocess.run([exe, p["reads.fa"], "--reference", p["ref.fa"], "-p", str(tmp_path / "f"), "--batch-bases", "20000", "--threads", "4",
                         "--gpus", "2"], capture_output=True, text=True, timeout=600, env=dict(_ENV, MQ_STUB_DEVICES="2", MQ_DRIVER_FAIL_AT="20"))
     assert r.returncode == 101 and "injected failure" in r.stderr and "Sanitizer" not in r.stderr, (r.returncode, r.stderr[-2000:])
+
+
+def test_driver_does_not_deadlock_on_a_small_pool(built, tmp_path):
+    """Regression: the submit thread used to WAIT for a new chunk while holding submitted ones; when the writer was waiting for
+    exactly one of those and every other buffer of the pool sat behind the writer (formatted, out of turn), no new chunk could be
+    parsed and the run hung (about one run in five with these sizes: 60 chunks of 20 kB through a pool of 12).  Many runs, each
+    under a timeout; the TSan build widens the timing windows."""
+    p, recs = _inputs(tmp_path)
+    exe = built["mapquik_tsan"]
+    n_long = sum(1 for _, b in recs if len(b) >= 50)
+    for it in range(30):
+        for env, extra in (({"MQ_DRIVER_NO_PREFETCH": "1"}, []), ({"MQ_STUB_DEVICES": "2"}, ["--gpus", "2"])):
+            r = subprocess.run([exe, p["reads.fa"], "--reference", p["ref.fa"], "-p", str(tmp_path / "o"), "--batch-bases", "20000", "--threads", "4"] + extra,
+                               capture_output=True, text=True, timeout=90, env=dict(_ENV, **env))
+            _clean(r)
+        assert sum(1 for _ in open(str(tmp_path / "o.paf"))) == n_long

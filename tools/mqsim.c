@@ -135,6 +135,40 @@ void mqsim_plant_families(uint8_t *g, uint64_t len, uint64_t seed, uint64_t n_fa
     free(fl);
 }
 
+/* Satellite arrays (centromere-like): n_arrays arrays of length U[min_len,max_len]; each is a higher-order-repeat unit of
+ * U[unit_lo,unit_hi] bases (taken from the genome at the array's start) repeated end to end, every copy with its own
+ * substitutions at rate `div` -- so copies are (1 - 2 div) identical to each other, like alpha-satellite HOR arrays.  Reads from
+ * inside an array have no unique k-min-mers.  Sequential and deterministic. */
+void mqsim_plant_satellites(uint8_t *g, uint64_t len, uint64_t seed, uint64_t n_arrays, uint64_t min_len, uint64_t max_len,
+                            uint64_t unit_lo, uint64_t unit_hi, double div) {
+    uint64_t s = seed ^ 0x5A7E111735ULL;
+    if (len < 4 * max_len || unit_hi < unit_lo || unit_lo < 2) return;
+    uint8_t *unit = (uint8_t *)malloc(unit_hi);
+    for (uint64_t i = 0; i < n_arrays; i++) {
+        const uint64_t L = min_len + splitmix64(&s) % (max_len - min_len + 1);
+        const uint64_t U = unit_lo + splitmix64(&s) % (unit_hi - unit_lo + 1);
+        const uint64_t dst = splitmix64(&s) % (len - L);
+        memcpy(unit, g + dst, U);
+        const double lg = div > 0 ? log(1.0 - div) : 0;
+        for (uint64_t at = 0; at < L; at += U) {
+            const uint64_t n = at + U <= L ? U : L - at;
+            memcpy(g + dst + at, unit, n);
+            if (div > 0) {
+                uint64_t t = 0;
+                for (;;) {
+                    double u = u01(&s);
+                    if (u < 1e-300) u = 1e-300;
+                    t += (uint64_t)(log(u) / lg);
+                    if (t >= n) break;
+                    g[dst + at + t] = (uint8_t)ACGT[splitmix64(&s) & 3];
+                    t++;
+                }
+            }
+        }
+    }
+    free(unit);
+}
+
 /* Runs of N (assembly gaps): n_runs runs of length U[min_len,max_len]. */
 void mqsim_plant_n(uint8_t *g, uint64_t len, uint64_t seed, uint64_t n_runs, uint64_t min_len, uint64_t max_len) {
     uint64_t s = seed ^ 0x4E4E4E4EULL;

@@ -33,6 +33,7 @@ def lib():
         L.mqsim_plant_repeats.argtypes = [vp, u64, u64, u64, u64, u64, u64, dbl]
         L.mqsim_plant_families.argtypes = [vp, u64, u64, u64, u64, u64, u64, dbl, dbl]
         L.mqsim_plant_n.argtypes = [vp, u64, u64, u64, u64, u64]
+        L.mqsim_plant_satellites.argtypes = [vp, u64, u64, u64, u64, u64, u64, u64, dbl]
         L.mqsim_read_caps.argtypes = [vp, u32, u32, dbl, dbl, u64, u64, u64, vp]
         L.mqsim_reads.argtypes = [vp, vp, u32, u32, dbl, dbl, u64, u64, dbl, dbl, dbl, u64, C.c_int, vp, vp, vp, vp, vp, vp, vp]
         L.mqsim_compact.argtypes = [vp, vp, vp, u32, vp, vp]
@@ -58,10 +59,11 @@ MAIZE_LIKE = [308452471, 243675191, 238017767, 250330460, 226353449, 181357234, 
 
 
 def make_genome(contig_lens, seed=913, threads=8, repeat_frac=0.0, tandem_frac=0.0, div=0.01, prefix="chr", family_frac=0.0,
-                n_families=200, family_div=(0.01, 0.05), n_runs=0):
+                n_families=200, family_div=(0.01, 0.05), n_runs=0, satellite_frac=0.0, satellite_div=0.01, repeat_len=(1000, 20000)):
     """Uniform ACGT contigs; optionally overwrite ~repeat_frac of the bases with copied segments
     (1-20 kb, `div` divergence) and ~tandem_frac with tandem arrays; ~family_frac with copies of `n_families`
-    transposon-like families (1-12 kb, per-copy divergence U[family_div]); `n_runs` runs of N (100-50,000 bases)."""
+    transposon-like families (1-12 kb, per-copy divergence U[family_div]); `n_runs` runs of N (100-50,000 bases);
+    ~satellite_frac with satellite arrays (0.2-3 Mbp of a 0.7-2.8 kb unit, copies `satellite_div` from the unit)."""
     lens = np.asarray(contig_lens, dtype=np.uint64)
     offsets = np.zeros(lens.size + 1, dtype=np.uint64)
     offsets[1:] = np.cumsum(lens)
@@ -69,16 +71,28 @@ def make_genome(contig_lens, seed=913, threads=8, repeat_frac=0.0, tandem_frac=0
     g = np.empty(total, dtype=np.uint8)
     lib().mqsim_genome(_p(g), total, seed, threads)
     if repeat_frac > 0 or tandem_frac > 0:
-        mean_len = 10500
+        mean_len = (repeat_len[0] + repeat_len[1]) // 2
         n_seg = int(total * repeat_frac / mean_len)
         n_tan = int(total * tandem_frac / mean_len)
-        lib().mqsim_plant_repeats(_p(g), total, seed, n_seg, n_tan, 1000, 20000, div)
+        lib().mqsim_plant_repeats(_p(g), total, seed, n_seg, n_tan, repeat_len[0], repeat_len[1], div)
+    if satellite_frac > 0:
+        lo, hi = 200_000, 3_000_000
+        if total >= 4 * hi:
+            lib().mqsim_plant_satellites(_p(g), total, seed, max(1, int(total * satellite_frac / ((lo + hi) // 2))), lo, hi, 700, 2800, satellite_div)
     if family_frac > 0:
         lib().mqsim_plant_families(_p(g), total, seed, n_families, int(total * family_frac), 1000, 12000, family_div[0], family_div[1])
     if n_runs > 0:
         lib().mqsim_plant_n(_p(g), total, seed, n_runs, 100, 50000)
     names = ["%s%d" % (prefix, i + 1) for i in range(lens.size)]
     return g, offsets, names
+
+
+# A human-like repeat landscape for the CHM13-sized stand-in (bench.py --genome-preset human-like): ~6 % satellite arrays (CHM13's
+# share; copies 99.8 % identical), ~5 % segmental duplications of 10-200 kb at 1 % divergence, ~2 % young interspersed copies (0-3 % from their consensus),
+# 1 % short tandem arrays.  Old interspersed repeats (the other ~45 % of a human genome) are > 10 % diverged: no k-min-mer of
+# 5 x 31 bases survives that, so for this path they are unique sequence.
+HUMAN_LIKE = dict(repeat_frac=0.05, repeat_len=(10000, 200000), div=0.01, tandem_frac=0.01, satellite_frac=0.06, satellite_div=0.001,
+                  family_frac=0.02, n_families=300, family_div=(0.0, 0.03))
 
 
 def make_reads(genome, ctg_off, n_reads, seed=1, len_mean=24000.0, len_sd=2300.0, len_min=100, len_max=25000,
