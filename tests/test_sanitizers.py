@@ -76,7 +76,7 @@ def test_driver_pipeline_under_sanitizers(built, tmp_path, san):
     exe = built["mapquik_" + san]
     n_long = sum(1 for _, b in recs if len(b) >= 50)
     for reads, extra, env in ((p["reads.fa"], [], {}), (p["reads.fastq"], ["--gpus", "2", "--unmapped"], {"MQ_STUB_DEVICES": "2"}),
-                              (p["reads.fa.gz"], ["--threads", "3"], {}), (p["reads.fa"], [], {"MQ_DRIVER_NO_PREFETCH": "1"})):
+                              (p["reads.fa.gz"], ["--threads", "3"], {}), (p["reads.fa"], [], {"MQ_DRIVER_PREFETCH": "1"})):
         prefix = str(tmp_path / "out")
         r = subprocess.run([exe, reads, "--reference", p["ref.fa"], "-p", prefix, "--batch-bases", "20000", "--threads", "4"] + extra,
                            capture_output=True, text=True, timeout=600, env=dict(_ENV, **env))
@@ -98,7 +98,7 @@ def test_driver_does_not_deadlock_on_a_small_pool(built, tmp_path):
     exe = built["mapquik_tsan"]
     n_long = sum(1 for _, b in recs if len(b) >= 50)
     for it in range(30):
-        for env, extra in (({"MQ_DRIVER_NO_PREFETCH": "1"}, []), ({"MQ_STUB_DEVICES": "2"}, ["--gpus", "2"])):
+        for env, extra in (({}, []), ({"MQ_DRIVER_PREFETCH": "1"}, []), ({"MQ_STUB_DEVICES": "2"}, ["--gpus", "2"])):
             r = subprocess.run([exe, p["reads.fa"], "--reference", p["ref.fa"], "-p", str(tmp_path / "o"), "--batch-bases", "20000", "--threads", "4"] + extra,
                                capture_output=True, text=True, timeout=90, env=dict(_ENV, **env))
             _clean(r)
