@@ -307,7 +307,30 @@ __device__ __forceinline__ Hash2 window_hash(const SeedTables &T, const SeedLds 
 template <int PH, bool LIM_CHECK>
 __device__ __forceinline__ uint32_t stage_b_block(const SeedTables &T, uint32_t &glo, uint32_t &ghi, uint32_t &hlo, uint32_t &hhi, uint4 (&tv)[4],
                                                   uint32_t xe, uint32_t xo, uint32_t xe_n, uint32_t xo_n, uint32_t bhi, uint32_t lim) {
-    auto nib16 = [](uint32_t xe_, uint32_t xo_, uint32_t s) { return ((((s & 1u) ? xo_ : xe_) >> (4u * (s >> 1))) & 0xFu); };
+    // byte offset of entry (out | in<<2) of step s within a rotation's 16 entries = nibble (s >> 1) of xe / xo, times 16: ONE
+    // SDWA instruction per step (byte select + "& 0xF0" for a high nibble, byte select + "<< 4" cut to a byte for a low one)
+    // where shift + and take two
+    auto off16 = [](uint32_t xe_, uint32_t xo_, uint32_t s) -> uint32_t {
+        const uint32_t x = (s & 1u) ? xo_ : xe_, m = s >> 1;
+        uint32_t r;
+        if (m & 1u) {
+            switch (m >> 1) {
+                case 0: r = x & 0xF0u; break;
+                case 1: asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(x), "s"(0xF0u)); break;
+                case 2: asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(x), "s"(0xF0u)); break;
+                default: asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(x), "s"(0xF0u)); break;
+            }
+        } else {
+            switch (m >> 1) {
+                case 0: asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(x), "s"(4u)); break;
+                case 1: asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(x), "s"(4u)); break;
+                case 2: asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(x), "s"(4u)); break;
+                default: asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(x), "s"(4u)); break;
+            }
+        }
+        return r;
+    };
+    auto rot_at = [&T](uint32_t s4, uint32_t off) { return *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(&T.rot[s4 * 16u]) + off); };
     uint32_t fbits = 0;  // step t of the block ends up at bit 15 - t
 #pragma unroll
     for (uint32_t t = 0; t < 16; ++t) {
@@ -322,20 +345,18 @@ __device__ __forceinline__ uint32_t stage_b_block(const SeedTables &T, uint32_t 
             // fbits = 2 * fbits + (mhi <= bhi): v_cmp into vcc, v_addc with vcc as carry-in (high words only; the exact test runs in stage R)
             asm("v_cmp_ge_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(fbits) : "v"(mhi), "s"(bhi) : "vcc");
             const uint4 e = tv[t & 3u];
+            // four plain v_xor_b32 (as asm: left to itself the SLP vectoriser pairs the words and, for the swapped halves,
+            // first materialises the swap with two v_pk_mov_b32 per step -- 1 more VALU per step on average)
             if (((TT + 1u) & 63u) < 32u) {
-                glo ^= e.x;
-                ghi ^= e.y;
-                hlo ^= e.z;
-                hhi ^= e.w;
+                asm("v_xor_b32 %0, %0, %4\n\tv_xor_b32 %1, %1, %5\n\tv_xor_b32 %2, %2, %6\n\tv_xor_b32 %3, %3, %7"
+                    : "+v"(glo), "+v"(ghi), "+v"(hlo), "+v"(hhi) : "v"(e.x), "v"(e.y), "v"(e.z), "v"(e.w));
             } else {  // rotation by s + 32: the stored entry with its halves swapped
-                glo ^= e.y;
-                ghi ^= e.x;
-                hlo ^= e.w;
-                hhi ^= e.z;
+                asm("v_xor_b32 %0, %0, %4\n\tv_xor_b32 %1, %1, %5\n\tv_xor_b32 %2, %2, %6\n\tv_xor_b32 %3, %3, %7"
+                    : "+v"(glo), "+v"(ghi), "+v"(hlo), "+v"(hhi) : "v"(e.y), "v"(e.x), "v"(e.w), "v"(e.z));
             }
             // the look-up of step t + 4 (rotation (TT + 5) mod 64), in flight while the next steps run
             const uint32_t s4 = (TT + 5u) & 31u;
-            tv[t & 3u] = (t + 4u < 16u) ? T.rot[s4 * 16u + nib16(xe, xo, t + 4u)] : T.rot[s4 * 16u + nib16(xe_n, xo_n, t + 4u - 16u)];
+            tv[t & 3u] = (t + 4u < 16u) ? rot_at(s4, off16(xe, xo, t + 4u)) : rot_at(s4, off16(xe_n, xo_n, t + 4u - 16u));
         }
     }
     if (LIM_CHECK) fbits <<= 16u - lim;
