@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "../../../include/mapquik_hip.h"
+#include "par_gzip.hpp"
 
 namespace mapquik {
 namespace feeder {
@@ -211,6 +212,7 @@ struct Deflate {
     // enum libdeflate_result: 0 success, 1 bad data, 2 short output, 3 insufficient space
     int (*raw)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;                  // libdeflate_deflate_decompress
     int (*gzip_ex)(void *, const void *, size_t, void *, size_t, size_t *, size_t *) = nullptr;    // libdeflate_gzip_decompress_ex
+    uint32_t (*crc)(uint32_t, const void *, size_t) = nullptr;                                      // libdeflate_crc32 (optional)
     Deflate() {
         if (getenv("MQ_FEEDER_NO_LIBDEFLATE")) return;  // test hook: the zlib paths
         lib = dlopen("libdeflate.so.0", RTLD_NOW);
@@ -219,6 +221,7 @@ struct Deflate {
         free_ = (void (*)(void *))dlsym(lib, "libdeflate_free_decompressor");
         raw = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(lib, "libdeflate_deflate_decompress");
         gzip_ex = (int (*)(void *, const void *, size_t, void *, size_t, size_t *, size_t *))dlsym(lib, "libdeflate_gzip_decompress_ex");
+        crc = (uint32_t(*)(uint32_t, const void *, size_t))dlsym(lib, "libdeflate_crc32");
         if (!alloc || !free_ || !raw || !gzip_ex) {
             dlclose(lib);
             lib = nullptr;
@@ -780,9 +783,11 @@ class Feeder {
         worker_done(err);
     }
 
-    // plain gzip, member by member through libdeflate: a member is inflated whole into a huge-page buffer (behind the unfinished
-    // record the previous member may have ended with), cut into chunk-sized ranges at record boundaries, and the ranges are handed
-    // to the parser threads, which copy them into page-locked chunk buffers and parse them
+    // plain gzip, member by member: a member is inflated whole into a huge-page buffer (behind the unfinished record the previous
+    // member may have ended with), cut into chunk-sized ranges at record boundaries, and the ranges are handed to the parser
+    // threads, which copy them into page-locked chunk buffers and parse them.  A large member is inflated by all threads
+    // (par_gzip.hpp: block starts found by search, 16-bit symbols, windows resolved afterwards) and its ranges go to the parsers
+    // round by round while the next round inflates; a small one by one libdeflate call.
     void gzip_member_worker() {
         std::string err;
         void *d = nullptr;
@@ -792,27 +797,77 @@ class Feeder {
             size_t seq = 0;
             uint64_t p = 0;
             std::vector<uint8_t> carry;  // the previous member's unfinished last record
+            auto envu = [](const char *k, uint64_t dflt) {
+                const char *v = getenv(k);
+                return v ? strtoull(v, nullptr, 10) : dflt;
+            };
+            const bool par_on = envu("MQ_PARGZ", 1) != 0 && n_threads_ >= 2;
+            const uint64_t par_min = envu("MQ_PARGZ_MIN", 16u << 20);  // compressed bytes from which a member is worth many threads
+            bool prev_small = false;                                   // a file of many small members: do not start a round of threads for each
             while (p < file_size_) {
                 if (file_size_ - p < 18 || map_[p] != 0x1f || map_[p + 1] != 0x8b) throw FeederError("gzip stream truncated or corrupt: " + path_);
-                uint64_t cap = std::max<uint64_t>(64u << 20, 12 * (file_size_ - p)) + carry.size();  // address space; pages exist once written
+                const bool par = par_on && !prev_small && file_size_ - p >= par_min;
+                uint64_t cap = std::max<uint64_t>(64u << 20, (par ? 64 : 12) * (file_size_ - p)) + carry.size();  // address space; pages exist once written
                 std::shared_ptr<BigBuf> big;
                 size_t ain = 0, aout = 0;
+                uint64_t a = 0;  // start of the bytes not yet handed to a parser
+                auto hand_over = [&](uint64_t from, uint64_t to) {
+                    Chunk *c = get_buffer(to - from + 64, (to - from + 64) > chunk_bytes_ + chunk_bytes_ / 8 + (1u << 20));
+                    c->begin = 0;
+                    c->bytes = to - from;
+                    c->ext_src = big->p + from;
+                    c->ext_hold = big;
+                    c->seq_no = seq++;
+                    {
+                        std::lock_guard<std::mutex> lk(mu_);
+                        to_parse_.push_back(c);
+                    }
+                    cv_.notify_all();
+                };
                 for (;;) {
                     big = std::make_shared<BigBuf>(cap + 64);
+                    if (!carry.empty()) memcpy(big->p, carry.data(), carry.size());
                     const auto tt0 = std::chrono::steady_clock::now();
-                    const int rc = deflate_.gzip_ex(d, map_ + p, (size_t)(file_size_ - p), big->p + carry.size(), (size_t)(cap - carry.size()), &ain, &aout);
-                    if (getenv("MQ_FEEDER_TIMING")) fprintf(stderr, "gzip member: rc %d, %zu -> %zu bytes in %.3f s\n", rc, ain, aout, std::chrono::duration<double>(std::chrono::steady_clock::now() - tt0).count());
+                    int rc = 0;
+                    if (par) {
+                        pargz::Options o;
+                        o.threads = n_threads_;
+                        o.seg_bytes = envu("MQ_PARGZ_SEG", o.seg_bytes);
+                        o.min_seg_bytes = envu("MQ_PARGZ_MINSEG", o.min_seg_bytes);
+                        o.timing = getenv("MQ_FEEDER_TIMING") != nullptr;
+                        o.crc_fn = deflate_.crc;
+                        try {
+                            pargz::MemberInflater inf(map_ + p, file_size_ - p, o);
+                            uint64_t produced = 0;
+                            ain = (size_t)inf.run(big->p + carry.size(), cap - carry.size(), &produced, [&](uint64_t so_far, bool finished) {
+                                if (finished) return;  // the member's tail is cut below, where it is known whether more members follow
+                                const uint64_t avail = carry.size() + so_far;
+                                while (a + chunk_bytes_ < avail) {  // ranges that end at a record start found with bytes to spare
+                                    const uint64_t q = next_record_start(big->p, a + chunk_bytes_, avail, fastq_, false);
+                                    if (q == NEED_MORE || q >= avail) break;
+                                    hand_over(a, q);
+                                    a = q;
+                                }
+                            });
+                            aout = (size_t)produced;
+                        } catch (const pargz::Error &e) {
+                            if (strncmp(e.what(), "space", 5) == 0 && a == 0) rc = 3;
+                            else throw FeederError(std::string(strncmp(e.what(), "space", 5) == 0 ? "gzip member expands beyond the buffer" : e.what()) + ": " + path_);
+                        }
+                    } else {
+                        rc = deflate_.gzip_ex(d, map_ + p, (size_t)(file_size_ - p), big->p + carry.size(), (size_t)(cap - carry.size()), &ain, &aout);
+                    }
+                    if (getenv("MQ_FEEDER_TIMING")) fprintf(stderr, "gzip member (%s): rc %d, %zu -> %zu bytes in %.3f s\n", par ? "all threads" : "libdeflate", rc, ain, aout, std::chrono::duration<double>(std::chrono::steady_clock::now() - tt0).count());
                     if (rc == 0) break;
                     if (rc != 3 || cap > (1ull << 37)) throw FeederError("gzip stream truncated or corrupt: " + path_);
-                    cap *= 2;  // insufficient space: a member compressed better than 12:1
+                    cap *= 2;  // insufficient space: a member compressed better than expected
                 }
-                if (!carry.empty()) memcpy(big->p, carry.data(), carry.size());
+                prev_small = ain < par_min;
                 const uint64_t total = carry.size() + aout;
                 carry.clear();
                 p += ain;
                 const bool last_member = p >= file_size_;
                 // ranges [a, b): b = the first record start at or after a + chunk_bytes_ (the end of the data in the last member)
-                uint64_t a = 0;
                 while (a < total) {
                     uint64_t b = total;
                     if (a + chunk_bytes_ < total) {
@@ -840,17 +895,7 @@ class Feeder {
                             break;
                         }
                     }
-                    Chunk *c = get_buffer(b - a + 64, (b - a + 64) > chunk_bytes_ + chunk_bytes_ / 8 + (1u << 20));
-                    c->begin = 0;
-                    c->bytes = b - a;
-                    c->ext_src = big->p + a;
-                    c->ext_hold = big;
-                    c->seq_no = seq++;
-                    {
-                        std::lock_guard<std::mutex> lk(mu_);
-                        to_parse_.push_back(c);
-                    }
-                    cv_.notify_all();
+                    hand_over(a, b);
                     a = b;
                 }
             }

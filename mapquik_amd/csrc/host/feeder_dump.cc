@@ -1,6 +1,8 @@
 // feeder_dump -- test tool for fastx_feeder.hpp (no GPU needed: chunk buffers come from malloc).
 // usage: feeder_dump <file> <fasta|fastq|ref> <chunk_bytes> <threads>   -> one line per read, in input order: id TAB length TAB sequence
 //        (ref: through the reference loader, ref_loader.hpp; FEEDER_DUMP_QUIET=1 prints only "records bases" -- for timing)
+//        feeder_dump <file.gz> inflate <segment_bytes> <threads>        -> the inflated bytes of all members (par_gzip.hpp alone);
+//        stderr: "rounds R max_chain C" (FEEDER_DUMP_QUIET=1: no bytes, "bytes seconds" on stdout)
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -12,6 +14,38 @@ int main(int argc, char **argv) {
     if (argc < 5) return 2;
     using namespace mapquik::feeder;
     try {
+        if (std::string(argv[2]) == "inflate") {
+            namespace pz = mapquik::pargz;
+            const int fd = open(argv[1], O_RDONLY);
+            if (fd < 0) throw std::runtime_error("cannot open");
+            struct stat st;
+            fstat(fd, &st);
+            if (st.st_size == 0) return 0;
+            const uint8_t *m = (const uint8_t *)mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
+            pz::Options o;
+            o.threads = atoi(argv[4]);
+            o.seg_bytes = strtoull(argv[3], nullptr, 10);
+            o.min_seg_bytes = getenv("PARGZ_MINSEG") ? strtoull(getenv("PARGZ_MINSEG"), nullptr, 10) : o.seg_bytes / 4 + 1;
+            if (getenv("PARGZ_RATIO")) o.max_ratio = (uint32_t)atoi(getenv("PARGZ_RATIO"));
+            o.timing = getenv("MQ_FEEDER_TIMING") != nullptr;
+            Deflate dl;
+            if (!getenv("PARGZ_ZLIB_CRC")) o.crc_fn = dl.crc;
+            uint64_t cap = (uint64_t)st.st_size * (getenv("PARGZ_OUT_RATIO") ? strtoull(getenv("PARGZ_OUT_RATIO"), nullptr, 10) : 1100) + (1u << 20);
+            pz::Region out(cap);
+            uint64_t pos = 0, total = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (pos < (uint64_t)st.st_size) {
+                pz::MemberInflater inf(m + pos, (uint64_t)st.st_size - pos, o);
+                uint64_t prod = 0;
+                pos += inf.run((uint8_t *)out.p + total, cap - total, &prod, nullptr);
+                total += prod;
+                fprintf(stderr, "rounds %d max_chain %d\n", inf.rounds(), inf.max_chain());
+            }
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (getenv("FEEDER_DUMP_QUIET")) printf("%llu %.4f\n", (unsigned long long)total, dt);
+            else fwrite(out.p, 1, total, stdout);
+            return 0;
+        }
         if (std::string(argv[2]) == "ref") {
             RefLoader rl(argv[1], atoi(argv[4]));
             const bool quiet = getenv("FEEDER_DUMP_QUIET") != nullptr;

@@ -1,0 +1,198 @@
+"""One gzip member inflated by many threads (mapquik_amd/csrc/host/par_gzip.hpp) against zlib: block starts found by search in
+the middle of the stream, 16-bit symbols with markers for the unknown 32 KB, windows resolved afterwards, CRC-32 / ISIZE checked.
+Host only.  The reader it replaces is get_reader's single-threaded .gz branch (src/main.rs:60-75): same bytes, same errors."""
+import gzip
+import os
+import random
+import subprocess
+import zlib
+
+import pytest
+
+from mapquik_amd import build as B
+
+
+@pytest.fixture(scope="module")
+def tool():
+    return B.build_feeder_dump()
+
+
+def _reads(n, rng, fastq, genome_len=200_000):
+    """Reads off a small genome (so that the compressor finds matches far back) with repetitive headers."""
+    genome = "".join(rng.choice("ACGT") for _ in range(genome_len))
+    out = []
+    for i in range(n):
+        L = rng.choice([150, 500, 2000, 9000])
+        s = rng.randrange(0, genome_len - L)
+        seq = genome[s:s + L]
+        if fastq:
+            q = "".join(rng.choice("FFFFF:,#") for _ in range(L))
+            out.append("@m64011_%06d/%d/ccs np=%d\n%s\n+\n%s\n" % (i, i * 7, rng.randrange(3, 30), seq, q))
+        else:
+            out.append(">m64011_%06d/%d/ccs\n%s\n" % (i, i * 7, seq))
+    return "".join(out).encode()
+
+
+def _gz_wrap(raw_deflate, data):
+    return b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03" + raw_deflate + zlib.crc32(data).to_bytes(4, "little") + (len(data) & 0xFFFFFFFF).to_bytes(4, "little")
+
+
+def _deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, flush_every=0, mem=8):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, mem, strategy)
+    if not flush_every:
+        return c.compress(data) + c.flush()
+    parts = []
+    for a in range(0, len(data), flush_every):
+        parts.append(c.compress(data[a:a + flush_every]))
+        parts.append(c.flush(zlib.Z_SYNC_FLUSH if (a // flush_every) % 2 else zlib.Z_FULL_FLUSH))
+    parts.append(c.flush())
+    return b"".join(parts)
+
+
+def _inflate(tool, path, seg, threads, env=None, ok=True):
+    r = subprocess.run([tool, str(path), "inflate", str(seg), str(threads)], capture_output=True, timeout=120, env=dict(os.environ, **(env or {})))
+    if ok:
+        assert r.returncode == 0, r.stderr.decode()
+    return r
+
+
+def _chains(r):
+    return [tuple(int(x) for x in ln.split()[1::2]) for ln in r.stderr.decode().split("\n") if ln.startswith("rounds ")]
+
+
+@pytest.mark.parametrize("fastq", [False, True])
+def test_parallel_inflate_matches_zlib(tool, tmp_path, fastq):
+    """Levels 1 / 6 / 9, a small-memory compressor (more, smaller blocks), sync and full flush points (empty stored blocks in the
+    stream), tiny segments (a block start searched every few KB), 1 to 7 threads: the bytes zlib gives, and the segments did follow
+    each other (the search found real block starts)."""
+    data = _reads(700, random.Random(3 + fastq), fastq)
+    assert len(data) > 1_500_000
+    streams = {
+        "l1": _deflate(data, 1), "l6": _deflate(data, 6), "l9": _deflate(data, 9), "mem1": _deflate(data, 6, mem=1),
+        "flush": _deflate(data, 6, flush_every=70_001), "huffman_only": _deflate(data, 6, zlib.Z_HUFFMAN_ONLY), "rle": _deflate(data, 6, zlib.Z_RLE),
+    }
+    for name, raw in streams.items():
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(_gz_wrap(raw, data))
+        assert gzip.decompress(p.read_bytes()) == data
+        for seg, th in ((20_000, 4), (50_000, 7), (300_000, 3), (1 << 22, 2), (30_000, 1)):
+            r = _inflate(tool, p, seg, th)
+            assert r.stdout == data, (name, seg, th)
+            rounds, chain = _chains(r)[0]
+            if th > 1 and seg <= 50_000:
+                assert chain > 1, (name, seg, th, r.stderr)  # block starts were found and landed on
+
+
+def test_parallel_inflate_streams_without_block_starts(tool, tmp_path):
+    """Stored blocks only (level 0), fixed-Huffman blocks only, binary data, one giant record: no dynamic block start of text to be
+    found -- the first segment decodes alone, correctly."""
+    rng = random.Random(11)
+    text = _reads(200, rng, False)
+    binary = bytes(rng.randrange(256) for _ in range(300_000)) + text[:200_000]
+    cases = {
+        "stored": (_deflate(text, 0), text), "fixed": (_deflate(text, 6, zlib.Z_FIXED), text), "binary": (_deflate(binary, 6), binary),
+        "empty": (_deflate(b"", 6), b""), "tiny": (_deflate(b">r\nACGT\n", 9), b">r\nACGT\n"),
+    }
+    for name, (raw, data) in cases.items():
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(_gz_wrap(raw, data))
+        for seg, th in ((16_384, 4), (100_000, 3)):
+            r = _inflate(tool, p, seg, th)
+            assert r.stdout == data, (name, seg, th)
+
+
+def test_parallel_inflate_members_and_headers(tool, tmp_path):
+    """Concatenated members (the first large, then small ones, then a large one), gzip headers with a file name / comment / extra
+    field / header CRC: every member through the many-thread inflater."""
+    rng = random.Random(5)
+    a, b, c = _reads(300, rng, False), b">x\nAC\n", _reads(250, rng, True)
+    hdr_name = b"\x1f\x8b\x08\x08\x00\x00\x00\x00\x00\x03reads.fa\x00"
+    hdr_all = b"\x1f\x8b\x08\x1e\x01\x02\x03\x04\x02\x03" + b"\x05\x00EXTRA" + b"name\x00" + b"a comment\x00"
+    hdr_all += (zlib.crc32(hdr_all) & 0xFFFF).to_bytes(2, "little")
+
+    def member(h, d, level=6):
+        return h + _deflate(d, level) + zlib.crc32(d).to_bytes(4, "little") + len(d).to_bytes(4, "little")
+    blob = member(hdr_name, a) + gzip.compress(b) + member(hdr_all, b"") + member(hdr_all, c, 1) + gzip.compress(a[:1000])
+    p = tmp_path / "m.gz"
+    p.write_bytes(blob)
+    want = a + b + c + a[:1000]
+    assert gzip.decompress(blob) == want
+    for seg, th in ((25_000, 4), (1 << 20, 2)):
+        r = _inflate(tool, p, seg, th)
+        assert r.stdout == want
+        assert len(_chains(r)) == 5
+
+
+def test_parallel_inflate_rejects_damaged_members(tool, tmp_path):
+    """Truncated anywhere, a flipped bit in the data (CRC-32 or an invalid code), a wrong trailer: errors, as zlib / flate2 report
+    them -- never silently different bytes."""
+    data = _reads(400, random.Random(9), False)
+    good = gzip.compress(data, 6)
+    rng = random.Random(2)
+    cases = {"cut_half": good[:len(good) // 2], "cut_trailer": good[:-3], "cut_header": good[:7], "bad_crc": good[:-8] + b"\x00\x00\x00\x00" + good[-4:],
+             "bad_isize": good[:-4] + b"\x01\x00\x00\x00", "not_gzip": b"ACGT" * 100}
+    for k in range(6):
+        pos = rng.randrange(20, len(good) - 20)
+        cases["flip%d" % k] = good[:pos] + bytes([good[pos] ^ (1 << rng.randrange(8))]) + good[pos + 1:]
+    for name, blob in cases.items():
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(blob)
+        try:
+            ok = gzip.decompress(blob) == data
+        except Exception:
+            ok = False
+        assert not ok, name
+        for seg, th in ((20_000, 4), (1 << 20, 2)):
+            r = _inflate(tool, p, seg, th, ok=False)
+            assert r.returncode != 0, (name, seg, th)
+
+
+def test_parallel_inflate_small_symbol_buffers(tool, tmp_path):
+    """Highly compressible input against a symbol buffer sized for ratio 2: segments stop at their last whole block, rounds go on
+    from there, a block that does not fit gets a larger buffer; and a member that expands beyond the output buffer is an error."""
+    data = (b">r1\n" + b"ACGT" * 60_000 + b"\n") * 12
+    p = tmp_path / "z.gz"
+    p.write_bytes(gzip.compress(data, 6))
+    for seg, th in ((2_000, 4), (500, 3)):
+        r = _inflate(tool, p, seg, th, {"PARGZ_RATIO": "2", "PARGZ_MINSEG": "256"})
+        assert r.stdout == data
+    r = _inflate(tool, p, 2_000, 4, {"PARGZ_OUT_RATIO": "3"}, ok=False)
+    assert r.returncode != 0 and b"space" in r.stderr
+
+
+@pytest.mark.parametrize("fastq", [False, True])
+def test_feeder_uses_all_threads_on_a_large_member(tool, tmp_path, fastq):
+    """Through the feeder (what the driver runs): a member above MQ_PARGZ_MIN goes to the many-thread inflater, its rounds are handed
+    to the parsers as they finish; records identical to the zlib reader's, members cut in the middle of records included."""
+    rng = random.Random(21 + fastq)
+    data = _reads(500, rng, fastq)
+    recs, cur = [], None
+    lines = data.decode().split("\n")
+    if fastq:
+        recs = [[lines[i][1:].split(" ")[0], str(len(lines[i + 1])), lines[i + 1]] for i in range(0, len(lines) - 1, 4)]
+    else:
+        recs = [[lines[i][1:].split(" ")[0], str(len(lines[i + 1])), lines[i + 1]] for i in range(0, len(lines) - 1, 2)]
+    cut = len(data) // 2 + 13
+    blobs = {"one": gzip.compress(data, 6), "two": gzip.compress(data[:cut], 1) + gzip.compress(data[cut:], 9)}
+    env = {"MQ_PARGZ_MIN": "1000", "MQ_PARGZ_SEG": "40000", "MQ_PARGZ_MINSEG": "10000", "MQ_FEEDER_TIMING": "1"}
+    for name, blob in blobs.items():
+        p = tmp_path / (name + (".fq.gz" if fastq else ".fa.gz"))
+        p.write_bytes(blob)
+        for chunk, th in ((64, 4), (100_000, 3), (1 << 26, 2)):
+            r = subprocess.run([tool, str(p), "fastq" if fastq else "fasta", str(chunk), str(th)], capture_output=True, text=True, timeout=120,
+                               env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr
+            got = [ln.split("\t") for ln in r.stdout.split("\n") if ln != ""]
+            assert got == recs, (name, chunk, th)
+            assert "all threads" in r.stderr and "pargz round" in r.stderr
+        r = subprocess.run([tool, str(p), "fastq" if fastq else "fasta", "100000", "3"], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, MQ_PARGZ="0", MQ_FEEDER_TIMING="1"))
+        assert r.returncode == 0 and "all threads" not in r.stderr
+        assert [ln.split("\t") for ln in r.stdout.split("\n") if ln != ""] == recs
+    # a damaged large member is the same error through the feeder
+    bad = bytearray(blobs["one"])
+    bad[len(bad) // 2] ^= 0x10
+    p = tmp_path / ("bad.fq.gz" if fastq else "bad.fa.gz")
+    p.write_bytes(bytes(bad))
+    r = subprocess.run([tool, str(p), "fastq" if fastq else "fasta", "100000", "3"], capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
+    assert r.returncode != 0 and "gzip" in r.stderr

@@ -68,6 +68,23 @@ def test_feeder_and_reference_loader_under_sanitizers(built, tmp_path, san):
     open(cut, "wb").write(blob[:len(blob) // 2])
     r = subprocess.run([tool, cut, "fasta", "3000", "4"], capture_output=True, text=True, timeout=300, env=_ENV)
     assert r.returncode != 0 and "truncated" in r.stderr and "Sanitizer" not in r.stderr
+    # the many-thread member inflater (par_gzip.hpp): through the feeder and alone, whole and damaged input
+    env = dict(_ENV, MQ_PARGZ_MIN="1000", MQ_PARGZ_SEG="30000", MQ_PARGZ_MINSEG="8000", MQ_FEEDER_TIMING="1")
+    r = subprocess.run([tool, p["reads.fa.gz"], "fasta", "3000", "4"], capture_output=True, text=True, timeout=300, env=env)
+    _clean(r)
+    assert "all threads" in r.stderr and [tuple(ln.split("\t")[:2]) for ln in r.stdout.split("\n") if ln] == want
+    r = subprocess.run([tool, p["reads.fa.gz"], "inflate", "20000", "5"], capture_output=True, timeout=300, env=_ENV)
+    assert r.returncode == 0 and b"Sanitizer" not in r.stderr and b"runtime error" not in r.stderr
+    import gzip as _gz
+    assert r.stdout == _gz.decompress(blob)
+    flipped = str(tmp_path / "flip.fa.gz")
+    for pos in (len(blob) // 3, len(blob) // 2, len(blob) - 5):
+        open(flipped, "wb").write(blob[:pos] + bytes([blob[pos] ^ 0x40]) + blob[pos + 1:])
+        for args, e in ((["inflate", "20000", "4"], _ENV), (["fasta", "3000", "4"], env)):
+            r = subprocess.run([tool, flipped] + args, capture_output=True, timeout=300, env=e)
+            assert r.returncode != 0 and b"Sanitizer" not in r.stderr and b"runtime error" not in r.stderr, (pos, args)
+    r = subprocess.run([tool, cut, "inflate", "20000", "4"], capture_output=True, timeout=300, env=_ENV)
+    assert r.returncode != 0 and b"Sanitizer" not in r.stderr
 
 
 @pytest.mark.parametrize("san", ["asan", "tsan"])
