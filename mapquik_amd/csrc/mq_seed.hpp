@@ -48,7 +48,7 @@ static_assert(SD_BLOCKS <= 256, "block_of holds block numbers in a byte");
 struct SeedTables {
     uint4 rot[32 * 16];  // index s*16 + (out | in<<2), s = 0..31 : {ror(A,s) lo,hi ; rol(B,s) lo,hi} with the roll terms
                          //   A = rol(h(out),l)^h(in), B = ror(hc(out),1)^rol(hc(in),l-1); rotation by s+32 = the same entry, halves swapped
-    uint4 warm[4];       // index code        : {h(c) lo,hi ; rol(hc(c),l-1) lo,hi}
+    uint4 rem[64];       // index c0 | c1<<2 | c2<<4 : the last l mod 4 Horner steps at once (same form as quad, l mod 4 codes; entry 0 unused when l mod 4 = 0)
     uint4 quad[256];     // index c0 | c1<<2 | c2<<4 | c3<<6 : four Horner steps at once, {F4 lo,hi ; R4 lo,hi} with
                          //   F4 = rol(h(c0),3)^rol(h(c1),2)^rol(h(c2),1)^h(c3),  R4 = ror(X0,3)^ror(X1,2)^ror(X2,1)^X3,  X = rol(hc(c),l-1)
     uint16_t lut[1024];  // index prev | c0<<2 | c1<<4 | c2<<6 | c3<<8 : compacted codes (8 bits) | 2*count << 8 | head bits << 12
@@ -92,10 +92,14 @@ __device__ __forceinline__ void build_seed_tables(SeedTables &T, uint32_t l) {
         const uint64_t r = rotl64(rotr64(seed_of(o ^ 2u), 1) ^ rotl64(seed_of(in ^ 2u), l - 1u), sft);
         T.rot[i] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
     }
-    if (threadIdx.x < 4) {
-        const uint64_t f = seed_of(threadIdx.x);
-        const uint64_t r = rotl64(seed_of(threadIdx.x ^ 2u), l - 1u);
-        T.warm[threadIdx.x] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
+    for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) {
+        uint64_t f = 0, r = 0;
+        for (uint32_t m = 0; m < (l & 3u); ++m) {
+            const uint32_t c = (i >> (2 * m)) & 3u;
+            f = rotl64(f, 1) ^ seed_of(c);
+            r = rotr64(r, 1) ^ rotl64(seed_of(c ^ 2u), l - 1u);
+        }
+        T.rem[i] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
     }
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
         uint64_t f = 0, r = 0;
@@ -276,8 +280,44 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
 
 // ------------------------------------------------------------------ stage B
 // Both strands' ntHash of the l-mer that starts at code index a of the tile's code stream, from scratch: Horner form
-// (fh = rol(fh,1)^h(c), rh = ror(rh,1)^rol(hc(c),l-1)), four bases per table look-up, the last l mod 4 one by one.
+// (fh = rol(fh,1)^h(c), rh = ror(rh,1)^rol(hc(c),l-1)), four bases per table look-up, the last l mod 4 in one look-up of their own.
+// L known at compile time: every look-up of the window is in flight before the first is used, and nothing loops.
+template <uint32_t L>
+__device__ __forceinline__ Hash2 window_hash_fixed(const SeedTables &T, const SeedLds &S, uint32_t a) {
+    constexpr uint32_t NDW = (L + 15u) / 16u, NQ = L / 4u, REM = L & 3u;
+    uint32_t c[NDW + 1];
+#pragma unroll
+    for (uint32_t m = 0; m <= NDW; ++m) c[m] = S.codes[(a >> 4) + m];
+    uint32_t dw[NDW];
+#pragma unroll
+    for (uint32_t m = 0; m < NDW; ++m) dw[m] = __builtin_amdgcn_alignbit(c[m + 1], c[m], 2u * (a & 15u));  // 16 codes from a + 16 m
+    uint4 tv[NQ + 1];
+#pragma unroll
+    for (uint32_t q = 0; q < NQ; ++q) tv[q] = T.quad[(dw[q >> 2] >> (8u * (q & 3u))) & 0xFFu];
+    if (REM) tv[NQ] = T.rem[(dw[NQ >> 2] >> (8u * (NQ & 3u))) & ((1u << (2u * REM)) - 1u)];
+    Hash2 h = {tv[0].x, tv[0].y, tv[0].z, tv[0].w};
+#pragma unroll
+    for (uint32_t q = 1; q < NQ; ++q) {
+        const uint32_t nfhi = __builtin_amdgcn_alignbit(h.fhi, h.flo, 28), nflo = __builtin_amdgcn_alignbit(h.flo, h.fhi, 28);  // rol 4
+        const uint32_t nrlo = __builtin_amdgcn_alignbit(h.rhi, h.rlo, 4), nrhi = __builtin_amdgcn_alignbit(h.rlo, h.rhi, 4);    // ror 4
+        h.flo = nflo ^ tv[q].x;
+        h.fhi = nfhi ^ tv[q].y;
+        h.rlo = nrlo ^ tv[q].z;
+        h.rhi = nrhi ^ tv[q].w;
+    }
+    if (REM) {
+        const uint32_t nfhi = __builtin_amdgcn_alignbit(h.fhi, h.flo, 32u - REM), nflo = __builtin_amdgcn_alignbit(h.flo, h.fhi, 32u - REM);
+        const uint32_t nrlo = __builtin_amdgcn_alignbit(h.rhi, h.rlo, REM), nrhi = __builtin_amdgcn_alignbit(h.rlo, h.rhi, REM);
+        h.flo = nflo ^ tv[NQ].x;
+        h.fhi = nfhi ^ tv[NQ].y;
+        h.rlo = nrlo ^ tv[NQ].z;
+        h.rhi = nrhi ^ tv[NQ].w;
+    }
+    return h;
+}
+
 __device__ __forceinline__ Hash2 window_hash(const SeedTables &T, const SeedLds &S, uint32_t l, uint32_t a) {
+    if (l == 31u) return window_hash_fixed<31>(T, S, a);  // the reference's default l (src/main.rs: -l 31) and every BASELINE configuration
     Hash2 h = {0, 0, 0, 0};
     for (uint32_t m0 = 0; m0 < l; m0 += 16u) {
         const uint32_t d = (a + m0) >> 4;
@@ -293,7 +333,16 @@ __device__ __forceinline__ Hash2 window_hash(const SeedTables &T, const SeedLds 
             h.rlo = nrlo ^ tv.z;
             h.rhi = nrhi ^ tv.w;
         }
-        for (uint32_t m = 4u * nq; m < cnt; ++m) h.roll(T.warm[(dw >> (2u * m)) & 3u]);
+        const uint32_t r = cnt & 3u;  // non-zero in the last chunk only (= l mod 4)
+        if (r) {
+            const uint4 tv = T.rem[(dw >> (8u * nq)) & ((1u << (2u * r)) - 1u)];
+            const uint32_t nfhi = __builtin_amdgcn_alignbit(h.fhi, h.flo, 32u - r), nflo = __builtin_amdgcn_alignbit(h.flo, h.fhi, 32u - r);
+            const uint32_t nrlo = __builtin_amdgcn_alignbit(h.rhi, h.rlo, r), nrhi = __builtin_amdgcn_alignbit(h.rlo, h.rhi, r);
+            h.flo = nflo ^ tv.x;
+            h.fhi = nfhi ^ tv.y;
+            h.rlo = nrlo ^ tv.z;
+            h.rhi = nrhi ^ tv.w;
+        }
     }
     return h;
 }
