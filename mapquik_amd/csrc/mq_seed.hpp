@@ -62,9 +62,8 @@ struct SeedLds {
     unsigned long long flags[64 * SD_FLAG_BLKS / 4];  // lane L, 16-step block b: bit t of the uint16 at [L * SD_FLAG_BLKS + b] <=> step 16 b + t is a candidate
     uint32_t carry_codes[4];                     // codes carried into the next tile (<= 63)
     uint32_t carry_pos[64];                      // their raw positions
-    uint16_t lane_prefix[66];                    // exclusive prefix of the lanes' candidate counts
     uint8_t block_of[SD_CODES_MAX / 64 + 3];     // block_of[c]: the 64-base block that holds code 64 c (the walk to a code's block starts there)
-    uint8_t owner[SD_OWNER_CAP];                 // stage R: candidate (in position order, one round of them) -> owning lane
+    uint16_t cand[SD_OWNER_CAP];                 // stage R: candidate (in position order, one round of them) -> its window (code index in the tile)
 };
 
 // 2-bit code = (ASCII >> 1) & 3 : A=0 C=1 T=2 G=3 ; complement = code ^ 2
@@ -511,66 +510,88 @@ __device__ __forceinline__ uint32_t seed_rawpos(const SeedLds &S, uint32_t raw_b
     return raw_base + b * 64u + select_bit64(S.heads[b], j - (uint32_t)S.cnt[b]);
 }
 
+// The same for a whole lane-batch, without a dependent walk: block_of gives the first candidate block, the counts and head masks
+// of it and of the next two are read together (one LDS round trip after block_of's), the block is picked by comparison.  A lane
+// whose base lies further on (blocks of very few run heads: long homopolymer runs) walks as seed_rawpos does.
+__device__ __forceinline__ uint32_t seed_rawpos_batch(const SeedLds &S, uint32_t raw_base, uint32_t carry_n, uint32_t j) {
+    const uint32_t cpos = S.carry_pos[j < 63u ? j : 63u];
+    const uint32_t b0 = S.block_of[j >> 6];
+    const uint32_t b1 = b0 + 1u < SD_BLOCKS ? b0 + 1u : SD_BLOCKS - 1u, b2 = b0 + 2u < SD_BLOCKS ? b0 + 2u : SD_BLOCKS - 1u;
+    const uint32_t c0 = S.cnt[b0], c1 = S.cnt[b0 + 1u], c2 = S.cnt[b0 + 2u], c3 = S.cnt[b0 + 3u];
+    const unsigned long long h0 = S.heads[b0], h1 = S.heads[b1], h2 = S.heads[b2];
+    // cnt[n_blocks] = n_codes > j ends the walk before any stale count is looked at
+    const bool s1 = c1 <= j, s2 = s1 && c2 <= j, s3 = s2 && c3 <= j;
+    uint32_t b = b0 + (s1 ? 1u : 0u) + (s2 ? 1u : 0u);
+    unsigned long long hd = s2 ? h2 : s1 ? h1 : h0;
+    uint32_t cb = s2 ? c2 : s1 ? c1 : c0;
+    if (__ballot(s3 && j >= carry_n)) {
+        if (s3 && j >= carry_n) {
+            b = b0 + 3u;
+            while ((uint32_t)S.cnt[b + 1u] <= j) ++b;
+            hd = S.heads[b];
+            cb = S.cnt[b];
+        }
+    }
+    const uint32_t pos = raw_base + b * 64u + select_bit64(hd, j - cb);
+    return j < carry_n ? cpos : pos;
+}
+
 // Lists the tile's candidates in position order (lane = candidate), resolves their raw positions and appends them to the
 // sequence's minimizer list.  Returns the number of minimizers appended; sets inexact when a candidate fails the exact
 // 64-bit test (the sequence then goes to the general path, whose test is exact by construction).
+// Every lane first writes the windows of its own candidates to their places in the list (its flags are in registers: lowest
+// set bit, clear, next), so that a candidate's lane afterwards reads ONE value and starts its look-ups -- no search for the owning
+// lane, no bit select in another lane's flags.
 __device__ __forceinline__ uint32_t seed_stage_r(const SeedTables &T, SeedLds &S, const DevParams &P, uint32_t w_eff,
                                                  uint32_t n_blocks, uint32_t n_codes, uint32_t raw_base, uint32_t carry_n,
                                                  unsigned long long *__restrict__ mz_hash, uint32_t *__restrict__ mz_pos, uint32_t out_base,
                                                  uint32_t out_cap, bool &inexact) {
     const uint32_t lane = lane_id();
     const uint32_t lc = (w_eff + 63u) >> 6;
-    // this lane's flags, masked to its real windows (steps [0, nv)); the masked words go back for the other lanes to read
-    unsigned long long *fw = &S.flags[lane * (SD_FLAG_BLKS / 4u)];
+    // this lane's flags as 32-step words, masked to its real windows (steps [0, nv))
+    constexpr uint32_t NW = SD_FLAG_BLKS / 2u;
+    const uint32_t *fw = reinterpret_cast<const uint32_t *>(&S.flags[lane * (SD_FLAG_BLKS / 4u)]);
     const uint32_t s0 = lane * lc;
     const uint32_t nv = s0 < w_eff ? (w_eff - s0 < lc ? w_eff - s0 : lc) : 0u;
+    uint32_t f[NW];
     uint32_t my_count = 0;
 #pragma unroll
-    for (uint32_t w = 0; w < SD_FLAG_BLKS / 4u; ++w) {
-        const uint32_t k = nv > 64u * w ? nv - 64u * w : 0u;
-        const unsigned long long f = fw[w] & (k >= 64u ? ~0ull : ((1ull << k) - 1ull));
-        fw[w] = f;
-        my_count += (uint32_t)__popcll(f);
+    for (uint32_t w = 0; w < NW; ++w) {
+        const uint32_t k = nv > 32u * w ? nv - 32u * w : 0u;
+        f[w] = fw[w] & (k >= 32u ? ~0u : ((1u << k) - 1u));
+        my_count += (uint32_t)__popc(f[w]);
     }
     const uint32_t incl = wave_incl_scan_u32(my_count);
     const uint32_t total = rdlane(incl, 63);
-    S.lane_prefix[lane] = (uint16_t)(incl - my_count);
-    wave_sync();
     const uint32_t my_prefix = incl - my_count;
-    const uint32_t max_count = wave_max_u32(my_count);
+    const uint32_t nw_used = (lc + 31u) >> 5;  // words that can hold a flag at all (wave-uniform)
     for (uint32_t r0 = 0; r0 < total; r0 += SD_OWNER_CAP) {  // rounds of SD_OWNER_CAP candidates (one round unless the density is high)
-        // every lane writes its number over its candidates' places: owner[] then maps a candidate to its lane without a search
-        for (uint32_t e = 0; e < max_count; ++e) {
-            const uint32_t at = my_prefix + e - r0;
-            if (e < my_count && at < SD_OWNER_CAP) S.owner[at] = (uint8_t)lane;
+        uint32_t at = my_prefix - r0;  // place of this lane's next candidate in the round's list (wraps below zero before the round)
+#pragma unroll
+        for (uint32_t w = 0; w < NW; ++w) {
+            if (w < nw_used) {
+                uint32_t g = f[w];
+                while (__ballot(g != 0u)) {  // one pass lists one candidate of every lane that still has one in this word; straight-line body
+                    const bool has = g != 0u;
+                    const uint32_t t = s0 + 32u * w + (uint32_t)__ffs((int)g) - 1u;
+                    if (has && at < SD_OWNER_CAP) S.cand[at] = (uint16_t)t;
+                    at += has ? 1u : 0u;
+                    g &= g - 1u;  // 0 stays 0
+                }
+            }
         }
         wave_sync();
         const uint32_t r1 = total - r0 < SD_OWNER_CAP ? total : r0 + SD_OWNER_CAP;
         for (uint32_t i0 = r0; i0 < r1; i0 += 64u) {
             const uint32_t i = i0 + lane;
             if (i < r1) {
-                const uint32_t L = S.owner[i - r0];
-                uint32_t e = i - (uint32_t)S.lane_prefix[L];  // rank of the step among L's candidate steps
-                const unsigned long long *lf = &S.flags[L * (SD_FLAG_BLKS / 4u)];
-                uint32_t t = 0;
-                unsigned long long word = lf[0];
-#pragma unroll
-                for (uint32_t w = 1; w < SD_FLAG_BLKS / 4u; ++w) {
-                    const uint32_t c = (uint32_t)__popcll(word);
-                    if (e >= c) {
-                        e -= c;
-                        word = lf[w];
-                        t = 64u * w;
-                    }
-                }
-                t += select_bit64(word, e);
-                const uint32_t j = L * lc + t;
+                const uint32_t j = S.cand[i - r0];
                 const Hash2 wh = window_hash(T, S, P.l, j);
+                const uint32_t pos = seed_rawpos_batch(S, raw_base, carry_n, j);
                 const uint64_t F = ((uint64_t)wh.fhi << 32) | wh.flo, R = ((uint64_t)wh.rhi << 32) | wh.rlo;
                 const uint64_t hv = F < R ? F : R;
                 if (hv > P.bound) inexact = true;
                 const uint32_t dest = out_base + i;
-                const uint32_t pos = seed_rawpos(S, raw_base, carry_n, j);
                 if (dest < out_cap) {
                     mz_hash[dest] = hv;
                     mz_pos[dest] = pos;
