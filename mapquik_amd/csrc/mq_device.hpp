@@ -243,6 +243,28 @@ __device__ __forceinline__ uint64_t kminmer_hash(uint32_t k, Get get, bool &rev)
     return h.finish(8u * (k + 1u));
 }
 
+// The same for a k known at compile time: the k hashes are read once (all reads in flight together), the orientation comes out of
+// k/2 comparisons without a branch (pairs past the middle repeat the earlier ones, which were equal if the loop got that far).
+template <uint32_t K, class Get>
+__device__ __forceinline__ uint64_t kminmer_hash_fixed(Get get, bool &rev) {
+    uint64_t w[K];
+#pragma unroll
+    for (uint32_t i = 0; i < K; ++i) w[i] = get(i);
+    bool r = false, decided = false;
+#pragma unroll
+    for (uint32_t i = 0; i < K / 2u; ++i) {
+        r = decided ? r : (w[K - 1u - i] < w[i]);
+        decided = decided || (w[K - 1u - i] != w[i]);
+    }
+    rev = r;
+    Sip13 h;
+    h.init();
+    h.word((uint64_t)K);
+#pragma unroll
+    for (uint32_t i = 0; i < K; ++i) h.word(r ? w[K - 1u - i] : w[i]);
+    return h.finish(8u * (K + 1u));
+}
+
 // ------------------------------------------------------------------ index probe (ReadOnlyIndex::get, src/index.rs:118-126)
 // table has nslots = mask + 1 slots (nslots / 2 buckets) plus one extra bucket [nslots / 2] for the key 0.
 __device__ __forceinline__ uint4 ld_u4(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
@@ -557,7 +579,8 @@ struct MapSink {
         rev = false;
         q_start = q_end = 0;
         if (act) {
-            key = kminmer_hash(P.k, [&](uint32_t i) { return (uint64_t)mzh[i0 + i]; }, rev);
+            auto get = [&](uint32_t i) { return (uint64_t)mzh[i0 + i]; };
+            key = P.k == 5u ? kminmer_hash_fixed<5>(get, rev) : kminmer_hash(P.k, get, rev);  // 5: the reference's default k (src/main.rs: -k 5)
             q_start = mzp[i0];
             q_end = mzp[i0 + P.k - 1] + P.l - 1u;
         }
