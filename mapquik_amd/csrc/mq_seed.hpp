@@ -1,7 +1,7 @@
 // mq_seed.hpp -- the fast seeder: an ACGT-only sequence -> its ordered minimizer list (hash, raw position) in HBM.
 //
-// One wave per sequence, tile by tile (12,288 raw bases = three super-rows of 64 bases per lane); per-wave LDS 7.95 KB, so that
-// workgroups of 8 waves (78 KB with the shared tables) run 2 to a CU.  Everything lives in LDS between the stages; nothing but
+// One wave per sequence, tile by tile (12,288 raw bases = three super-rows of 64 bases per lane); per-wave LDS 8.1 KB, so that
+// workgroups of 8 waves (78.1 KB with the shared tables) run 2 to a CU.  Everything lives in LDS between the stages; nothing but
 // the final list goes to HBM.  (Measured on MI355X: 2 super-rows 920, 3 super-rows 950 Gbases/s; 5 or 6 waves per SIMD at
 // 2 super-rows bought nothing, the fused kernel needs 128 VGPRs for its map phase.)
 //   stage A  decode + homopolymer compression: SWAR ASCII -> 2-bit codes (OR-merge + 4x4 transpose of 2-bit elements),
@@ -14,10 +14,11 @@
 //            The per-step test is min(fh.hi, rh.hi) <= hi(bound) (one v_alignbit per strand to un-rotate the high word); its
 //            outcome is shifted into a per-lane flag word (v_cmp + v_addc: no branch, no scalar work, nothing stored); the
 //            flag words go to LDS once per 16 steps.
-//   stage R  lane = candidate, in position order: the owning lane by binary search in the lanes' count prefix, the step by
-//            bit select in that lane's flags; the window's two hashes computed again from the code stream, four bases per
-//            look-up (256-entry table); exact 64-bit test; raw position = block search in the per-block counts + select on
-//            the 64-bit head mask; then {hash, pos} go to the sequence's region of the minimizer buffer.
+//   stage R  every lane lists the windows of its own candidates at their places (prefix sum of the lanes' counts); then lane =
+//            candidate, in position order: the window's two hashes computed again from the code stream, four bases per look-up
+//            (256-entry table; l = 31: all eight look-ups in flight at once); exact 64-bit test; raw position = the block
+//            (per-block counts of three candidate blocks compared at once) + select on its 64-bit head mask; then {hash, pos}
+//            go to the sequence's region of the minimizer buffer.
 // A sequence with a byte other than A C G T (or a candidate that passes the high-word test but not the exact one) is
 // handed to the general streaming seeder (mq_device.hpp) through a queue; both produce the same list.
 #pragma once
