@@ -503,17 +503,10 @@ __device__ __forceinline__ uint32_t select_bit64(unsigned long long m, uint32_t 
     return bit;
 }
 
-// raw position of compressed base j of the current tile
-__device__ __forceinline__ uint32_t seed_rawpos(const SeedLds &S, uint32_t raw_base, uint32_t carry_n, uint32_t j) {
-    if (j < carry_n) return S.carry_pos[j];  // a base of the previous tile's last l-1
-    uint32_t b = S.block_of[j >> 6];         // the block of code 64 * (j / 64); j's block is that one or one of the next few
-    while ((uint32_t)S.cnt[b + 1u] <= j) ++b;
-    return raw_base + b * 64u + select_bit64(S.heads[b], j - (uint32_t)S.cnt[b]);
-}
-
-// The same for a whole lane-batch, without a dependent walk: block_of gives the first candidate block, the counts and head masks
-// of it and of the next two are read together (one LDS round trip after block_of's), the block is picked by comparison.  A lane
-// whose base lies further on (blocks of very few run heads: long homopolymer runs) walks as seed_rawpos does.
+// Raw position of compressed base j of the current tile (a base of the previous tile's last l-1: from carry_pos), without a
+// dependent walk: block_of gives the first candidate block, the counts and head masks of it and of the next two are read together
+// (one LDS round trip after block_of's), the block is picked by comparison.  A lane whose base lies further on (blocks of very
+// few run heads: long homopolymer runs) walks on from there, block by block.
 __device__ __forceinline__ uint32_t seed_rawpos_batch(const SeedLds &S, uint32_t raw_base, uint32_t carry_n, uint32_t j) {
     const uint32_t cpos = S.carry_pos[j < 63u ? j : 63u];
     const uint32_t b0 = S.block_of[j >> 6];
@@ -643,7 +636,7 @@ __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict
             // tile's code stream; their raw positions stay available for windows that start in them
             const uint32_t new_cn = n_codes < P.l - 1u ? n_codes : P.l - 1u;
             uint32_t cpos = 0, ccode = 0;
-            if (lane < new_cn) cpos = seed_rawpos(S, raw0, carry_n, n_codes - new_cn + lane);
+            if (lane < new_cn) cpos = seed_rawpos_batch(S, raw0, carry_n, n_codes - new_cn + lane);
             if (lane < 4u) {
                 const uint32_t sb = 2u * (n_codes - new_cn) + 32u * lane;
                 ccode = __builtin_amdgcn_alignbit(S.codes[(sb >> 5) + 1u], S.codes[sb >> 5], sb & 31u);
