@@ -539,6 +539,16 @@ def test_native_cli_end_to_end_paf_identical(mq, oracle, simlib, tmp_path):
                         capture_output=True, text=True, env=env)
     assert r3.returncode == 0, r3.stderr
     assert open(prefix + "3.paf").read() == open(prefix + ".paf").read()
+    # the same reads as ONE gzip member, inflated by all feeder threads (par_gzip.hpp; forced at this size) and by one libdeflate call
+    rdz = tmp_path / "reads.fastq.gz"
+    rdz.write_bytes(gzip.compress(open(rd, "rb").read(), 6))
+    for tag, envz in (("z", dict(os.environ, MQ_PARGZ_MIN="1000", MQ_PARGZ_SEG="60000", MQ_PARGZ_MINSEG="15000", MQ_FEEDER_TIMING="1")),
+                      ("y", dict(os.environ, MQ_PARGZ="0", MQ_FEEDER_TIMING="1"))):
+        rz = subprocess.run([exe, str(rdz), "--reference", str(ref), "-p", prefix + tag, "--batch-bases", "300000", "--threads", "4"],
+                            capture_output=True, text=True, env=envz)
+        assert rz.returncode == 0, rz.stderr
+        assert ("all threads" in rz.stderr) == (tag == "z"), rz.stderr[-400:]
+        assert open(prefix + tag + ".paf").read() == open(prefix + ".paf").read()
     r9 = subprocess.run([exe, str(rd), "--reference", str(ref), "-p", prefix + "9", "--gpus", "9"], capture_output=True, text=True)
     assert r9.returncode == 101 and "devices" in r9.stderr
     po = oracle.params()
