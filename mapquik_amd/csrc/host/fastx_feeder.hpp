@@ -270,11 +270,15 @@ class Feeder {
         file_size_ = (uint64_t)st.st_size;
         if (kind_ == 1 && index_bgzf()) kind_ = 3;  // logical (inflated) size from here on; chunked and read like a raw file
         if (kind_ == 1 && deflate_.ok() && file_size_ > 0) {
-            // a plain gzip file of moderate size: every member inflated whole by libdeflate (the output of a member has to fit
-            // memory: larger files stream through zlib)
+            // a plain gzip file: members inflated whole into a buffer of their own -- large ones by all threads, round by round, the
+            // pages of a round given back as soon as the parsers have copied its records out (memory stays bounded whatever the
+            // file's size); with a single thread a member is one libdeflate call whose whole output has to be resident, so files
+            // beyond MQ_GZ_WHOLE_LIMIT then stream through zlib
             const char *lim = getenv("MQ_GZ_WHOLE_LIMIT");
             const uint64_t limit = lim ? strtoull(lim, nullptr, 10) : (4ull << 30);
-            if (file_size_ <= limit) {
+            const char *pz = getenv("MQ_PARGZ");
+            const bool par_possible = !lim && n_threads_ >= 2 && !(pz && atoi(pz) == 0);
+            if (file_size_ <= limit || par_possible) {
                 const uint8_t *m = (const uint8_t *)mmap(nullptr, file_size_, PROT_READ, MAP_SHARED, fd_, 0);
                 if (m != MAP_FAILED) {
                     map_ = m;
@@ -773,6 +777,10 @@ class Feeder {
                 }
                 if (c->ext_src) {  // whole-member gzip reader: the bytes come out of the member's inflate buffer here, in parallel
                     memcpy(c->buf, c->ext_src, c->bytes);
+                    // the whole pages of this range are not needed again (the inflater keeps its own copy of the last 32 KB): back to
+                    // the system, so that a member of any size costs the memory of the rounds in flight
+                    const uintptr_t pa = ((uintptr_t)c->ext_src + 4095u) & ~(uintptr_t)4095u, pb = ((uintptr_t)c->ext_src + c->bytes) & ~(uintptr_t)4095u;
+                    if (pb > pa) madvise((void *)pa, pb - pa, MADV_DONTNEED);
                     c->ext_src = nullptr;
                     c->ext_hold.reset();
                 }

@@ -499,6 +499,7 @@ class MemberInflater {
         const int T = opt_.threads;
         uint64_t max_ratio = opt_.max_ratio;
         rounds_ = max_chain_ = 0;
+        win_.assign(WIN, 0);
         segs_.clear();
         for (int j = 0; j < T; ++j) segs_.emplace_back(new Seg());
         while (!final) {
@@ -538,8 +539,7 @@ class MemberInflater {
             const uint64_t known = total < WIN ? total : WIN;
             {
                 uint16_t *sy = (uint16_t *)segs_[0]->sym.p;
-                for (uint32_t i = 0; i < WIN; ++i) sy[i] = 0;
-                for (uint64_t i = 0; i < known; ++i) sy[WIN - known + i] = out[total - known + i];
+                for (uint32_t i = 0; i < WIN; ++i) sy[i] = i >= WIN - known ? win_[i] : 0;  // (kept here, not read back from `out`: the caller may have given those pages back)
             }
             const auto t0 = std::chrono::steady_clock::now();
             std::vector<std::thread> th;
@@ -569,7 +569,7 @@ class MemberInflater {
             // windows in order: segment k's markers point into the last 32 KB before it
             std::vector<std::vector<uint8_t>> lut(chain.size());
             {
-                std::vector<uint8_t> win(WIN, 0);
+                std::vector<uint8_t> &win = win_;  // enters as the window before this round, leaves as the one after it
                 for (size_t c = 0; c < chain.size(); ++c) {
                     Seg &s = *segs_[(size_t)chain[c]];
                     lut[c].assign(65536, 0);
@@ -759,6 +759,7 @@ class MemberInflater {
     Options opt_;
     std::vector<std::unique_ptr<Seg>> segs_;
     std::atomic<bool> abort_{false};
+    std::vector<uint8_t> win_;  // the last 32 KB of the member's output so far (right-aligned)
     int rounds_ = 0, max_chain_ = 0;
 };
 

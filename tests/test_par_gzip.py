@@ -196,3 +196,34 @@ def test_feeder_uses_all_threads_on_a_large_member(tool, tmp_path, fastq):
     p.write_bytes(bytes(bad))
     r = subprocess.run([tool, str(p), "fastq" if fastq else "fasta", "100000", "3"], capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
     assert r.returncode != 0 and "gzip" in r.stderr
+
+
+def test_feeder_memory_stays_bounded_on_a_large_member(tool, tmp_path):
+    """A member is inflated into one buffer of its own, round by round; the pages of a round go back to the system once the parsers
+    have copied its records out (the inflater keeps the last 32 KB itself), so a member of any size costs the memory of the rounds
+    in flight, not of its whole output: peak RSS on a 96-MB member stays far below 96 MB, records identical to the one-thread
+    reader's."""
+    import sys
+    rng = random.Random(77)
+    genome = "".join(rng.choice("ACGT") for _ in range(1 << 20))
+    recs = []
+    for i in range(6000):
+        s = rng.randrange(0, (1 << 20) - 16000)
+        recs.append(">r%d\n%s\n" % (i, genome[s:s + 16000]))
+    data = "".join(recs).encode()
+    assert len(data) > 96_000_000
+    p = tmp_path / "big.fa.gz"
+    p.write_bytes(gzip.compress(data, 1))
+    runner = ("import resource, subprocess, sys; r = subprocess.run(sys.argv[1:], capture_output=True, text=True); "
+              "print(r.returncode, resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss, r.stdout.strip())")
+    out = {}
+    for name, env in (("par", {"MQ_PARGZ_MIN": "1000", "MQ_PARGZ_SEG": "400000", "MQ_PARGZ_MINSEG": "100000"}), ("one", {"MQ_PARGZ": "0"})):
+        r = subprocess.run([sys.executable, "-c", runner, tool, str(p), "fasta", str(1 << 20), "4"], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, FEEDER_DUMP_QUIET="1", **env))
+        rc, rss_kb, n_rec, n_bases = r.stdout.split()
+        assert rc == "0", r.stdout + r.stderr
+        out[name] = (int(rss_kb), n_rec, n_bases)
+    assert out["par"][1:] == out["one"][1:] == ("6000", str(6000 * 16000))
+    # KB: the mapped input (~27 MB here) + the rounds in flight (symbols, chunk buffers) -- not the 96 MB of the member on top
+    assert out["par"][0] < 72_000 and out["par"][0] < 0.6 * out["one"][0], out
+    assert out["one"][0] > 96_000, out      # the one-call reader holds the whole output
