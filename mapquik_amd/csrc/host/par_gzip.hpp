@@ -211,7 +211,7 @@ static const Tables &fixed_tables() {
     return *T;
 }
 
-enum Rc { RC_OK = 0, RC_CORRUPT = 1, RC_TRUNCATED = 2, RC_NOSPACE = 3, RC_NOT_TEXT = 4 };
+enum Rc { RC_OK = 0, RC_CORRUPT = 1, RC_TRUNCATED = 2, RC_NOSPACE = 3, RC_NOT_TEXT = 4, RC_NOMEM = 5 };
 
 // dynamic block header (after the 3 header bits) -> t.  strict: what a block START SEARCH demands on top of validity.
 static Rc read_dynamic_header(Bits &b, Tables &t, bool strict) {
@@ -554,6 +554,7 @@ class MemberInflater {
                 for (;;) {
                     Seg &s = *segs_[(size_t)k];
                     if (s.rc == RC_TRUNCATED) throw Error("gzip stream truncated");
+                    if (s.rc == RC_NOMEM) throw Error("out of memory inflating a gzip member");
                     if (s.rc != RC_OK) throw Error("gzip stream corrupt");
                     chain.push_back(k);
                     if (s.final || s.next_seg < 0 || s.next_seg >= ns) break;
@@ -676,7 +677,20 @@ class MemberInflater {
         return p;
     }
 
+    // a worker never leaves its segment's start unpublished (its predecessor waits for it) and never lets an exception escape its thread
     void seg_worker(int j, int ns, const uint8_t *din, const uint8_t *dend, uint64_t round_end_bit, uint32_t known) {
+        Seg &s = *segs_[(size_t)j];
+        try {
+            seg_work(j, ns, din, dend, round_end_bit, known);
+        } catch (...) {  // out of memory for the tables: the round fails as a whole
+            s.rc = RC_NOMEM;
+            s.n_sym = 0;
+        }
+        int64_t pend = PENDING;
+        s.sync.compare_exchange_strong(pend, NONE);
+    }
+
+    void seg_work(int j, int ns, const uint8_t *din, const uint8_t *dend, uint64_t round_end_bit, uint32_t known) {
         Seg &s = *segs_[(size_t)j];
         uint16_t *sym = (uint16_t *)s.sym.p;
         std::unique_ptr<Tables> tab(new Tables());
