@@ -493,40 +493,16 @@ class MemberInflater {
         const uint8_t *din = in_ + hdr;
         const uint8_t *dend = in_ + in_len_;
         uint64_t bit = 0;       // where the next round starts (exact)
-        uint64_t total = 0;     // bytes of the member laid out so far (translated up to the round before the one in flight)
-        uint32_t crc = 0;       // CRC-32 of nothing
+        uint64_t total = 0;     // bytes of the member produced so far
+        uint32_t crc = 0;  // CRC-32 of nothing
         bool final = false;
         const int T = opt_.threads;
         uint64_t max_ratio = opt_.max_ratio;
         rounds_ = max_chain_ = 0;
         win_.assign(WIN, 0);
-        for (auto &set : sets_) {
-            set.clear();
-            for (int j = 0; j < T; ++j) set.emplace_back(new Seg());
-        }
-        // a round's translation to bytes (+ CRC) runs beside the next round's decoding: two sets of segments take turns
-        struct Finish {
-            std::thread th;
-            std::vector<int> chain;
-            int set = 0;
-            uint64_t total_after = 0;
-            bool final = false, active = false;
-        } fin;
-        auto join_finish = [&](bool report) {
-            if (!fin.active) return;
-            fin.th.join();
-            fin.active = false;
-            for (int k : fin.chain) crc = (uint32_t)crc32_combine(crc, sets_[fin.set][(size_t)k]->crc, (z_off_t)sets_[fin.set][(size_t)k]->n_sym);
-            if (report && on_round) on_round(fin.total_after, fin.final);
-        };
-        struct Guard {  // no thread outlives an exception
-            std::function<void()> f;
-            ~Guard() { f(); }
-        } guard{[&] { if (fin.active) { fin.th.join(); fin.active = false; } }};
-        for (int r = 0; !final; ++r) {
-            const int set = r & 1;
-            cur_ = &sets_[set];
-            auto &segs_ = sets_[set];
+        segs_.clear();
+        for (int j = 0; j < T; ++j) segs_.emplace_back(new Seg());
+        while (!final) {
             const uint64_t byte0 = bit >> 3, bit0 = bit;
             const uint64_t rest = (uint64_t)(dend - din) - byte0;
             // segments of this round: whole rounds of threads x seg_bytes, the member's rest (up to 1.5 rounds' worth) in equal parts
@@ -566,14 +542,11 @@ class MemberInflater {
                 for (uint32_t i = 0; i < WIN; ++i) sy[i] = i >= WIN - known ? win_[i] : 0;  // (kept here, not read back from `out`: the caller may have given those pages back)
             }
             const auto t0 = std::chrono::steady_clock::now();
-            {
-                std::vector<std::thread> th;
-                for (int j = 1; j < ns; ++j) th.emplace_back([&, j] { seg_worker(j, ns, din, dend, round_end_bit, WIN); });
-                seg_worker(0, ns, din, dend, round_end_bit, (uint32_t)known);
-                for (auto &t : th) t.join();
-            }
+            std::vector<std::thread> th;
+            for (int j = 1; j < ns; ++j) th.emplace_back([&, j] { seg_worker(j, ns, din, dend, round_end_bit, WIN); });
+            seg_worker(0, ns, din, dend, round_end_bit, (uint32_t)known);
+            for (auto &t : th) t.join();
             const auto t1 = std::chrono::steady_clock::now();
-            join_finish(true);  // the round before this one is bytes now: its ranges go to the caller while this round is laid out
             // the chain of segments that really follow each other
             std::vector<int> chain;
             {
@@ -595,49 +568,33 @@ class MemberInflater {
             }
             if (total + round_bytes > out_cap) throw Error("space (the member's output)");
             // windows in order: segment k's markers point into the last 32 KB before it
-            auto lut = std::make_shared<std::vector<std::vector<uint8_t>>>(chain.size());
+            std::vector<std::vector<uint8_t>> lut(chain.size());
             {
                 std::vector<uint8_t> &win = win_;  // enters as the window before this round, leaves as the one after it
                 for (size_t c = 0; c < chain.size(); ++c) {
                     Seg &s = *segs_[(size_t)chain[c]];
-                    (*lut)[c].assign(65536, 0);
-                    for (uint32_t v = 0; v < 256; ++v) (*lut)[c][v] = (uint8_t)v;
-                    if (c > 0) memcpy(&(*lut)[c][0x8000], win.data(), WIN);
+                    lut[c].assign(65536, 0);
+                    for (uint32_t v = 0; v < 256; ++v) lut[c][v] = (uint8_t)v;
+                    if (c > 0) memcpy(&lut[c][0x8000], win.data(), WIN);
                     // this segment's last 32 KB (its prefix included when it produced less), resolved: the next one's window
                     const uint16_t *sy = (const uint16_t *)s.sym.p + s.n_sym;  // = end - WIN of [prefix | data]
                     std::vector<uint8_t> nw(WIN);
-                    for (uint32_t i = 0; i < WIN; ++i) nw[i] = (*lut)[c][sy[i]];
+                    for (uint32_t i = 0; i < WIN; ++i) nw[i] = lut[c][sy[i]];
                     win.swap(nw);
                 }
             }
-            total += round_bytes;
-            rounds_++;
-            if ((int)chain.size() > max_chain_) max_chain_ = (int)chain.size();
-            const Seg &lastseg = *segs_[(size_t)chain.back()];
-            final = lastseg.final;
-            bit = lastseg.end_bit;
-            if (!final && chain.size() == 1 && lastseg.end_bit == bit0) {  // no progress: a block that does not fit the symbol buffer, or nonsense
-                if (!lastseg.nospace || max_ratio > 4096) throw Error("gzip stream corrupt");
-                max_ratio *= 8;
-            }
-            // translate + CRC, all segments at once -- beside the next round's decoding
-            fin.chain = chain;
-            fin.set = set;
-            fin.total_after = total;
-            fin.final = final;
-            fin.active = true;
-            auto *segs = &sets_[set];
-            fin.th = std::thread([this, segs, chain, lut, out, T] {
+            // translate + CRC, all segments at once
+            {
                 std::vector<std::thread> tt;
                 std::atomic<size_t> nextc{0};
                 auto work = [&] {
                     for (;;) {
                         const size_t c = nextc.fetch_add(1);
                         if (c >= chain.size()) break;
-                        Seg &s = *(*segs)[(size_t)chain[c]];
+                        Seg &s = *segs_[(size_t)chain[c]];
                         const uint16_t *sy = (const uint16_t *)s.sym.p + WIN;
                         uint8_t *o = out + s.out_off;
-                        const uint8_t *L = (*lut)[c].data();
+                        const uint8_t *L = lut[c].data();
                         const uint64_t n = s.n_sym;
                         translate(sy, o, n, L);
                         uint32_t cr = 0;
@@ -653,14 +610,25 @@ class MemberInflater {
                 for (int i = 1; i < nt; ++i) tt.emplace_back(work);
                 work();
                 for (auto &t : tt) t.join();
-            });
+            }
+            for (int k : chain) crc = (uint32_t)crc32_combine(crc, segs_[(size_t)k]->crc, (z_off_t)segs_[(size_t)k]->n_sym);
+            total += round_bytes;
+            rounds_++;
+            if ((int)chain.size() > max_chain_) max_chain_ = (int)chain.size();
+            const Seg &lastseg = *segs_[(size_t)chain.back()];
+            final = lastseg.final;
+            bit = lastseg.end_bit;
             if (opt_.timing) {
                 const auto t2 = std::chrono::steady_clock::now();
-                fprintf(stderr, "pargz round: %d segments of %.1f MB, %zu in the chain, %.1f MB out, decode %.3f s, windows %.3f s (bytes + CRC beside the next round)\n", ns, S / 1e6,
-                        chain.size(), round_bytes / 1e6, std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count());
+                fprintf(stderr, "pargz round: %d segments of %.1f MB, %zu in the chain, %.1f MB out, decode %.3f s, resolve %.3f s\n", ns, S / 1e6, chain.size(),
+                        round_bytes / 1e6, std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count());
             }
+            if (!final && chain.size() == 1 && lastseg.end_bit == bit0) {  // no progress: a block that does not fit the symbol buffer, or nonsense
+                if (!lastseg.nospace || max_ratio > 4096) throw Error("gzip stream corrupt");
+                max_ratio *= 8;
+            }
+            if (on_round) on_round(total, final);
         }
-        join_finish(true);
         // trailer: CRC-32 and ISIZE at the next byte boundary
         const uint64_t tpos = (bit + 7u) >> 3;
         if ((uint64_t)(dend - din) < tpos + 8u) throw Error("gzip stream truncated");
@@ -711,7 +679,7 @@ class MemberInflater {
 
     // a worker never leaves its segment's start unpublished (its predecessor waits for it) and never lets an exception escape its thread
     void seg_worker(int j, int ns, const uint8_t *din, const uint8_t *dend, uint64_t round_end_bit, uint32_t known) {
-        Seg &s = *(*cur_)[(size_t)j];
+        Seg &s = *segs_[(size_t)j];
         try {
             seg_work(j, ns, din, dend, round_end_bit, known);
         } catch (...) {  // out of memory for the tables: the round fails as a whole
@@ -723,7 +691,7 @@ class MemberInflater {
     }
 
     void seg_work(int j, int ns, const uint8_t *din, const uint8_t *dend, uint64_t round_end_bit, uint32_t known) {
-        Seg &s = *(*cur_)[(size_t)j];
+        Seg &s = *segs_[(size_t)j];
         uint16_t *sym = (uint16_t *)s.sym.p;
         std::unique_ptr<Tables> tab(new Tables());
         uint64_t start;
@@ -732,7 +700,7 @@ class MemberInflater {
         } else {
             // a block start in [nominal, next segment's nominal), looked for in the segment's first 2 MB (blocks are far smaller)
             for (uint32_t i = 0; i < WIN; ++i) sym[i] = (uint16_t)(0x8000u + i);
-            uint64_t lim = j + 1 < ns ? (*cur_)[(size_t)j + 1]->nominal_bit : (uint64_t)(dend - din) * 8u;
+            uint64_t lim = j + 1 < ns ? segs_[(size_t)j + 1]->nominal_bit : (uint64_t)(dend - din) * 8u;
             if (lim > s.nominal_bit + (16u << 20)) lim = s.nominal_bit + (16u << 20);
             int64_t found = NONE;
             for (uint64_t at = s.nominal_bit; at < lim; ++at) {
@@ -778,9 +746,9 @@ class MemberInflater {
             }
             if (j != 0 && abort_.load(std::memory_order_relaxed)) break;
             bool stop = false;
-            while (target < ns && at >= (*cur_)[(size_t)target]->nominal_bit) {
+            while (target < ns && at >= segs_[(size_t)target]->nominal_bit) {
                 int64_t t;
-                while ((t = (*cur_)[(size_t)target]->sync.load(std::memory_order_acquire)) == PENDING) std::this_thread::yield();
+                while ((t = segs_[(size_t)target]->sync.load(std::memory_order_acquire)) == PENDING) std::this_thread::yield();
                 if (t == NONE || (uint64_t)t < at) {
                     ++target;  // no start there, or one this decoder walked over: not a block boundary after all
                     continue;
@@ -803,8 +771,7 @@ class MemberInflater {
     const uint8_t *in_;
     uint64_t in_len_;
     Options opt_;
-    std::vector<std::unique_ptr<Seg>> sets_[2];  // two sets of segments: one decodes while the other is turned into bytes
-    std::vector<std::unique_ptr<Seg>> *cur_ = nullptr;
+    std::vector<std::unique_ptr<Seg>> segs_;
     std::atomic<bool> abort_{false};
     std::vector<uint8_t> win_;  // the last 32 KB of the member's output so far (right-aligned)
     int rounds_ = 0, max_chain_ = 0;
