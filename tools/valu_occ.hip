@@ -185,6 +185,33 @@ int main() {
         }
         fflush(stdout);
     }
+    // workgroups whose wave count is no multiple of 4 (10 waves x 2 per CU = 5 per SIMD if the hardware spreads them evenly): the
+    // median and the slowest wave against the even layouts above
+    for (const Test &t : tests) {
+        if (t.per_iter != 88 && t.per_iter != 16 * 11) continue;
+        for (int waves : {10, 6}) {
+            const int bpc = 2, threads = 64 * waves;
+            const size_t lds = 64 * 1024;
+            CHECK(hipFuncSetAttribute((const void *)t.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const int grid = n_cu * bpc;
+            double med = 1e30, mx = 1e30, mn = 1e30;
+            for (int rep = 0; rep < 3; ++rep) {
+                hipLaunchKernelGGL(t.fn, dim3(grid), dim3(threads), lds, 0, 12345u + rep, 77u, d_out);
+                CHECK(hipGetLastError());
+                CHECK(hipDeviceSynchronize());
+                if (rep == 0) continue;
+                std::vector<unsigned long long> h((size_t)grid * waves);
+                CHECK(hipMemcpy(h.data(), d_out + 1, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                std::sort(h.begin(), h.end());
+                const double den = (double)ITER * t.per_iter * (waves * bpc / 4.0);
+                med = std::min(med, (double)h[h.size() / 2] / den);
+                mx = std::min(mx, (double)h.back() / den);
+                mn = std::min(mn, (double)h[0] / den);
+            }
+            printf("%s: %d-wave workgroups x 2 (%.1f waves per SIMD): fastest / median / slowest wave %.2f / %.2f / %.2f cycles per instruction per SIMD\n", t.name, waves,
+                   waves * bpc / 4.0, mn, med, mx);
+        }
+    }
     CHECK(hipFree(d_out));
     return 0;
 }
