@@ -237,7 +237,8 @@ struct BigBuf {
     uint64_t cap = 0;
     explicit BigBuf(uint64_t n) {
         cap = ((n + (2u << 20) - 1) / (2u << 20)) * (2u << 20);
-        p = (uint8_t *)mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        // address space only: pages exist once written (and go back once parsed), so the mapping is not to be charged in full
+        p = (uint8_t *)mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
         if (p == MAP_FAILED) {
             p = nullptr;
             throw FeederError("cannot map memory for a gzip member");
@@ -833,7 +834,15 @@ class Feeder {
                     cv_.notify_all();
                 };
                 for (;;) {
-                    big = std::make_shared<BigBuf>(cap + 64);
+                    for (;;) {  // a refused reservation (strict overcommit accounting) is asked for again at a quarter, down to 2 x the rest of the file
+                        try {
+                            big = std::make_shared<BigBuf>(cap + 64);
+                            break;
+                        } catch (const FeederError &) {
+                            if (cap / 4 < 2 * (file_size_ - p) + carry.size() + (64u << 20)) throw;
+                            cap /= 4;
+                        }
+                    }
                     if (!carry.empty()) memcpy(big->p, carry.data(), carry.size());
                     const auto tt0 = std::chrono::steady_clock::now();
                     int rc = 0;
