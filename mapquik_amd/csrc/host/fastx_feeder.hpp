@@ -816,7 +816,10 @@ class Feeder {
             while (p < file_size_) {
                 if (file_size_ - p < 18 || map_[p] != 0x1f || map_[p + 1] != 0x8b) throw FeederError("gzip stream truncated or corrupt: " + path_);
                 const bool par = par_on && !prev_small && file_size_ - p >= par_min;
-                uint64_t cap = std::max<uint64_t>(64u << 20, (par ? 64 : 12) * (file_size_ - p)) + carry.size();  // address space; pages exist once written
+                // address space; pages exist once written.  All threads: what deflate can expand to at most (1032 : 1), within 16 TB (but
+                // 64 : 1 at least), since pages behind the parsers go back to the system; one call: 12 : 1, doubled when it was not enough
+                const uint64_t rest = file_size_ - p;
+                uint64_t cap = (par ? std::max<uint64_t>(64 * rest, std::min<uint64_t>(1100 * rest, 16ull << 40)) : std::max<uint64_t>(64u << 20, 12 * rest)) + carry.size();
                 std::shared_ptr<BigBuf> big;
                 size_t ain = 0, aout = 0;
                 uint64_t a = 0;  // start of the bytes not yet handed to a parser
