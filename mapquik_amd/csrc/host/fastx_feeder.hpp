@@ -87,7 +87,7 @@ inline int fastq_record_at(const uint8_t *b, uint64_t p, uint64_t end, bool at_e
     // tells a header from a quality line that happens to begin with '@'
     if (p >= end) return at_eof ? 0 : 2;
     if (b[p] != '@') return 0;
-    const int unknown = at_eof ? 1 : 2;
+    const int unknown = at_eof ? 0 : 2;  // at the end of the input an "@" line with fewer than three lines behind it starts no record (a quality line that begins with "@")
     const uint8_t *e1 = (const uint8_t *)memchr(b + p, '\n', end - p);
     if (!e1) return unknown;
     const uint8_t *e2 = (const uint8_t *)memchr(e1 + 1, '\n', b + end - (e1 + 1));
@@ -604,6 +604,12 @@ class Feeder {
                 const int rc = inflate(&zs, Z_FINISH);
                 if (rc != Z_STREAM_END || zs.avail_out != 0) throw FeederError("BGZF block corrupt: " + path_);
             }
+            {  // the block's CRC-32 (the four bytes before ISIZE): a damaged block of the right length is an error, as for flate2
+                const uint8_t *t = map_ + bg_coff_[b + 1] - 8;
+                const uint32_t want = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+                const uint32_t have = deflate_.crc ? deflate_.crc(0, out, (size_t)(u1 - u0)) : (uint32_t)crc32(0L, out, (uInt)(u1 - u0));
+                if (have != want) throw FeederError("BGZF block corrupt: " + path_);
+            }
             if (!whole) {
                 const uint64_t a = std::max(u0, off), e = std::min(u1, end);
                 memcpy(dst + (a - off), tmp + (a - u0), e - a);
@@ -815,11 +821,20 @@ class Feeder {
             bool prev_small = false;                                   // a file of many small members: do not start a round of threads for each
             while (p < file_size_) {
                 if (file_size_ - p < 18 || map_[p] != 0x1f || map_[p + 1] != 0x8b) throw FeederError("gzip stream truncated or corrupt: " + path_);
-                const bool par = par_on && !prev_small && file_size_ - p >= par_min;
-                // address space; pages exist once written.  All threads: what deflate can expand to at most (1032 : 1), within 16 TB (but
-                // 64 : 1 at least), since pages behind the parsers go back to the system; one call: 12 : 1, doubled when it was not enough
                 const uint64_t rest = file_size_ - p;
-                uint64_t cap = (par ? std::max<uint64_t>(64 * rest, std::min<uint64_t>(1100 * rest, 16ull << 40)) : std::max<uint64_t>(64u << 20, 12 * rest)) + carry.size();
+                const bool par_ok = par_on && rest >= par_min;
+                bool par = par_ok && !prev_small;
+                // address space; pages exist once written.  All threads: what deflate can expand to at most (1032 : 1), within 16 TB (but
+                // 64 : 1 at least), since pages behind the parsers go back to the system; one call: 12 : 1, doubled when it was not enough.
+                // A one-call attempt made only because the PREVIOUS member was small is bounded (a small member fits 16 x par_min): a
+                // member that does not fit is a large one after all and goes to all threads, so that a tiny first member in front of a
+                // multi-GB one does not make the large one inflate fully resident.
+                auto cap_for = [&](bool all_threads) -> uint64_t {
+                    if (all_threads) return std::max<uint64_t>(64 * rest, std::min<uint64_t>(1100 * rest, 16ull << 40)) + carry.size();
+                    const uint64_t one = std::max<uint64_t>(64u << 20, 12 * rest);
+                    return (par_ok ? std::min<uint64_t>(one, std::max<uint64_t>(64u << 20, 16 * par_min)) : one) + carry.size();
+                };
+                uint64_t cap = cap_for(par);
                 std::shared_ptr<BigBuf> big;
                 size_t ain = 0, aout = 0;
                 uint64_t a = 0;  // start of the bytes not yet handed to a parser
@@ -880,6 +895,11 @@ class Feeder {
                     if (getenv("MQ_FEEDER_TIMING")) fprintf(stderr, "gzip member (%s): rc %d, %zu -> %zu bytes in %.3f s\n", par ? "all threads" : "libdeflate", rc, ain, aout, std::chrono::duration<double>(std::chrono::steady_clock::now() - tt0).count());
                     if (rc == 0) break;
                     if (rc != 3 || cap > (1ull << 37)) throw FeederError("gzip stream truncated or corrupt: " + path_);
+                    if (!par && par_ok) {  // not a small member after all
+                        par = true;
+                        cap = cap_for(true);
+                        continue;
+                    }
                     cap *= 2;  // insufficient space: a member compressed better than expected
                 }
                 prev_small = ain < par_min;

@@ -543,7 +543,20 @@ class MemberInflater {
             }
             const auto t0 = std::chrono::steady_clock::now();
             std::vector<std::thread> th;
-            for (int j = 1; j < ns; ++j) th.emplace_back([&, j] { seg_worker(j, ns, din, dend, round_end_bit, WIN); });
+            try {
+                th.reserve((size_t)ns);
+                for (int j = 1; j < ns; ++j) th.emplace_back([&, j] { seg_worker(j, ns, din, dend, round_end_bit, WIN); });
+            } catch (const std::exception &) {
+                // a thread could not be started (EAGAIN under a pid / thread limit): the segments nobody will decode publish "no start" so
+                // that no predecessor waits for them, the started ones are told to stop and joined -- an Error, not std::terminate
+                abort_.store(true);
+                for (int j = (int)th.size() + 1; j < ns; ++j) {
+                    int64_t pend = PENDING;
+                    segs_[(size_t)j]->sync.compare_exchange_strong(pend, NONE);
+                }
+                for (auto &t : th) t.join();
+                throw Error("cannot start a thread for a gzip segment");
+            }
             seg_worker(0, ns, din, dend, round_end_bit, (uint32_t)known);
             for (auto &t : th) t.join();
             const auto t1 = std::chrono::steady_clock::now();
@@ -607,7 +620,12 @@ class MemberInflater {
                     }
                 };
                 const int nt = (int)std::min<size_t>(chain.size(), (size_t)T);
-                for (int i = 1; i < nt; ++i) tt.emplace_back(work);
+                try {
+                    tt.reserve((size_t)nt);
+                    for (int i = 1; i < nt; ++i) tt.emplace_back(work);
+                } catch (const std::exception &) {
+                    // fewer helpers than wanted: the started ones and this thread share the segments (work() takes them from one counter)
+                }
                 work();
                 for (auto &t : tt) t.join();
             }

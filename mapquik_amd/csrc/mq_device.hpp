@@ -106,8 +106,8 @@ __device__ __forceinline__ uint32_t lane_id() {
 constexpr int MQ_N_CLK = 12;
 #ifdef MQ_STAGE_CLOCKS
 struct StageClkLds {
-    unsigned long long acc[12][MQ_N_CLK];  // workgroups of at most 12 waves
-    unsigned long long last[12];
+    unsigned long long acc[16][MQ_N_CLK];  // a workgroup has at most 16 waves (1,024 threads)
+    unsigned long long last[16];
 };
 __device__ __forceinline__ StageClkLds &mq_clk_lds() {
     __shared__ StageClkLds C;

@@ -13,7 +13,7 @@
 //            rotation sits in the ds_read_b128's immediate offset), four look-ups in flight.
 //            The per-step test is min(fh.hi, rh.hi) <= hi(bound) (one v_alignbit per strand to un-rotate the high word); its
 //            outcome is shifted into a per-lane flag word (v_cmp + v_addc: no branch, no scalar work, nothing stored); the
-//            flag words go to LDS once per 16 steps.
+//            flag words stay in registers (one per 32 steps) until stage R has listed them.
 //   stage R  every lane lists the windows of its own candidates at their places (prefix sum of the lanes' counts); then lane =
 //            candidate, in position order: the window's two hashes computed again from the code stream, four bases per look-up
 //            (256-entry table; l = 31: all eight look-ups in flight at once); exact 64-bit test; raw position = the block
@@ -35,13 +35,23 @@ constexpr uint32_t SD_TILE_RAW = SD_SR_RAW * SD_MAX_SR;    // 12288
 constexpr uint32_t SD_BLOCKS = SD_TILE_RAW / 64;           // 64-base blocks per tile
 constexpr uint32_t SD_CODES_MAX = SD_TILE_RAW + MAX_L - 1; // codes of one tile incl. the carried l-1 (no compression at all)
 constexpr uint32_t SD_LC_MAX = (SD_CODES_MAX + 63) / 64;   // windows per lane
-constexpr uint32_t SD_FLAG_BLKS = 4 * ((SD_LC_MAX + 63) / 64);  // 16-step blocks per lane (flag words of 16 bits), padded to whole 64-bit words
+constexpr uint32_t SD_FLAG_WORDS = (SD_LC_MAX + 31) / 32;  // 32-step flag words per lane (kept in registers between stages B and R)
+static_assert(SD_FLAG_WORDS <= 16, "flag words per lane");
+// the flag words as one register tuple: stage B writes word w with w wave-uniform but not a compile-time constant (an indexed
+// register move, s_set_gpr_idx + v_mov), stage R reads them with constant indices
+typedef uint32_t FlagWords __attribute__((ext_vector_type(SD_FLAG_WORDS <= 4 ? 4 : SD_FLAG_WORDS <= 8 ? 8 : 16)));
 constexpr uint32_t SD_CODES_DW = 4 * ((63 * SD_LC_MAX + 16 * ((SD_LC_MAX + 15) / 16) + MAX_L + 32) / 64 + 1);  // packed 2-bit codes + zero read-ahead padding (whole uint4s)
 static_assert((63 * SD_LC_MAX + 16 * ((SD_LC_MAX + 15) / 16) + MAX_L + 32) / 16 < SD_CODES_DW, "code stream read-ahead padding");
-static_assert((SD_LC_MAX + 15) / 16 <= SD_FLAG_BLKS && SD_FLAG_BLKS % 4 == 0, "flag words");
 #ifndef MQ_SD_OWNER_CAP
 #define MQ_SD_OWNER_CAP 256
 #endif
+// 1: a tile's first super-row is requested by the previous tile's stage A and rides through its stages B and R in 16 registers
+// (no tile opens with an exposed HBM round trip); 0: every tile requests its own (builds that must stay under 64 registers
+// and have eight waves per SIMD to cover the wait)
+#ifndef MQ_SD_CROSS_PREFETCH
+#define MQ_SD_CROSS_PREFETCH 1
+#endif
+constexpr bool SD_CROSS_PREFETCH = MQ_SD_CROSS_PREFETCH != 0;
 constexpr uint32_t SD_OWNER_CAP = MQ_SD_OWNER_CAP;                     // candidates listed per round of stage R (four lane-batches)
 static_assert(SD_BLOCKS <= 256, "block_of holds block numbers in a byte");
 
@@ -60,7 +70,6 @@ struct SeedLds {
     uint32_t codes[SD_CODES_DW];                 // the tile's 2-bit code stream (carried l-1 codes first)
     unsigned long long heads[SD_BLOCKS];         // bit b of heads[k]: raw base 64k + b of the tile is a run head
     uint16_t cnt[SD_BLOCKS + 4];                 // index in the code stream of block k's first run head; cnt[n_blocks] = n_codes
-    unsigned long long flags[64 * SD_FLAG_BLKS / 4];  // lane L, 16-step block b: bit t of the uint16 at [L * SD_FLAG_BLKS + b] <=> step 16 b + t is a candidate
     uint32_t carry_codes[4];                     // codes carried into the next tile (<= 63)
     uint32_t carry_pos[64];                      // their raw positions
     uint8_t block_of[SD_CODES_MAX / 64 + 3];     // block_of[c]: the 64-base block that holds code 64 c (the walk to a code's block starts there)
@@ -188,9 +197,8 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
     if (n_sr > SD_MAX_SR) n_sr = SD_MAX_SR;
     const uint32_t tile_end = raw0 + n_sr * SD_SR_RAW;  // >= len in the sequence's last tile
     uint4 &nx0 = pre.nx0, &nx1 = pre.nx1, &nx2 = pre.nx2, &nx3 = pre.nx3;
+    if (!SD_CROSS_PREFETCH && raw0 != 0) stage_a_request(seq, len, raw0, pre);
     for (uint32_t i = lane * 4u; i < SD_CODES_DW; i += 256u) *reinterpret_cast<uint4 *>(&S.codes[i]) = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (uint32_t w = 0; w < SD_FLAG_BLKS / 4u; ++w) S.flags[lane * (SD_FLAG_BLKS / 4u) + w] = 0ull;  // stage B sets bits in its own blocks only
     wave_sync();
     if (lane < 4u && carry_n) S.codes[lane] = S.carry_codes[lane];  // the carried codes open the stream
     if (lane == 0) S.block_of[0] = 0;  // codes [carry_n, 64): the walk starts at block 0 (whose range may begin after code 0)
@@ -199,7 +207,7 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
     constexpr uint32_t S1 = 0x00430041u, S0 = 0x00470054u;  // v_perm pool: selector 0,2 -> 'A','C' ; 4,6 -> 'T','G'
     for (uint32_t sr = 0; sr < n_sr; ++sr) {
         const uint32_t pos = raw0 + sr * SD_SR_RAW + lane * 64u;
-        const bool more_sr = sr + 1u < n_sr || tile_end < len;  // the tile's last super-row requests the next tile's first
+        const bool more_sr = sr + 1u < n_sr || (SD_CROSS_PREFETCH && tile_end < len);  // the tile's last super-row requests the next tile's first
         uint32_t p[4];
         // decode piece j, then send the load of the NEXT super-row's piece j into the registers just freed: 16 registers of
         // bases in flight plus the piece being decoded, instead of two whole super-rows
@@ -413,15 +421,16 @@ __device__ __forceinline__ uint32_t stage_b_block(const SeedTables &T, uint32_t 
 }
 
 // Rolls ntHash over windows [0, w_eff) of the tile's code stream; lane L owns windows [L*lc, (L+1)*lc), lc = ceil(w_eff/64).
-// The outcome of every step's high-word test goes into the lane's flag word; nothing else is kept (stage R computes a
-// candidate's hashes again).  Steps past the last window (only the last active lane has them) may set bits too: stage R
-// masks them.  S.flags must be zero on entry for the blocks this lane does not write.
-__device__ __forceinline__ void seed_stage_b(const SeedTables &T, SeedLds &S, const DevParams &P, uint32_t w_eff) {
+// The outcome of every step's high-word test goes into the lane's flag words f[] (bit t of f[w] <=> step 32 w + t is a
+// candidate); nothing else is kept (stage R computes a candidate's hashes again) and the flags never leave the registers.
+// Steps past the last window (only the last active lane has them) may set bits too: stage R masks them.
+__device__ __forceinline__ void seed_stage_b(const SeedTables &T, SeedLds &S, const DevParams &P, uint32_t w_eff, FlagWords &f) {
     const uint32_t lane = lane_id();
     const uint32_t l = P.l;
     const uint32_t lc = (w_eff + 63u) >> 6;
     const uint32_t s0 = lane * lc;
     const uint32_t bhi = (uint32_t)(P.bound >> 32);
+    f = 0u;
     if (s0 < w_eff) {  // lanes beyond the last window sit out (exec-masked)
         const Hash2 h0 = window_hash(T, S, l, s0);  // the lane's first window: G_0 = F_0, H_0 = R_0
         uint32_t glo = h0.flo, ghi = h0.fhi, hlo = h0.rlo, hhi = h0.rhi;
@@ -446,17 +455,41 @@ __device__ __forceinline__ void seed_stage_b(const SeedTables &T, SeedLds &S, co
 #pragma unroll
         for (uint32_t s = 0; s < 4; ++s) tv[s] = T.rot[(s + 1u) * 16u + nib(xe, xo, s)];
         const uint32_t nb = (lc + 15u) >> 4;
-        uint16_t *fl = reinterpret_cast<uint16_t *>(S.flags) + lane * SD_FLAG_BLKS;
-        for (uint32_t blk = 0; blk < nb; ++blk) {
+        // the code words of the block after block b, as nibbles (out | in<<2) of its even and odd steps
+        auto next_x = [&](uint32_t b, uint32_t &xe_n, uint32_t &xo_n) {
+            const uint32_t no = S.codes[o_dw + b + 2u], ni = S.codes[i_dw + b + 2u];
+            const uint32_t ow = __builtin_amdgcn_alignbit(no, prev_o, o_sh), iw = __builtin_amdgcn_alignbit(ni, prev_i, i_sh);
+            prev_o = no;
+            prev_i = ni;
+            xe_n = mk_xe(ow, iw);
+            xo_n = mk_xo(ow, iw);
+        };
+        // flag word w of the lane (w is wave-uniform: a scalar compare picks the register)
+        auto put = [&](uint32_t w_at, uint32_t v) { f[w_at] = v; };
+        // Whole 64-step groups: the four rotation phases of the frame back to back in straight-line code, so that the hash state, the
+        // ring of table values and the code words stay where they are (a loop over single blocks with a switch over the phase
+        // costs ~14 register moves per block at the merge points).
+        uint32_t blk = 0;
+        for (const uint32_t full = (lc >> 6) << 2; blk < full; blk += 4u) {
+            uint32_t xe1, xo1, xe2, xo2, xe3, xo3, xe4, xo4;
+            next_x(blk, xe1, xo1);
+            const uint32_t b0 = stage_b_block<0, false>(T, glo, ghi, hlo, hhi, tv, xe, xo, xe1, xo1, bhi, 16u);
+            next_x(blk + 1u, xe2, xo2);
+            const uint32_t b1 = stage_b_block<1, false>(T, glo, ghi, hlo, hhi, tv, xe1, xo1, xe2, xo2, bhi, 16u);
+            put(blk >> 1, (__brev(b0) >> 16) | (__brev(b1) & 0xFFFF0000u));  // bit t <=> step t
+            next_x(blk + 2u, xe3, xo3);
+            const uint32_t b2 = stage_b_block<2, false>(T, glo, ghi, hlo, hhi, tv, xe2, xo2, xe3, xo3, bhi, 16u);
+            next_x(blk + 3u, xe4, xo4);
+            const uint32_t b3 = stage_b_block<3, false>(T, glo, ghi, hlo, hhi, tv, xe3, xo3, xe4, xo4, bhi, 16u);
+            put((blk >> 1) + 1u, (__brev(b2) >> 16) | (__brev(b3) & 0xFFFF0000u));
+            xe = xe4;
+            xo = xo4;
+        }
+        // the last, incomplete group: up to four blocks, the last of them possibly partial
+        uint32_t word = 0;  // the 32-step flag word being filled (two 16-step blocks)
+        for (; blk < nb; ++blk) {
             uint32_t xe_n, xo_n;
-            {
-                const uint32_t no = S.codes[o_dw + blk + 2u], ni = S.codes[i_dw + blk + 2u];
-                const uint32_t ow = __builtin_amdgcn_alignbit(no, prev_o, o_sh), iw = __builtin_amdgcn_alignbit(ni, prev_i, i_sh);
-                prev_o = no;
-                prev_i = ni;
-                xe_n = mk_xe(ow, iw);
-                xo_n = mk_xo(ow, iw);
-            }
+            next_x(blk, xe_n, xo_n);
             const uint32_t lim = lc - 16u * blk;  // steps left (wave-uniform): the last block may be partial
             uint32_t fbits;
             if (lim >= 16u) {
@@ -474,10 +507,15 @@ __device__ __forceinline__ void seed_stage_b(const SeedTables &T, SeedLds &S, co
                     default: fbits = stage_b_block<3, true>(T, glo, ghi, hlo, hhi, tv, xe, xo, xe_n, xo_n, bhi, lim); break;
                 }
             }
-            fl[blk] = (uint16_t)(__brev(fbits) >> 16);  // bit t <=> step t
+            if (blk & 1u) {
+                put(blk >> 1, word | (__brev(fbits) & 0xFFFF0000u));
+            } else {
+                word = __brev(fbits) >> 16;
+            }
             xe = xe_n;
             xo = xo_n;
         }
+        if (nb & 1u) put(nb >> 1, word);
     }
 }
 
@@ -539,20 +577,18 @@ __device__ __forceinline__ uint32_t seed_rawpos_batch(const SeedLds &S, uint32_t
 __device__ __forceinline__ uint32_t seed_stage_r(const SeedTables &T, SeedLds &S, const DevParams &P, uint32_t w_eff,
                                                  uint32_t n_blocks, uint32_t n_codes, uint32_t raw_base, uint32_t carry_n,
                                                  unsigned long long *__restrict__ mz_hash, uint32_t *__restrict__ mz_pos, uint32_t out_base,
-                                                 uint32_t out_cap, bool &inexact) {
+                                                 uint32_t out_cap, bool &inexact, FlagWords &f) {
     const uint32_t lane = lane_id();
     const uint32_t lc = (w_eff + 63u) >> 6;
-    // this lane's flags as 32-step words, masked to its real windows (steps [0, nv))
-    constexpr uint32_t NW = SD_FLAG_BLKS / 2u;
-    const uint32_t *fw = reinterpret_cast<const uint32_t *>(&S.flags[lane * (SD_FLAG_BLKS / 4u)]);
+    // this lane's flags (stage B left them in f[]) as 32-step words, masked to its real windows (steps [0, nv))
+    constexpr uint32_t NW = SD_FLAG_WORDS;
     const uint32_t s0 = lane * lc;
     const uint32_t nv = s0 < w_eff ? (w_eff - s0 < lc ? w_eff - s0 : lc) : 0u;
-    uint32_t f[NW];
     uint32_t my_count = 0;
 #pragma unroll
     for (uint32_t w = 0; w < NW; ++w) {
         const uint32_t k = nv > 32u * w ? nv - 32u * w : 0u;
-        f[w] = fw[w] & (k >= 32u ? ~0u : ((1u << k) - 1u));
+        f[w] &= (k >= 32u ? ~0u : ((1u << k) - 1u));
         my_count += (uint32_t)__popc(f[w]);
     }
     const uint32_t incl = wave_incl_scan_u32(my_count);
@@ -622,13 +658,19 @@ __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict
         const bool more = raw_end < len;
         if (STOP != 1 && n_codes >= P.l) {
             const uint32_t w_eff = n_codes - P.l + 1u;
-            seed_stage_b(T, S, P, w_eff);
+            FlagWords flags;
+            seed_stage_b(T, S, P, w_eff, flags);
             mq_clk(1);
             if (STOP != 2) {
                 bool inexact = false;
-                n_out += seed_stage_r(T, S, P, w_eff, n_blocks, n_codes, raw0, carry_n, mz_hash, mz_pos, n_out, out_cap, inexact);
+                n_out += seed_stage_r(T, S, P, w_eff, n_blocks, n_codes, raw0, carry_n, mz_hash, mz_pos, n_out, out_cap, inexact, flags);
                 mq_clk(2);
                 if (inexact) return SD_NOT_FAST;
+            } else {  // diagnostic build: keep stage B alive without stage R
+                uint32_t any = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < SD_FLAG_WORDS; ++w) any += flags[w];
+                if (any == 0xFFFFFFF1u && out_cap) mz_pos[0] = any;
             }
         }
         if (more) {

@@ -223,3 +223,35 @@ def test_feeder_gzip_members_cut_anywhere(tool, tmp_path):
         for chunk, th in ((64, 4), (3000, 2), (1 << 26, 3)):
             assert _dump(tool, p, fastq, chunk, th) == want, (fastq, chunk)
             assert _dump(tool, p, fastq, chunk, th, {"MQ_FEEDER_NO_LIBDEFLATE": "1"}) == want
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+def test_feeder_last_quality_line_starting_with_at(tool, tmp_path, crlf):
+    """A chunk boundary inside the LAST record of a FASTQ file whose quality line begins with '@': at the end of the input an '@'
+    line followed by fewer than three further lines starts no record (it used to come out as a phantom read of length 0 with the
+    quality string as its id).  Raw (pread), lean (mapped), plain gzip (both readers) and BGZF."""
+    rng = random.Random(77 + crlf)
+    nl = "\r\n" if crlf else "\n"
+    recs, out = [], []
+    for i in range(40):
+        L = rng.choice([30, 70, 400])
+        seq = "".join(rng.choice("ACGT") for _ in range(L))
+        q = "@" + "".join(rng.choice("@+IJ") for _ in range(L - 1))  # every quality line begins with '@'
+        recs.append(("q%d" % i, seq))
+        out.append("@q%d%s%s%s+%s%s%s" % (i, nl, seq, nl, nl, q, nl))
+    want = [[a, str(len(b)), b] for a, b in recs]
+    for trailing in (True, False):
+        text = "".join(out) if trailing else "".join(out).rstrip("\r\n")
+        raw, gz, bg = tmp_path / "t.fq", tmp_path / "t.fq.gz", tmp_path / "b.fq.gz"
+        raw.write_text(text, newline="")
+        with gzip.open(gz, "wt", newline="") as f:
+            f.write(text)
+        bg.write_bytes(_bgzf(text.encode(), block=500))
+        for chunk in (64, 100, 333, 1000, 70000):
+            for th in (1, 3):
+                assert _dump(tool, raw, True, chunk, th) == want, ("lean", chunk, th, trailing)
+                assert _dump(tool, raw, True, chunk, th, {"MQ_FEEDER_NO_LEAN_FASTQ": "1"}) == want, ("raw", chunk, th, trailing)
+                assert _dump(tool, gz, True, chunk, th) == want, ("gz", chunk, th, trailing)
+                assert _dump(tool, gz, True, chunk, th, {"MQ_GZ_WHOLE_LIMIT": "0"}) == want, ("gz-stream", chunk, th, trailing)
+                assert _dump(tool, gz, True, chunk, th, {"MQ_FEEDER_NO_LIBDEFLATE": "1"}) == want, ("gz-zlib", chunk, th, trailing)
+                assert _dump(tool, bg, True, chunk, th) == want, ("bgzf", chunk, th, trailing)

@@ -3,7 +3,7 @@
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -Wno-align-mismatch -mllvm -amdgpu-atomic-optimizer-strategy=None -gline-tables-only "$@" -S --cuda-device-only -o /tmp/spills.s $ROOT/mapquik_amd/csrc/mq_capi.hip 2>/dev/null
 python3 - <<'PY'
-import re
+import re,os
 L=open('/tmp/spills.s').read().split('\n')
 files={}
 k=None; loc=None; depth=0; out={}
@@ -16,7 +16,7 @@ for l in L:
     m=re.search(r'Depth=(\d+)',l)
     if m and l.startswith('.LBB'): depth=int(m.group(1))
     elif l.startswith('.LBB'): depth=0
-    if 'scratch_' in l and k and 'map_kernelILi64ELb0' in k:
+    if 'scratch_' in l and k and os.environ.get("SPILL_KERNEL","map_kernelILi64ELb0") in k:
         kind='store' if 'store' in l else 'load'
         key=(loc,depth,kind)
         out[key]=out.get(key,0)+1
