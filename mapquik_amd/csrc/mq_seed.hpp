@@ -13,7 +13,7 @@
 //            rotation sits in the ds_read_b128's immediate offset), four look-ups in flight.
 //            The per-step test is min(fh.hi, rh.hi) <= hi(bound) (one v_alignbit per strand to un-rotate the high word); its
 //            outcome is shifted into a per-lane flag word (v_cmp + v_addc: no branch, no scalar work, nothing stored); the
-//            flag words stay in registers (one per 32 steps) until stage R has listed them.
+//            flag words go to LDS once per 32 steps, word-major (conflict-free).
 //   stage R  every lane lists the windows of its own candidates at their places (prefix sum of the lanes' counts); then lane =
 //            candidate, in position order: the window's two hashes computed again from the code stream, four bases per look-up
 //            (256-entry table; l = 31: all eight look-ups in flight at once); exact 64-bit test; raw position = the block
@@ -35,11 +35,7 @@ constexpr uint32_t SD_TILE_RAW = SD_SR_RAW * SD_MAX_SR;    // 12288
 constexpr uint32_t SD_BLOCKS = SD_TILE_RAW / 64;           // 64-base blocks per tile
 constexpr uint32_t SD_CODES_MAX = SD_TILE_RAW + MAX_L - 1; // codes of one tile incl. the carried l-1 (no compression at all)
 constexpr uint32_t SD_LC_MAX = (SD_CODES_MAX + 63) / 64;   // windows per lane
-constexpr uint32_t SD_FLAG_WORDS = (SD_LC_MAX + 31) / 32;  // 32-step flag words per lane (kept in registers between stages B and R)
-static_assert(SD_FLAG_WORDS <= 16, "flag words per lane");
-// the flag words as one register tuple: stage B writes word w with w wave-uniform but not a compile-time constant (an indexed
-// register move, s_set_gpr_idx + v_mov), stage R reads them with constant indices
-typedef uint32_t FlagWords __attribute__((ext_vector_type(SD_FLAG_WORDS <= 4 ? 4 : SD_FLAG_WORDS <= 8 ? 8 : 16)));
+constexpr uint32_t SD_FLAG_WORDS = (SD_LC_MAX + 31) / 32;  // 32-step flag words per lane
 constexpr uint32_t SD_CODES_DW = 4 * ((63 * SD_LC_MAX + 16 * ((SD_LC_MAX + 15) / 16) + MAX_L + 32) / 64 + 1);  // packed 2-bit codes + zero read-ahead padding (whole uint4s)
 static_assert((63 * SD_LC_MAX + 16 * ((SD_LC_MAX + 15) / 16) + MAX_L + 32) / 16 < SD_CODES_DW, "code stream read-ahead padding");
 #ifndef MQ_SD_OWNER_CAP
@@ -70,6 +66,8 @@ struct SeedLds {
     uint32_t codes[SD_CODES_DW];                 // the tile's 2-bit code stream (carried l-1 codes first)
     unsigned long long heads[SD_BLOCKS];         // bit b of heads[k]: raw base 64k + b of the tile is a run head
     uint16_t cnt[SD_BLOCKS + 4];                 // index in the code stream of block k's first run head; cnt[n_blocks] = n_codes
+    uint32_t flagw[SD_FLAG_WORDS * 64];          // stage B -> stage R: bit t of flagw[w * 64 + L] <=> step 32 w + t of lane L is a candidate (word-major:
+                                                 // a wave's write or read of one word index touches 64 consecutive dwords, conflict-free)
     uint32_t carry_codes[4];                     // codes carried into the next tile (<= 63)
     uint32_t carry_pos[64];                      // their raw positions
     uint8_t block_of[SD_CODES_MAX / 64 + 3];     // block_of[c]: the 64-base block that holds code 64 c (the walk to a code's block starts there)
@@ -421,16 +419,15 @@ __device__ __forceinline__ uint32_t stage_b_block(const SeedTables &T, uint32_t 
 }
 
 // Rolls ntHash over windows [0, w_eff) of the tile's code stream; lane L owns windows [L*lc, (L+1)*lc), lc = ceil(w_eff/64).
-// The outcome of every step's high-word test goes into the lane's flag words f[] (bit t of f[w] <=> step 32 w + t is a
-// candidate); nothing else is kept (stage R computes a candidate's hashes again) and the flags never leave the registers.
+// The outcome of every step's high-word test goes into the lane's flag words (S.flagw, one 32-step word per store); nothing
+// else is kept (stage R computes a candidate's hashes again).
 // Steps past the last window (only the last active lane has them) may set bits too: stage R masks them.
-__device__ __forceinline__ void seed_stage_b(const SeedTables &T, SeedLds &S, const DevParams &P, uint32_t w_eff, FlagWords &f) {
+__device__ __forceinline__ void seed_stage_b(const SeedTables &T, SeedLds &S, const DevParams &P, uint32_t w_eff) {
     const uint32_t lane = lane_id();
     const uint32_t l = P.l;
     const uint32_t lc = (w_eff + 63u) >> 6;
     const uint32_t s0 = lane * lc;
     const uint32_t bhi = (uint32_t)(P.bound >> 32);
-    f = 0u;
     if (s0 < w_eff) {  // lanes beyond the last window sit out (exec-masked)
         const Hash2 h0 = window_hash(T, S, l, s0);  // the lane's first window: G_0 = F_0, H_0 = R_0
         uint32_t glo = h0.flo, ghi = h0.fhi, hlo = h0.rlo, hhi = h0.rhi;
@@ -464,8 +461,8 @@ __device__ __forceinline__ void seed_stage_b(const SeedTables &T, SeedLds &S, co
             xe_n = mk_xe(ow, iw);
             xo_n = mk_xo(ow, iw);
         };
-        // flag word w of the lane (w is wave-uniform: a scalar compare picks the register)
-        auto put = [&](uint32_t w_at, uint32_t v) { f[w_at] = v; };
+        // flag word w of the lane (words a lane never writes are never looked at: stage R masks by the lane's window count)
+        auto put = [&](uint32_t w_at, uint32_t v) { S.flagw[w_at * 64u + lane] = v; };
         // Whole 64-step groups: the four rotation phases of the frame back to back in straight-line code, so that the hash state, the
         // ring of table values and the code words stay where they are (a loop over single blocks with a switch over the phase
         // costs ~14 register moves per block at the merge points).
@@ -577,14 +574,18 @@ __device__ __forceinline__ uint32_t seed_rawpos_batch(const SeedLds &S, uint32_t
 __device__ __forceinline__ uint32_t seed_stage_r(const SeedTables &T, SeedLds &S, const DevParams &P, uint32_t w_eff,
                                                  uint32_t n_blocks, uint32_t n_codes, uint32_t raw_base, uint32_t carry_n,
                                                  unsigned long long *__restrict__ mz_hash, uint32_t *__restrict__ mz_pos, uint32_t out_base,
-                                                 uint32_t out_cap, bool &inexact, FlagWords &f) {
+                                                 uint32_t out_cap, bool &inexact) {
     const uint32_t lane = lane_id();
     const uint32_t lc = (w_eff + 63u) >> 6;
-    // this lane's flags (stage B left them in f[]) as 32-step words, masked to its real windows (steps [0, nv))
+    // this lane's flags as 32-step words, masked to its real windows (steps [0, nv)): words and lanes stage B did not write hold
+    // stale bits, all of them beyond nv
     constexpr uint32_t NW = SD_FLAG_WORDS;
     const uint32_t s0 = lane * lc;
     const uint32_t nv = s0 < w_eff ? (w_eff - s0 < lc ? w_eff - s0 : lc) : 0u;
+    uint32_t f[NW];
     uint32_t my_count = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < NW; ++w) f[w] = S.flagw[w * 64u + lane];
 #pragma unroll
     for (uint32_t w = 0; w < NW; ++w) {
         const uint32_t k = nv > 32u * w ? nv - 32u * w : 0u;
@@ -658,19 +659,13 @@ __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict
         const bool more = raw_end < len;
         if (STOP != 1 && n_codes >= P.l) {
             const uint32_t w_eff = n_codes - P.l + 1u;
-            FlagWords flags;
-            seed_stage_b(T, S, P, w_eff, flags);
+            seed_stage_b(T, S, P, w_eff);
             mq_clk(1);
             if (STOP != 2) {
                 bool inexact = false;
-                n_out += seed_stage_r(T, S, P, w_eff, n_blocks, n_codes, raw0, carry_n, mz_hash, mz_pos, n_out, out_cap, inexact, flags);
+                n_out += seed_stage_r(T, S, P, w_eff, n_blocks, n_codes, raw0, carry_n, mz_hash, mz_pos, n_out, out_cap, inexact);
                 mq_clk(2);
                 if (inexact) return SD_NOT_FAST;
-            } else {  // diagnostic build: keep stage B alive without stage R
-                uint32_t any = 0;
-#pragma unroll
-                for (uint32_t w = 0; w < SD_FLAG_WORDS; ++w) any += flags[w];
-                if (any == 0xFFFFFFF1u && out_cap) mz_pos[0] = any;
             }
         }
         if (more) {
