@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--e2e-fastq-reads", type=int, default=786432,
                     help="reads of the FASTQ + -k 7 leg (BASELINE config 4's shape, experiments/table1.sh:50-55): 786,432 reads = 18.5 Gbases; 0 = skip")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the kernel-only legs of the other configurations (human-like, maize-like, -k 7)")
+    ap.add_argument("--config-reads", type=int, default=0, help="reads per step of the kernel-only legs (0 = --reads)")
+    ap.add_argument("--config-sample-reads", type=int, default=8192, help="reads of each leg that the C oracle maps for the column-by-column check")
     return ap.parse_args()
 
 
@@ -126,7 +129,7 @@ def write_reference(genome, ctg_off, ctg_names, path):
             f.write(b"\n")
 
 
-def measure_file_to_paf(ref, reads, n_reads, threads, workdir, fastq=False, extra_args=(), compress=None):
+def measure_file_to_paf(ref, reads, n_reads, threads, workdir, fastq=False, extra_args=(), compress=None, env=None):
     """End to end through the native driver (mapquik_amd/lib/mapquik): reference FASTA + reads file on disk -> <prefix>.paf.
     fastq: the reads as a FASTQ file; compress="gz": as a plain gzip stream.  Three runs: one to bring the files into the page cache,
     the driver's default = the strict run (nothing of the reads is touched before the index is ready; also reported under the
@@ -149,10 +152,12 @@ def measure_file_to_paf(ref, reads, n_reads, threads, workdir, fastq=False, extr
            "args": " ".join(extra_args)}
     prefix = os.path.join(workdir, "e2e")
 
+    base_env = dict(os.environ, **(env or {}))
+
     def run(env):
         t0 = time.perf_counter()
         r = subprocess.run([exe, rd, "--reference", ref, "-p", prefix, "--threads", str(threads)] + list(extra_args),
-                           capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+                           capture_output=True, text=True, timeout=900, env=dict(base_env, **env))
         wall = time.perf_counter() - t0
         if r.returncode != 0:
             raise RuntimeError((r.stderr or r.stdout)[-300:])
@@ -200,6 +205,98 @@ def measure_index_file(mq, ix, P, device, workdir):
     return dict(file_bytes=size, save_s=round(t_save, 3), load_s=round(t_load, 3), stats_identical_after_load=bool(same))
 
 
+def expected_kminmers(n_bases, P):
+    """What Index::new sizes its map for (src/index.rs:83 hardcodes CHM13's 39,821,990): canonical selection keeps 1 - (1 - d)^2 of the
+    l-mers, homopolymer compression about three quarters of the bases."""
+    d = min(1.0, max(0.0, P.density))
+    return int(n_bases * (1.0 - (1.0 - d) ** 2) * (0.75 if P.use_hpc else 1.0)) + 1
+
+
+def build_index_device(mq, torch, dev, local_rank, P, genome, ctg_off, ctg_names, ix=None):
+    """Reference contigs to the device first (one copy of the genome, timed by itself), then the index build proper from
+    device-resident contigs: mq_index_add_ref_device per contig + mq_index_finalize (mers::ref_extract + Index::add_with_mer +
+    into_read_only, src/mers.rs:15-38, src/index.rs:94-116).  Returns (index, per-contig k-min-mer counts, unique, upload s, build s)."""
+    t0 = time.time()
+    d_genome = torch.from_numpy(genome).to(dev)
+    torch.cuda.synchronize()
+    t_up = time.time() - t0
+    t0 = time.time()
+    if ix is None:  # (the main configuration creates its index -- and reserves its table -- before the genome exists)
+        ix = mq.Index(P, device=local_rank)
+        ix.reserve_table(expected_kminmers(genome.size, P))
+    per_ref = []
+    for r in range(len(ctg_names)):
+        a, b = int(ctg_off[r]), int(ctg_off[r + 1])
+        per_ref.append(ix.add_ref_device(r, ctg_names[r], d_genome.data_ptr() + a, b - a))
+    n_unique = ix.finalize()
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+    del d_genome
+    return ix, per_ref, n_unique, t_up, t_build
+
+
+def oracle_sample_check(mq, O, genome, ctg_off, ctg_names, po, ncpu, reads, hits, ns):
+    """The first ns reads through the C oracle (index built with all granted threads): are status and every numeric PAF column
+    of the GPU's hits the oracle's?  Returns (identical, oracle unique k-min-mers)."""
+    ox = O.Index()
+    ox.build_mt(genome, ctg_off, ctg_names, po, ncpu)
+    offs = reads["offsets"]
+    ns = min(ns, offs.size - 1)
+    want = ox.map_batch(reads["bases"][:int(offs[ns])], offs[:ns + 1], po, threads=ncpu)
+    m = want["mapped"] != 0
+    same = bool(np.array_equal(hits["status"][:ns] == 1, m)) and all(
+        np.array_equal(mq.hit_column(hits[:ns], a)[m], want[a][m].astype(np.uint64))
+        for a in ("ref_id", "rc", "mapq", "q_start", "q_end", "r_start", "r_end", "score"))
+    uniq = int(ox.count())
+    del ox
+    return same, uniq
+
+
+def kernel_leg(mq, sim, O, torch, dev, local_rank, P, po, genome, ctg_off, ctg_names, reads, steps, warmup, ncpu, sample_reads, workload):
+    """One kernel-only leg of another configuration: index on the GPU, the batch resident in HBM, `steps` timed launches of
+    map_kernel, mapeval counts over the batch, the oracle's columns on a sample."""
+    ix, _, n_unique, _, t_build = build_index_device(mq, torch, dev, local_rank, P, genome, ctg_off, ctg_names)
+    offs = reads["offsets"]
+    n, total_bases = offs.size - 1, int(offs[-1])
+    d_bases = torch.from_numpy(reads["bases"]).to(dev)
+    d_offs = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_out = torch.zeros(n * mq.hit_dtype.itemsize, dtype=torch.uint8, device=dev)
+    ix.reserve(n, total_bases)
+    stream = torch.cuda.current_stream(dev)
+    for _ in range(warmup):
+        ix.map_batch_device(d_bases.data_ptr(), d_offs.data_ptr(), n, total_bases, d_out.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(steps):
+        ix.map_batch_device(d_bases.data_ptr(), d_offs.data_ptr(), n, total_bases, d_out.data_ptr(), stream.cuda_stream)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    hits = np.frombuffer(d_out.cpu().numpy().tobytes(), dtype=mq.hit_dtype)
+    truth = {k: v for k, v in reads.items() if k not in ("bases", "offsets")}
+    pafs = {"mapped": (hits["status"] == 1).astype(np.uint32)}
+    for a_ in ("ref_id", "rc", "mapq", "r_start", "r_end"):
+        pafs[a_] = hits[a_]
+    n_m, n_q60, n_q60_wrong = sim.mapeval(truth, pafs)
+    n_fast, n_general = ix.last_map_path_counts()
+    same, ouniq = oracle_sample_check(mq, O, genome, ctg_off, ctg_names, po, ncpu, reads, hits, sample_reads)
+    st = ix.stats()
+    ix.close()
+    del d_bases, d_offs, d_out
+    return dict(workload=workload, value=round(total_bases / (ms * 1e-3) / 1e9, 3), unit="Gbases/s", ms_per_launch=round(ms, 4), steps=steps,
+                reads_per_step=n, bases_per_step=total_bases, kminmers_per_step=int(hits["n_kminmers"].astype(np.int64).sum()),
+                mapped_frac=round(n_m / max(n, 1), 4), q60=n_q60, q60_wrong=n_q60_wrong, overflow_reads=int((hits["status"] == 2).sum()),
+                general_path_reads=int(n_general), index_unique_kminmers=int(n_unique), index_keys=int(st["n_keys"]), index_build_s=round(t_build, 3),
+                paf_columns_identical_to_oracle=same, oracle_sample_reads=min(sample_reads, n), unique_kminmers_equal_oracle=bool(ouniq == n_unique))
+
+
+def fake_ranks():
+    """Test hook (tests/test_bench_ranks.py): MQ_BENCH_FAKE_RANKS=1 runs every rank on device 0 with the gloo backend and the two
+    all-reduces on CPU tensors, so that the world > 1 branch executes on a one-GPU box."""
+    return os.environ.get("MQ_BENCH_FAKE_RANKS", "") not in ("", "0")
+
+
 def main():
     args = parse()
     import torch
@@ -214,11 +311,18 @@ def main():
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the mapquik HIP path has no CPU fallback")
+    fake = fake_ranks()
+    if fake:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = torch.device("cpu") if fake else dev  # where the tensors of the two all-reduces live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if fake:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     import mapquik_amd as mq
     from tools import sim
@@ -227,9 +331,13 @@ def main():
     threads = max(1, ncpu // world)
     P = mq.Params(k=args.k, l=args.l, density=args.density)  # defaults k=5 l=31 d=0.01, HPC on, c=4 s=11 g=2000 (src/main.rs:174-188)
 
+    # ---- Index::new with its capacity (src/index.rs:78-83): the table is allocated and cleared in the background from here on
+    lens = [max(40, int(x * args.genome_scale)) for x in sim.CHM13_LIKE]
+    ix0 = mq.Index(P, device=local_rank)
+    ix0.reserve_table(expected_kminmers(sum(lens), P))
+
     # ---- genome (same on every rank: the index is replicated)
     t0 = time.time()
-    lens = [max(40, int(x * args.genome_scale)) for x in sim.CHM13_LIKE]
     if args.genome_preset == "human-like":
         genome, ctg_off, ctg_names = sim.make_genome(lens, seed=args.seed, threads=threads, **sim.HUMAN_LIKE)
     else:
@@ -237,19 +345,18 @@ def main():
                                                      tandem_frac=args.tandem_frac, div=args.repeat_div)
     t_genome = time.time() - t0
 
-    # ---- index on this rank's GPU (Index::add_with_mer + into_read_only on device)
-    t0 = time.time()
-    ix = mq.Index(P, device=local_rank)
-    per_ref = []
-    for r in range(len(lens)):
-        seg = genome[int(ctg_off[r]):int(ctg_off[r + 1])]
-        d_seg = torch.from_numpy(seg).to(dev)
-        per_ref.append(ix.add_ref_device(r, ctg_names[r], d_seg.data_ptr(), seg.size))
-        del d_seg
-    n_unique = ix.finalize()
-    torch.cuda.synchronize()
-    t_index = time.time() - t0
+    # ---- index on this rank's GPU (Index::add_with_mer + into_read_only on device), from device-resident contigs
+    ix, per_ref, n_unique, t_upload, t_index = build_index_device(mq, torch, dev, local_rank, P, genome, ctg_off, ctg_names, ix=ix0)
     st = ix.stats()
+    # algorithmic bytes of the build = L_ref * b_in + n_kmm * S_slot * 2 (every reference k-min-mer's slot written and read back)
+    ib_bytes = int(sum(lens)) * 1 + int(sum(per_ref)) * st["slot_bytes"] * 2
+    index_build = dict(ms=round(t_index * 1e3, 2), algorithmic_bytes=ib_bytes, unit="GB/s", achieved=round(ib_bytes / max(t_index, 1e-9) / 1e9, 2),
+                       peak=8000.0, frac=round(ib_bytes / max(t_index, 1e-9) / 1e9 / 8000.0, 5), reference_bases=int(sum(lens)),
+                       reference_kminmers=int(sum(per_ref)), unique_kminmers=int(n_unique),
+                       note="wall time of mq_index_add_ref_device x %d contigs + mq_index_finalize from device-resident contigs, including whatever "
+                            "was left to wait for of the %.1f GB table's allocation (requested at Index creation like the reference's "
+                            "DashMap::with_capacity, src/index.rs:83; fresh device memory costs ~30 ms per GB here); the contigs' upload (%.2f s) "
+                            "is not in it" % (len(lens), st["table_bytes"] / 1e9, t_upload))
 
     # ---- this rank's batch of reads, resident in HBM
     t0 = time.time()
@@ -301,15 +408,21 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tb = torch.tensor([float(total_bases), float(n)], dtype=torch.float64, device=dev)
+        tb = torch.tensor([float(total_bases), float(n)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         all_bases, all_reads = float(tb[0].item()), float(tb[1].item())
+        mine = torch.tensor([elapsed_local, float(total_bases)], dtype=torch.float64, device=red_dev)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = [round(float(g[1].item()) * args.steps / float(g[0].item()) / 1e9, 3) for g in gathered]
     else:
         all_bases, all_reads = float(total_bases), float(n)
+        per_rank = None
     if strong:  # the kernel's own launch time for the roofline: one resident launch of this rank's shard, outside the timed region
         pipe.close()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -324,6 +437,8 @@ def main():
     avg_kern_s = float(np.mean(kern_ms)) / 1e3
 
     hits = np.frombuffer(d_out.cpu().numpy().tobytes(), dtype=mq.hit_dtype)
+    if os.environ.get("MQ_BENCH_DUMP_HITS"):  # test hook: this rank's hits (strong scaling: of its shard of the one read set)
+        np.save(os.path.join(os.environ["MQ_BENCH_DUMP_HITS"], "hits_rank%d_of_%d.npy" % (rank, world)), hits.view(np.uint8))
     n_kmm = int(hits["n_kminmers"].astype(np.int64).sum())
     n_mapped = int((hits["status"] == 1).sum())
     n_over = int((hits["status"] == 2).sum())
@@ -353,6 +468,29 @@ def main():
     roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=8000.0, unit="GB/s", frac=round(achieved / 8000.0, 4),
                     traffic=traffic, traffic_taken_at_commit=traffic_commit, kernel="map_kernel", avg_launch_ms=round(avg_kern_s * 1e3, 4),
                     algorithmic_bytes_per_launch=int(alg_bytes), mean_probes_per_lookup=round(p_bar, 4))
+
+    # SURVEY.md 8(d)'s second bound: vector-instruction issue.  wave-instructions per launch and the shader clock come from the PMC
+    # passes of the same workload (profiles/pmc_issue.json, tools/issue_json.py); the launch time is this run's; the ceiling is
+    # what a SIMD issues at map_kernel's occupancy (four waves per SIMD as two 8-wave workgroups per CU) on the instruction mix
+    # of stage B in the microbenchmark (profiles/r04_valu_occ.txt / r04_valu_enc.txt).
+    ipath = os.path.join(ROOT, "profiles", "pmc_issue.json")
+    if os.path.exists(ipath):
+        try:
+            ij = json.load(open(ipath))
+            if ij.get("reads") == n and abs(ij.get("genome_scale", -1) - args.genome_scale) < 1e-9 and ij.get("k") == args.k and not strong:
+                n_simd = int(ij["n_simd"])
+                cyc = avg_kern_s * float(ij["shader_clock_mhz"]) * 1e6
+                cpi = cyc * n_simd / float(ij["wave_instructions_per_launch"])
+                roofline["secondary"] = dict(bound="valu_issue", wave_instructions_per_launch=int(ij["wave_instructions_per_launch"]),
+                                             valu=int(ij["valu"]), salu=int(ij["salu"]), lds=int(ij["lds"]), vmem=int(ij["vmem"]), n_simd=n_simd,
+                                             shader_clock_mhz=ij["shader_clock_mhz"], cycles_per_instruction=round(cpi, 3),
+                                             ceiling_cycles_per_instruction=ij["ceiling_cycles_per_instruction"],
+                                             frac=round(float(ij["ceiling_cycles_per_instruction"]) / cpi, 4), waves_per_simd=ij.get("waves_per_simd"),
+                                             counters_taken_at_commit=ij.get("commit"), ceiling_source=ij.get("ceiling_source"),
+                                             note="cycles per wave-instruction per SIMD = this run's launch time x measured shader clock x SIMDs / "
+                                                  "instructions counted by rocprofv3 --pmc on the same workload; frac = ceiling / achieved")
+        except Exception as ex:  # noqa: BLE001
+            roofline["secondary"] = {"error": repr(ex)[:200]}
 
     # ---- accuracy on the whole batch (BASELINE metric: "Q60 mapeval parity"): paftools-mapeval-style counts
     truth = {k: v for k, v in reads.items() if k not in ("bases", "offsets")}
@@ -407,6 +545,50 @@ def main():
                                          "run on its authors' machine, Rust path, not measured here)"))
         del ox
 
+    # ---- kernel-only legs of the other configurations (rank 0, N=1): a human-like repeat landscape, a maize-like repetitive genome
+    # (BASELINE config 5, experiments/simulate_maize.sh:9) and -k 7 (BASELINE config 4, experiments/table1.sh:50)
+    configs = None
+    if rank == 0 and world == 1 and not args.no_configs and not strong:
+        from oracle import oracle as O
+        configs = {}
+        nr = args.config_reads or args.reads
+        lsteps, lwarm = max(3, min(args.steps, 10)), 1
+
+        def run_leg(name, fn):
+            t0 = time.time()
+            try:
+                configs[name] = fn()
+                configs[name]["leg_wall_s"] = round(time.time() - t0, 1)
+            except Exception as ex:  # noqa: BLE001
+                configs[name] = {"error": repr(ex)[:300]}
+
+        def leg_k7():
+            P7, po7 = mq.Params(k=7, l=31, density=0.01), O.params(k=7, l=31, density=0.01)
+            rd = reads if nr >= n else {k: (v[:nr] if k not in ("bases", "offsets") else v) for k, v in reads.items()}
+            if nr < n:
+                rd["offsets"] = offs[:nr + 1]
+                rd["bases"] = reads["bases"][:int(offs[nr])]
+            return kernel_leg(mq, sim, O, torch, dev, local_rank, P7, po7, genome, ctg_off, ctg_names, rd, lsteps, lwarm, ncpu, args.config_sample_reads,
+                              "the step batch's genome and reads at -k 7 -l 31 -d 0.01 (BASELINE config 4's parameters, experiments/table1.sh:50)")
+
+        def leg_genome(lens_, kw, seed, workload):
+            g, co, cn = sim.make_genome(lens_, seed=seed, threads=threads, **kw)
+            rd = sim.make_reads(g, co, nr, seed=seed + 1, threads=threads)
+            return kernel_leg(mq, sim, O, torch, dev, local_rank, P, O.params(k=args.k, l=args.l, density=args.density), g, co, cn, rd, lsteps, lwarm, ncpu,
+                              args.config_sample_reads, workload)
+
+        if args.k != 7:
+            run_leg("k7", leg_k7)
+        if args.genome_preset != "human-like":
+            run_leg("human_like", lambda: leg_genome(lens, sim.HUMAN_LIKE, args.seed + 31,
+                                                     "CHM13-sized genome (scale %.3g) with tools/sim.py HUMAN_LIKE repeats (6%% satellite arrays at 99.8%% identity, 5%% segmental "
+                                                     "duplications, young interspersed copies) x pbsim-like HiFi reads; k=%d l=%d d=%g" % (args.genome_scale, args.k, args.l, args.density)))
+        run_leg("maize_like", lambda: leg_genome([max(40, int(x * args.genome_scale)) for x in sim.MAIZE_LIKE],
+                                                 dict(family_frac=1.9, n_families=400, family_div=(0.005, 0.025), tandem_frac=0.02, n_runs=300), args.seed + 57,
+                                                 "maize-B73-shaped genome (10 contigs, 2.13 Gbp x scale %.3g), ~85%% of the bases in 400 transposon-like families "
+                                                 "(copies 1-5%% apart), 300 runs of N, x pbsim-like HiFi reads (BASELINE config 5, experiments/simulate_maize.sh:9); "
+                                                 "k=%d l=%d d=%g" % (args.genome_scale, args.k, args.l, args.density)))
+
     # ---- end to end (rank 0, N=1): host buffers -> hits through three stream slots, and FASTA files -> PAF through the native driver
     e2e = None
     if rank == 0 and world == 1 and not args.no_e2e:
@@ -429,8 +611,12 @@ def main():
                     e2e[name] = {"error": repr(ex)[:300]}
 
             # the step batch as a FASTA file, at the bench's own parameters
-            leg("file_to_paf", reads=reads, n_reads=args.e2e_file_reads, threads=ncpu, workdir=wd, extra_args=kargs)
+            # (four host threads: the records are found on the device, the reader threads only cut the mapped file at record starts)
+            leg("file_to_paf", reads=reads, n_reads=args.e2e_file_reads, threads=min(4, ncpu), workdir=wd, extra_args=kargs)
             e2e["file_to_paf_gbases_s"] = e2e["file_to_paf"].get("gbases_s")
+            leg("file_to_paf_8_threads", reads=reads, n_reads=args.e2e_file_reads, threads=min(8, ncpu), workdir=wd, extra_args=kargs)
+            # the same with every chunk read and parsed by the reader threads (earlier rounds' path), all granted threads
+            leg("file_to_paf_host_parse", reads=reads, n_reads=args.e2e_file_reads, threads=ncpu, workdir=wd, extra_args=kargs, env={"MQ_DRIVER_HOST_PARSE": "1"})
             # a plain gzip stream of a quarter of it (get_reader's .gz branch, src/main.rs:60-75)
             leg("gz_to_paf", reads=reads, n_reads=max(1, args.e2e_file_reads // 4), threads=ncpu, workdir=wd, extra_args=kargs, compress="gz")
             try:
@@ -468,9 +654,12 @@ def main():
             "data": "synthetic",
             "config": {
                 "genome_preset": args.genome_preset,
-                "workload": "CHM13v2.0-like synthetic genome (25 contigs, %.3f Gbp, scale %.3g, %g%% planted repeats) "
+                "workload": "CHM13v2.0-like synthetic genome (25 contigs, %.3f Gbp, scale %.3g, %s) "
                             "x pbsim-like HiFi reads (mean 24 kb, 1%% error); k=%d l=%d d=%g HPC"
-                            % (sum(lens) / 1e9, args.genome_scale, 100 * args.repeat_frac, args.k, args.l, args.density),
+                            % (sum(lens) / 1e9, args.genome_scale,
+                               "human-like repeats: 6% satellite arrays, 5% segmental duplications, young interspersed copies" if args.genome_preset == "human-like"
+                               else "%g%% planted repeats + %g%% tandem arrays" % (100 * args.repeat_frac, 100 * args.tandem_frac),
+                               args.k, args.l, args.density),
                 "reads_per_step_per_gpu": n,
                 "bases_per_step_per_gpu": total_bases,
                 "index_unique_kminmers": int(n_unique),
@@ -480,15 +669,18 @@ def main():
                                 "reads sharded over %d GPU(s) (every rank its own HBM-resident batch), index replicated, no data-path collective") % world,
             },
             "mreads_per_s": round(all_reads * args.steps / elapsed / 1e6, 4),
+            "per_rank_gbases_s": per_rank,
             "mapped_frac": round(n_mapped / max(n, 1), 4),
             "overflow_reads": n_over,
             "kminmers_per_step": n_kmm,
-            "setup_s": {"genome": round(t_genome, 1), "gpu_index": round(t_index, 2), "reads": round(t_reads, 1)},
+            "setup_s": {"genome": round(t_genome, 1), "genome_upload": round(t_upload, 2), "gpu_index": round(t_index, 3), "reads": round(t_reads, 1)},
+            "index_build": index_build,
             "q60": n_q60,
             "q60_wrong": n_q60_wrong,
             "mapped_reads": n_m,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "configs": configs,
             "end_to_end": e2e,
         }
         print(json.dumps(line), flush=True)

@@ -115,6 +115,11 @@ void mq_index_free(mq_index *idx);
 int64_t mq_index_add_ref(mq_index *idx, uint32_t ref_id, const char *name, const uint8_t *seq, uint64_t len);
 int64_t mq_index_add_ref_device(mq_index *idx, uint32_t ref_id, const char *name, const uint8_t *d_seq, uint64_t len);
 
+/* DashMap::with_capacity (src/index.rs:83 sizes its map for 39,821,990 k-min-mers at Index::new): a hint that about
+ * expected_kminmers k-min-mers will be inserted.  The table is allocated and cleared in the background while the references are
+ * added; mq_index_finalize adopts it when the size fits and allocates anew when it does not.  Fresh device memory costs ~30 ms per GB
+ * here (0.5 s for a human genome's table): call this as early as the reference's size is known.  One reservation per index. */
+int mq_index_reserve(mq_index *idx, uint64_t expected_kminmers);
 /* get_count + into_read_only (src/closures.rs:92-94): dedup (a hash seen twice is a tombstone,
  * src/index.rs:94-104), build the HBM-resident table.  Returns the unique count or <0. */
 int64_t mq_index_finalize(mq_index *idx);
@@ -164,18 +169,35 @@ int mq_ctx_wait(mq_ctx *ctx);
  * MQ_FLAG_FOLD_CASE the host never has to touch a base.  starts/lens/buf/out must stay valid until mq_ctx_wait. */
 int mq_ctx_submit_spans(mq_ctx *ctx, const uint8_t *buf, uint64_t buf_bytes, const uint64_t *starts, const uint32_t *lens, uint32_t n,
                         mq_hit *out);
+/* FASTA records found on the device (the batch form of closures.rs:100-123 for a reader that does not parse): buf[begin, bytes) is a
+ * piece of an uncompressed FASTA file that holds WHOLE records, begin at a record's '>'.  The bytes go to the device as they are,
+ * kernels find the line ends, and read i is the second line of record i (a '\r' in front of the '\n' is cut; a last line without
+ * '\n' ends at `bytes`).  mq_ctx_submit_fasta queues copy and scan and returns; mq_ctx_wait_fasta launches the map kernels once the
+ * record count is known and returns pointers into the context's page-locked memory, valid until its next submit:
+ *   line_ends[0 .. n_lines)  positions of the line ends in buf, ascending; record i: header = buf[(i ? line_ends[2i-1]+1 : begin), line_ends[2i]),
+ *                            sequence = buf[line_ends[2i]+1, line_ends[2i+1])   (n_lines = 2 * n_reads)
+ *   hits[0 .. n_reads)       as mq_ctx_wait fills them (overflow reads redone)
+ * flags & MQ_FASTA_IRREGULAR: the piece is not "header line, sequence line" all through (sequences over several lines, blank lines,
+ * more line ends than bytes / 16): nothing was mapped, n_reads = 0 -- parse it on the host and use mq_ctx_submit_spans.  buf must stay
+ * valid until mq_ctx_wait_fasta has returned; page-locked memory (mq_host_alloc) gives the full PCIe rate. */
+#define MQ_FASTA_IRREGULAR 1u
+int mq_ctx_submit_fasta(mq_ctx *ctx, const uint8_t *buf, uint64_t begin, uint64_t bytes);
+int mq_ctx_wait_fasta(mq_ctx *ctx, uint32_t *n_reads, const uint32_t **line_ends, uint32_t *n_lines, const mq_hit **hits, uint32_t *flags);
 /* Pre-size the context's device staging, minimizer lists and scratch for batches of up to n_reads reads / total_bytes buffer
  * bytes, so that the first submit does not pay for the allocations. */
 int mq_ctx_reserve(mq_ctx *ctx, uint32_t n_reads, uint64_t total_bytes);
 /* mq_map_batch_device on this context. */
 int mq_ctx_map_batch_device(mq_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases,
                             mq_hit *d_out, void *stream);
-int mq_ctx_last_map_ms(mq_ctx *ctx, float *ms);
 
 /* Page-locked host memory for the buffers handed to mq_map_batch / mq_index_add_ref (a feeder that parses FASTX straight
  * into such buffers gets the full PCIe rate on the copy in; pageable buffers work too, at roughly a quarter of it). */
 void *mq_host_alloc(size_t bytes);
 void mq_host_free(void *p);
+/* Page-lock / release a range the caller owns, whole pages (the feeder does this to slices of the mapped reads file, so that
+ * mq_ctx_submit_fasta's copy is a DMA out of the page cache that no host thread waits for).  0 on success. */
+int mq_host_register(void *ptr, size_t bytes);
+int mq_host_unregister(void *ptr);
 
 /* Pre-size the default context's scratch for batches of up to n_reads reads / total_bases bases, so that mq_map_batch_device
  * never allocates. */
@@ -193,30 +215,7 @@ int mq_index_lookup(mq_index *idx, const uint64_t *hashes, uint32_t n, uint8_t *
 /* The format! of src/mers.rs:181 (no newline).  Returns the length or <0. */
 int mq_format_paf(const mq_index *idx, const char *q_id, uint64_t q_len, const mq_hit *hit, char *buf, size_t cap);
 
-/* Diagnostic: how many reads of the last map launch took the fast seeding path (ACGT-only) and how many
- * the general streaming path.  Both produce identical results.  Synchronises on the launch. */
-int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general);
-
-/* Measurement aid: one instrumented (slower, never timed) launch of the same batch that counts index lookups and the slots
- * visited beyond each lookup's home slot: mean probes per lookup = 1 + extra_steps / lookups (SURVEY 8d's p-bar). */
-int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases, mq_hit *d_out,
-                       uint64_t *lookups, uint64_t *extra_steps);
-
-/* Diagnostic (tools/probe_rate.py): blocks*256 threads each probe per_thread pseudo-random (absent) keys of the finalized table;
- * returns the kernel time, the lookups made and the slots visited beyond the home slots.  Measures the random-access rate the
- * memory system sustains on this table, detached from the map path.  bitmap_log2 != 0: test a stand-in bitmap of 2^bitmap_log2
- * bits (one in eight set) first, and probe the table only for keys whose bit is set (table_too) or not at all. */
-int mq_probe_rate(mq_index *idx, uint32_t blocks, uint32_t per_thread, uint32_t bitmap_log2, uint32_t table_too, float *ms,
-                  uint64_t *lookups, uint64_t *extra_steps);
-
-/* Diagnostic: shader-clock cycles the waves of the last map launch of the index's default context spent in each of 12 stages
- * (list in mapquik_amd/csrc/mq_device.hpp, mq_clk), summed over waves.  Only a library built with -DMQ_STAGE_CLOCKS fills
- * them (tools/stage_clocks.py builds one beside the product library); the product build returns zeros. */
-int mq_last_stage_clocks(mq_index *idx, uint64_t *out12);
-
-/* Timing of the last mq_map_batch_device launch sequence on its stream, from HIP events recorded around the
- * kernels (milliseconds).  Synchronises on the end event. */
-int mq_last_map_ms(mq_index *idx, float *ms);
+/* Measurement and diagnostic entry points (probe statistics, stage clocks, launch timers): include/mapquik_hip_diag.h. */
 
 #ifdef __cplusplus
 }

@@ -27,8 +27,9 @@ def hit_column(hits, name):
         v = v | (hits[name + "_hi"].astype(np.uint64) << np.uint64(32))
     return v
 
-# every symbol include/mapquik_hip.h declares
-EXPORTS = ["mq_last_error", "mq_abi_version", "mq_device_count", "mq_params_default", "mq_index_new", "mq_index_free",
+# every symbol include/mapquik_hip.h (the seam) and include/mapquik_hip_diag.h (measurement / diagnostics) declare
+EXPORTS = ["mq_ctx_submit_fasta", "mq_ctx_wait_fasta", "mq_index_reserve", "mq_host_register", "mq_host_unregister",
+           "mq_last_error", "mq_abi_version", "mq_device_count", "mq_params_default", "mq_index_new", "mq_index_free",
            "mq_index_add_ref", "mq_index_add_ref_device", "mq_index_finalize", "mq_index_get_stats", "mq_index_ref_info",
            "mq_map_batch", "mq_map_batch_device", "mq_map_reserve", "mq_kminmers_batch", "mq_index_lookup", "mq_format_paf",
            "mq_last_map_ms", "mq_last_map_path_counts", "mq_host_alloc", "mq_host_free", "mq_index_save", "mq_index_load", "mq_index_clone", "mq_map_probe_stats",
@@ -98,6 +99,12 @@ def load_library(path=None):
     L.mq_ctx_submit.argtypes = [vp, vp, vp, u32, vp]
     L.mq_ctx_submit_spans.argtypes = [vp, vp, u64, vp, vp, u32, vp]
     L.mq_ctx_wait.argtypes = [vp]
+    if path is None or hasattr(L, "mq_ctx_submit_fasta"):  # (an older build given by path for an A/B run lacks them)
+        L.mq_index_reserve.argtypes = [vp, u64]
+        L.mq_host_register.argtypes = [vp, C.c_size_t]
+        L.mq_host_unregister.argtypes = [vp]
+        L.mq_ctx_submit_fasta.argtypes = [vp, vp, u64, u64]
+        L.mq_ctx_wait_fasta.argtypes = [vp, C.POINTER(u32), C.POINTER(vp), C.POINTER(u32), C.POINTER(vp), C.POINTER(u32)]
     L.mq_ctx_reserve.argtypes = [vp, u32, u64]
     L.mq_ctx_map_batch_device.argtypes = [vp, vp, vp, u32, u64, vp, vp]
     L.mq_ctx_last_map_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -216,6 +223,11 @@ class Index:
         if n < 0:
             raise _err(self._L, "mq_index_add_ref_device")
         return n
+
+    def reserve_table(self, expected_kminmers):
+        """DashMap::with_capacity (src/index.rs:83): the table for about this many k-min-mers is allocated and cleared in the background."""
+        if self._L.mq_index_reserve(self._h, int(expected_kminmers)) != 0:
+            raise _err(self._L, "mq_index_reserve")
 
     def finalize(self):
         """get_count + into_read_only (src/closures.rs:92-94): returns the unique k-min-mer count."""
@@ -400,6 +412,26 @@ class Context:
         if n > 0 and self._L.mq_ctx_submit_spans(self._h, _p(buf), buf.size, _p(starts), _p(lens), n, _p(out)) != 0:
             raise _err(self._L, "mq_ctx_submit_spans")
         self._keep = (buf, starts, out, lens)
+
+    def submit_fasta(self, buf, begin=0):
+        """Queue a piece of an uncompressed FASTA file that holds whole records (buf[begin:]): the records are found on the device."""
+        buf = _seq(buf)
+        if self._L.mq_ctx_submit_fasta(self._h, _p(buf), int(begin), buf.size) != 0:
+            raise _err(self._L, "mq_ctx_submit_fasta")
+        self._keep = (buf,)
+
+    def wait_fasta(self):
+        """(hits, line_ends, flags) of the piece submitted with submit_fasta; flags & 1 (MQ_FASTA_IRREGULAR): not two lines per record, nothing mapped."""
+        n, nl, fl = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        le, hp = C.c_void_p(), C.c_void_p()
+        if self._L.mq_ctx_wait_fasta(self._h, C.byref(n), C.byref(le), C.byref(nl), C.byref(hp), C.byref(fl)) != 0:
+            raise _err(self._L, "mq_ctx_wait_fasta")
+        self._keep = None
+        if fl.value & 1 or n.value == 0:
+            return np.zeros(0, dtype=hit_dtype), np.zeros(0, dtype=np.uint32), fl.value
+        hits = np.frombuffer(C.string_at(hp.value, n.value * hit_dtype.itemsize), dtype=hit_dtype).copy()
+        lines = np.frombuffer(C.string_at(le.value, nl.value * 4), dtype=np.uint32).copy()
+        return hits, lines, fl.value
 
     def wait(self):
         if self._L.mq_ctx_wait(self._h) != 0:

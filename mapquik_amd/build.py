@@ -57,7 +57,7 @@ FEEDER_DUMP = os.path.join(LIBDIR, "feeder_dump")
 def build_feeder_dump(force=False):
     """Test tool for the FASTX feeder (host only, no GPU): lib/feeder_dump."""
     src = os.path.join(HOST_DIR, "feeder_dump.cc")
-    deps = [src] + [os.path.join(HOST_DIR, h) for h in ("fastx_feeder.hpp", "par_gzip.hpp", "ref_loader.hpp")]
+    deps = [src] + [os.path.join(HOST_DIR, h) for h in ("fastx_feeder.hpp", "fastx_records.hpp", "par_gzip.hpp", "ref_loader.hpp")]
     if not force and os.path.exists(FEEDER_DUMP) and all(os.path.getmtime(FEEDER_DUMP) >= os.path.getmtime(d) for d in deps):
         return FEEDER_DUMP
     os.makedirs(LIBDIR, exist_ok=True)

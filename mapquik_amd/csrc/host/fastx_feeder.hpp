@@ -38,217 +38,10 @@
 #include "../../../include/mapquik_hip.h"
 #include "par_gzip.hpp"
 
+#include "fastx_records.hpp"
+
 namespace mapquik {
 namespace feeder {
-
-struct IdSpan {
-    uint64_t off;
-    uint32_t len;
-};
-
-// one unit of work through the pipeline: raw bytes + the reads found in them
-struct Chunk {
-    size_t seq_no = 0;
-    uint8_t *buf = nullptr;  // page-locked (mq_host_alloc)
-    uint64_t cap = 0, begin = 0, bytes = 0;  // whole records occupy buf[begin, bytes)
-    std::vector<uint64_t> starts;
-    std::vector<uint32_t> lens;
-    std::vector<IdSpan> ids;
-    std::vector<mq_hit> hits;
-    std::string paf, unmapped, unmapped_fa;  // formatted output of this chunk
-    // set by the whole-member gzip reader: the chunk's bytes still sit in a member's inflate buffer (kept alive by ext_hold);
-    // the parser thread that takes the chunk copies them into buf first
-    const uint8_t *ext_src = nullptr;
-    std::shared_ptr<void> ext_hold;
-    void clear() {
-        ext_src = nullptr;
-        ext_hold.reset();
-        begin = bytes = 0;
-        starts.clear();
-        lens.clear();
-        ids.clear();
-        hits.clear();
-        paf.clear();
-        unmapped.clear();
-        unmapped_fa.clear();
-    }
-};
-
-struct FeederError : std::runtime_error {
-    using std::runtime_error::runtime_error;
-};
-
-// ---------------------------------------------------------------- record boundaries
-constexpr uint64_t NEED_MORE = ~0ull;
-
-// 1: a FASTQ record starts at p; 0: it does not; 2: cannot tell without bytes beyond `end` (never when at_eof)
-inline int fastq_record_at(const uint8_t *b, uint64_t p, uint64_t end, bool at_eof) {
-    // '@' at a line start whose line after next starts with '+' and whose quality line is as long as its sequence line:
-    // tells a header from a quality line that happens to begin with '@'
-    if (p >= end) return at_eof ? 0 : 2;
-    if (b[p] != '@') return 0;
-    const int unknown = at_eof ? 0 : 2;  // at the end of the input an "@" line with fewer than three lines behind it starts no record (a quality line that begins with "@")
-    const uint8_t *e1 = (const uint8_t *)memchr(b + p, '\n', end - p);
-    if (!e1) return unknown;
-    const uint8_t *e2 = (const uint8_t *)memchr(e1 + 1, '\n', b + end - (e1 + 1));
-    if (!e2 || e2 + 1 >= b + end) return unknown;
-    if (e2[1] != '+') return 0;
-    const uint8_t *e3 = (const uint8_t *)memchr(e2 + 1, '\n', b + end - (e2 + 1));
-    if (!e3) return unknown;
-    const uint8_t *e4 = (const uint8_t *)memchr(e3 + 1, '\n', b + end - (e3 + 1));
-    if (!e4) return at_eof ? ((b + end - e3) == (e2 - e1) ? 1 : 0) : 2;  // last record of a file without a final newline
-    return (e4 - e3) == (e2 - e1) ? 1 : 0;
-}
-
-// first record start at or after `from`; `end` if there is none; NEED_MORE if that cannot be decided inside [.., end)
-inline uint64_t next_record_start(const uint8_t *b, uint64_t from, uint64_t end, bool fastq, bool at_eof) {
-    uint64_t p = from;
-    if (p > 0 && b[p - 1] != '\n') {  // move to the next line start
-        const uint8_t *e = (const uint8_t *)memchr(b + p, '\n', end - p);
-        if (!e) return at_eof ? end : NEED_MORE;
-        p = (uint64_t)(e - b) + 1;
-    }
-    while (p < end) {
-        if (fastq) {
-            const int r = fastq_record_at(b, p, end, at_eof);
-            if (r == 1) return p;
-            if (r == 2) return NEED_MORE;
-        } else if (b[p] == '>') {
-            return p;
-        }
-        const uint8_t *e = (const uint8_t *)memchr(b + p, '\n', end - p);
-        if (!e) return at_eof ? end : NEED_MORE;
-        p = (uint64_t)(e - b) + 1;
-    }
-    return at_eof ? end : NEED_MORE;
-}
-
-// ---------------------------------------------------------------- parser: whole records in c.buf[0, c.bytes) -> spans
-inline void parse_chunk(Chunk &c, bool fastq) {
-    uint8_t *b = c.buf;
-    const uint64_t end = c.bytes;
-    uint64_t p = c.begin;
-    auto line_end = [&](uint64_t from) -> uint64_t {
-        const uint8_t *e = (const uint8_t *)memchr(b + from, '\n', end - from);
-        return e ? (uint64_t)(e - b) : end;
-    };
-    auto add_id = [&](uint64_t h0, uint64_t h1) {  // seq_io's id(): the header line up to its first SPACE (a TAB is part of the id)
-        if (h1 > h0 + 1 && b[h1 - 1] == '\r') --h1;  // CR-LF files: the CR is not part of the line
-        uint64_t s = h0 + 1, e = s;
-        while (e < h1 && b[e] != ' ') ++e;
-        c.ids.push_back({s, (uint32_t)(e - s)});
-    };
-    while (p < end) {
-        if (b[p] == '\n' || b[p] == '\r') { ++p; continue; }
-        if (fastq) {
-            if (b[p] != '@') throw FeederError("malformed FASTQ record");
-            const uint64_t e1 = line_end(p);
-            add_id(p, e1);
-            const uint64_t s = e1 + 1 < end ? e1 + 1 : end;
-            const uint64_t e2 = line_end(s);
-            uint64_t sl = e2 - s;
-            if (sl && b[s + sl - 1] == '\r') --sl;
-            if (sl >= (1ull << 32)) throw FeederError("sequence length must be < 2^32");
-            c.starts.push_back(s);
-            c.lens.push_back((uint32_t)sl);
-            const uint64_t e3 = e2 < end ? line_end(e2 + 1) : end;                 // '+' line
-            uint64_t e4 = e3 < end ? e3 + 1 + (e2 - s) : end;                       // quality: as long as the sequence line
-            if (e4 > end || (e4 < end && b[e4] != '\n')) e4 = e3 < end ? line_end(e3 + 1) : end;
-            p = e4 < end ? e4 + 1 : end;
-        } else {
-            if (b[p] != '>') throw FeederError("malformed FASTA record");
-            const uint64_t e1 = line_end(p);
-            add_id(p, e1);
-            uint64_t s = e1 + 1 < end ? e1 + 1 : end;
-            uint64_t e2 = line_end(s);
-            uint64_t dst = e2;
-            if (dst > s && b[dst - 1] == '\r') --dst;
-            uint64_t q = e2 < end ? e2 + 1 : end;
-            while (q < end && b[q] != '>') {  // further sequence lines: compact them onto the first one
-                const uint64_t e = line_end(q);
-                uint64_t n = e - q;
-                if (n && b[q + n - 1] == '\r') --n;
-                if (n) memmove(b + dst, b + q, n);
-                dst += n;
-                q = e < end ? e + 1 : end;
-            }
-            if (dst - s >= (1ull << 32)) throw FeederError("sequence length must be < 2^32");
-            c.starts.push_back(s);
-            c.lens.push_back((uint32_t)(dst - s));
-            p = q;
-        }
-    }
-}
-
-// ---------------------------------------------------------------- lz4 frame decoder through liblz4.so.1 (no headers in the image)
-struct Lz4 {
-    void *lib = nullptr;
-    void *ctx = nullptr;
-    size_t (*create)(void **, unsigned) = nullptr;
-    size_t (*free_)(void *) = nullptr;
-    size_t (*decompress)(void *, void *, size_t *, const void *, size_t *, const void *) = nullptr;
-    unsigned (*is_error)(size_t) = nullptr;
-    Lz4() {
-        lib = dlopen("liblz4.so.1", RTLD_NOW);
-        if (!lib) throw FeederError("Error opening compressed file: liblz4.so.1 not found");
-        create = (size_t(*)(void **, unsigned))dlsym(lib, "LZ4F_createDecompressionContext");
-        free_ = (size_t(*)(void *))dlsym(lib, "LZ4F_freeDecompressionContext");
-        decompress = (size_t(*)(void *, void *, size_t *, const void *, size_t *, const void *))dlsym(lib, "LZ4F_decompress");
-        is_error = (unsigned (*)(size_t))dlsym(lib, "LZ4F_isError");
-        if (!create || !free_ || !decompress || !is_error || is_error(create(&ctx, 100))) throw FeederError("liblz4: LZ4F API not usable");
-    }
-    ~Lz4() {
-        if (ctx) free_(ctx);
-        if (lib) dlclose(lib);
-    }
-};
-
-// ---------------------------------------------------------------- libdeflate through libdeflate.so.0 (no headers in the image)
-// Whole-buffer inflate, ~3x zlib's rate on FASTX text.  Optional: without the library everything goes through zlib.
-struct Deflate {
-    void *lib = nullptr;
-    void *(*alloc)(void) = nullptr;
-    void (*free_)(void *) = nullptr;
-    // enum libdeflate_result: 0 success, 1 bad data, 2 short output, 3 insufficient space
-    int (*raw)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;                  // libdeflate_deflate_decompress
-    int (*gzip_ex)(void *, const void *, size_t, void *, size_t, size_t *, size_t *) = nullptr;    // libdeflate_gzip_decompress_ex
-    uint32_t (*crc)(uint32_t, const void *, size_t) = nullptr;                                      // libdeflate_crc32 (optional)
-    Deflate() {
-        if (getenv("MQ_FEEDER_NO_LIBDEFLATE")) return;  // test hook: the zlib paths
-        lib = dlopen("libdeflate.so.0", RTLD_NOW);
-        if (!lib) return;
-        alloc = (void *(*)(void))dlsym(lib, "libdeflate_alloc_decompressor");
-        free_ = (void (*)(void *))dlsym(lib, "libdeflate_free_decompressor");
-        raw = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(lib, "libdeflate_deflate_decompress");
-        gzip_ex = (int (*)(void *, const void *, size_t, void *, size_t, size_t *, size_t *))dlsym(lib, "libdeflate_gzip_decompress_ex");
-        crc = (uint32_t(*)(uint32_t, const void *, size_t))dlsym(lib, "libdeflate_crc32");
-        if (!alloc || !free_ || !raw || !gzip_ex) {
-            dlclose(lib);
-            lib = nullptr;
-        }
-    }
-    ~Deflate() { if (lib) dlclose(lib); }
-    bool ok() const { return lib != nullptr; }
-};
-
-// an anonymous, huge-page-backed buffer (a gzip member's inflated bytes)
-struct BigBuf {
-    uint8_t *p = nullptr;
-    uint64_t cap = 0;
-    explicit BigBuf(uint64_t n) {
-        cap = ((n + (2u << 20) - 1) / (2u << 20)) * (2u << 20);
-        // address space only: pages exist once written (and go back once parsed), so the mapping is not to be charged in full
-        p = (uint8_t *)mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-        if (p == MAP_FAILED) {
-            p = nullptr;
-            throw FeederError("cannot map memory for a gzip member");
-        }
-        madvise(p, cap, MADV_HUGEPAGE);
-    }
-    ~BigBuf() { if (p) munmap(p, cap); }
-    BigBuf(const BigBuf &) = delete;
-    BigBuf &operator=(const BigBuf &) = delete;
-};
 
 // ---------------------------------------------------------------- the feeder
 class Feeder {
@@ -256,9 +49,10 @@ class Feeder {
     // chunk_bytes: target raw bytes per chunk; n_threads: reader/parser threads
     // alloc/release: where chunk buffers come from (page-locked memory through mq_host_alloc unless a test says otherwise)
     Feeder(const std::string &path, bool fastq, uint64_t chunk_bytes, int n_threads, int max_chunks,
-           std::function<void *(size_t)> alloc = mq_host_alloc, std::function<void(void *)> release = mq_host_free)
+           std::function<void *(size_t)> alloc = mq_host_alloc, std::function<void(void *)> release = mq_host_free,
+           std::function<int(void *, size_t)> lock = mq_host_register, std::function<int(void *)> unlock = mq_host_unregister)
         : path_(path), fastq_(fastq), chunk_bytes_(chunk_bytes < 64 ? 64 : chunk_bytes), n_threads_(n_threads < 1 ? 1 : n_threads),
-          max_chunks_(max_chunks), alloc_(alloc), release_(release) {
+          max_chunks_(max_chunks), alloc_(alloc), release_(release), lock_(lock), unlock_(unlock) {
         auto ends = [&](const char *t) {
             const size_t n = strlen(t);
             return path.size() >= n && path.compare(path.size() - n, n, t) == 0;
@@ -303,13 +97,29 @@ class Feeder {
     }
     ~Feeder() {
         stop();
-        for (auto &c : all_) release_(c->buf);
+        for (auto &c : all_) release_(c->own ? c->own : c->buf);
         if (map_) munmap((void *)map_, map_size_);
         if (fd_ >= 0) close(fd_);
     }
 
     void start() {
-        if (lean_fastq_) {
+        if (leave_unparsed_ && kind_ == 0 && !fastq_ && file_size_ > 0 && getenv("MQ_FEEDER_MAPPED_FASTA")) {
+            // MQ_FEEDER_MAPPED_FASTA=1 (experimental; measured slower than pread into page-locked chunks inside the driver, profiles/NOTES.md):
+            // nothing is read here at all -- the file is mapped and a chunk is a view of its records, its whole pages page-locked by the
+            // reader threads so that the copy to the device is a DMA out of the page cache
+            const uint8_t *m = (const uint8_t *)mmap(nullptr, file_size_, PROT_READ, MAP_SHARED, fd_, 0);
+            if (m != MAP_FAILED) {
+                map_ = m;
+                map_size_ = file_size_;
+                mapped_fasta_ = true;
+                // the chunks' pages are locked by the reader threads (MQ_FEEDER_NO_PAGE_LOCK=1: the copies read pageable memory)
+                page_ = (uint64_t)sysconf(_SC_PAGESIZE);
+                lock_pages_ = page_ > 0 && !getenv("MQ_FEEDER_NO_PAGE_LOCK");
+            }
+        }
+        if (mapped_fasta_) {
+            for (int t = 0; t < n_threads_; ++t) threads_.emplace_back([this] { mapped_fasta_worker(); });
+        } else if (lean_fastq_) {
             for (int t = 0; t < n_threads_; ++t) threads_.emplace_back([this] { lean_fastq_worker(); });
         } else if (kind_ == 0 || kind_ == 3) {
             for (int t = 0; t < n_threads_; ++t) threads_.emplace_back([this] { raw_worker(); });
@@ -362,6 +172,11 @@ class Feeder {
     }
     // hand a chunk back for re-use
     void recycle(Chunk *c) {
+        if (c->locked_len) {  // a view of the mapped file whose pages were locked for the copy to the device
+            unlock_(c->locked_at);
+            c->locked_at = nullptr;
+            c->locked_len = 0;
+        }
         c->clear();
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -371,6 +186,28 @@ class Feeder {
     }
     size_t chunks_total() const { return produced_.load(); }
     uint64_t bytes_in() const { return file_size_; }
+    // Before start(): n buffers of the pool allocated (page-locked) now, by as many threads, so that the first chunks do not wait for
+    // them -- the pool's buffers do not depend on the input's bytes
+    void preallocate(int n) {
+        if (mapped_views()) return;
+        std::vector<std::thread> th;
+        std::vector<Chunk *> got((size_t)std::max(0, std::min(n, max_chunks_)), nullptr);
+        const uint64_t need = std::min<uint64_t>(chunk_bytes_ + (1u << 20) + 2, file_size_ + 2);
+        for (size_t i = 0; i < got.size(); ++i)
+            th.emplace_back([&, i] {
+                try { got[i] = get_buffer(need, true); } catch (const std::exception &) {}
+            });
+        for (auto &t : th) t.join();
+        for (Chunk *c : got)
+            if (c) recycle(c);
+    }
+    // Before start(): chunks of an uncompressed FASTA file are handed over as they were read, Chunk::unparsed set, no host thread
+    // having looked at a base (the consumer submits them with mq_ctx_submit_fasta; a chunk that comes back MQ_FASTA_IRREGULAR is
+    // parsed with parse_chunk after all).  Compressed input and FASTQ are parsed here as always.
+    void leave_unparsed(bool on) { leave_unparsed_ = on; }
+    bool fastq() const { return fastq_; }
+    // chunks will be (after start(): are) views of the mapped file (see start())
+    bool mapped_views() const { return mapped_fasta_ || (leave_unparsed_ && kind_ == 0 && !fastq_ && file_size_ > 0 && getenv("MQ_FEEDER_MAPPED_FASTA")); }
     const char *kind_name() const { return kind_ == 0 ? "raw" : kind_ == 1 ? (gz_whole_ ? "gzip (libdeflate, whole members)" : "gzip") : kind_ == 2 ? "lz4" : "bgzf"; }
 
   private:
@@ -388,9 +225,10 @@ class Feeder {
             if (force || (int)all_.size() < max_chunks_ || free_.size() == all_.size()) {  // grow the pool (or replace a too-small buffer when nothing is in flight)
                 lk.unlock();
                 std::unique_ptr<Chunk> c(new Chunk());
-                const uint64_t cap = std::max<uint64_t>(need, std::min<uint64_t>(chunk_bytes_ + chunk_bytes_ / 8 + (1u << 20), file_size_ + 64));
+                const uint64_t cap = mapped_fasta_ ? std::max<uint64_t>(need, 64) : std::max<uint64_t>(need, std::min<uint64_t>(chunk_bytes_ + chunk_bytes_ / 8 + (1u << 20), file_size_ + 64));
                 c->buf = (uint8_t *)alloc_(cap);
                 if (!c->buf) throw FeederError("cannot allocate a chunk buffer");
+                c->own = c->buf;
                 c->cap = cap;
                 lk.lock();
                 all_.push_back(std::move(c));
@@ -416,6 +254,48 @@ class Feeder {
             done_workers_++;
         }
         cv_.notify_all();
+    }
+
+    // mapped FASTA: chunk i = a view of the records whose first byte lies in [i*CH, (i+1)*CH) of the mapping; only the lines around the
+    // two cuts are looked at
+    void mapped_fasta_worker() {
+        std::string err;
+        try {
+            for (;;) {
+                Chunk *c = get_buffer(64);
+                const size_t i = next_raw_.fetch_add(1);
+                if (i >= n_raw_chunks_) {
+                    recycle(c);
+                    break;
+                }
+                const uint64_t lo = (uint64_t)i * chunk_bytes_, hi = std::min<uint64_t>(lo + chunk_bytes_, file_size_);
+                const uint64_t first = lo ? next_record_start(map_, lo, file_size_, false, true) : 0;
+                const uint64_t last = hi < file_size_ ? next_record_start(map_, hi, file_size_, false, true) : file_size_;
+                c->seq_no = i;
+                if (first >= last || first >= hi) {
+                    c->begin = c->bytes = 0;  // no record starts in this chunk (inside a long record)
+                } else {
+                    if (last - first >= (1ull << 32)) throw FeederError("sequence length must be < 2^32");
+                    c->buf = const_cast<uint8_t *>(map_) + first;
+                    c->begin = 0;
+                    c->bytes = last - first;
+                    c->unparsed = true;
+                    // Page-lock the chunk's whole pages [floor(first), floor(last)): the copy to the device is then a DMA out of the page cache
+                    // that no thread waits for (tools/file_h2d.hip: 47-50 GB/s against 15 per thread from pageable memory).  The ranges of
+                    // consecutive chunks tile the file, so no page is locked twice; the chunk's last partial page belongs to the next
+                    // chunk's range, and mq_ctx_submit_fasta moves those < 4 KB through a buffer of its own.  Released by recycle().
+                    if (lock_pages_) {
+                        const uint64_t a = first / page_ * page_, b = last / page_ * page_;
+                        if (b > a && lock_(const_cast<uint8_t *>(map_) + a, (size_t)(b - a)) == 0) {
+                            c->locked_at = const_cast<uint8_t *>(map_) + a;
+                            c->locked_len = b - a;
+                        }
+                    }
+                }
+                publish(c);
+            }
+        } catch (const std::exception &e) { err = e.what(); }
+        worker_done(err);
     }
 
     // raw file: chunk i owns the records whose first byte lies in [i*CH, (i+1)*CH)
@@ -472,7 +352,8 @@ class Feeder {
                     break;
                 }
                 c->seq_no = i;
-                parse_chunk(*c, fastq_);
+                if (leave_unparsed_ && kind_ == 0 && !fastq_ && c->bytes > c->begin) c->unparsed = true;  // the consumer finds the records (on the device)
+                else parse_chunk(*c, fastq_);
                 publish(c);
             }
         } catch (const std::exception &e) { err = e.what(); }
@@ -977,8 +858,14 @@ class Feeder {
     int n_threads_, max_chunks_;
     std::function<void *(size_t)> alloc_;
     std::function<void(void *)> release_;
+    std::function<int(void *, size_t)> lock_;  // page-lock / release whole pages of the mapped file (mq_host_register / mq_host_unregister)
+    std::function<int(void *)> unlock_;
     int kind_ = 0;  // 0 raw, 1 gzip, 2 lz4, 3 BGZF (indexed, read like raw)
     bool lean_fastq_ = false;  // raw FASTQ through the mapping: header and sequence lines only
+    bool leave_unparsed_ = false;
+    bool mapped_fasta_ = false;  // raw FASTA, records found by the consumer: chunks are views of the mapped file
+    bool lock_pages_ = false;    // ... and their pages are locked for the copy to the device
+    uint64_t page_ = 4096;
     bool gz_whole_ = false;    // plain gzip, members inflated whole by libdeflate
     Deflate deflate_;
     const uint8_t *map_ = nullptr;  // BGZF: the compressed file, mapped

@@ -63,7 +63,7 @@ int main(int argc, char **argv) {
             return 0;
         }
         Feeder f(argv[1], std::string(argv[2]) == "fastq", strtoull(argv[3], nullptr, 10), atoi(argv[4]), atoi(argv[4]) + 4,
-                 [](size_t n) { return malloc(n); }, [](void *p) { free(p); });
+                 [](size_t n) { return malloc(n); }, [](void *p) { free(p); }, [](void *, size_t) { return 0; }, [](void *) { return 0; });
         if (getenv("FEEDER_DUMP_KIND")) fprintf(stderr, "kind=%s\n", f.kind_name());
         f.start();
         std::map<size_t, Chunk *> held;

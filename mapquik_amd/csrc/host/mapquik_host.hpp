@@ -67,6 +67,10 @@ class Index {
     ~Index() { mq_index_free(h_); }
     mq_index *handle() const { return h_; }
     const Params &params() const { return params_; }
+    // DashMap::with_capacity (src/index.rs:83): the table for about n k-min-mers is allocated and cleared while the references load
+    void with_capacity(uint64_t n_kminmers) {
+        if (mq_index_reserve(h_, n_kminmers) != MQ_OK) throw Error("Index::with_capacity: " + last_error());
+    }
     // get_count (src/index.rs:90-92) is reported by into_read_only()
     ReadOnlyIndex into_read_only() &&;
 
@@ -115,6 +119,64 @@ inline ReadOnlyIndex Index::into_read_only() && {
     h_ = nullptr;
     return ReadOnlyIndex(h, (uint64_t)u);
 }
+
+// The format! of src/mers.rs:181 for many reads: the same bytes as mq_format_paf, appended to a string, with the reference names and
+// lengths looked up once per reference (a formatter thread of the native driver writes ~200,000 lines per batch; snprintf and a map
+// lookup per line were 3-4 us of it).
+class PafWriter {
+  public:
+    explicit PafWriter(const ReadOnlyIndex &index) : idx_(index.handle()) {}
+    // appends "q_id\tq_len\t...\tmapq\n" for a mapped hit
+    void append(std::string &out, const char *q_id, size_t q_id_len, uint64_t q_len, const mq_hit &h) {
+        const Ref &r = ref(h.ref_id);
+        char num[8 * 21 + 16];
+        char *p = num;
+        auto u = [&](uint64_t x) {
+            char t[20];
+            int n = 0;
+            do { t[n++] = (char)('0' + x % 10); x /= 10; } while (x);
+            while (n) *p++ = t[--n];
+        };
+        out.append(q_id, q_id_len);
+        *p++ = '\t'; u(q_len);
+        *p++ = '\t'; u(((uint64_t)h.q_start_hi << 32) | h.q_start);
+        *p++ = '\t'; u(((uint64_t)h.q_end_hi << 32) | h.q_end);
+        *p++ = '\t'; *p++ = h.rc ? '-' : '+'; *p++ = '\t';
+        out.append(num, (size_t)(p - num));
+        out += r.name;
+        p = num;
+        *p++ = '\t'; u(r.len);
+        *p++ = '\t'; u(h.r_start);
+        *p++ = '\t'; u(h.r_end);
+        *p++ = '\t'; u(h.score);
+        *p++ = '\t'; u(r.len);
+        *p++ = '\t'; u(h.mapq);
+        *p++ = '\n';
+        out.append(num, (size_t)(p - num));
+    }
+
+  private:
+    struct Ref {
+        std::string name;
+        uint64_t len = 0;
+        bool known = false;
+    };
+    const Ref &ref(uint32_t id) {
+        if (id >= refs_.size()) refs_.resize((size_t)id + 1);
+        Ref &r = refs_[id];
+        if (!r.known) {
+            const char *name = nullptr;
+            uint64_t len = 0;
+            if (mq_index_ref_info(idx_, id, &name, &len) != MQ_OK) throw Error("find_coords: " + last_error());
+            r.name = name ? name : "";
+            r.len = len;
+            r.known = true;
+        }
+        return r;
+    }
+    mq_index *idx_;
+    std::vector<Ref> refs_;
+};
 
 namespace mers {
 

@@ -8,6 +8,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +23,7 @@
 #include <vector>
 
 #include <sys/resource.h>
+#include <sys/stat.h>
 
 #include "fastx_feeder.hpp"
 #include "mapquik_host.hpp"
@@ -128,8 +130,12 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         using feeder::Chunk;
         const int n_parse = (int)std::max<size_t>(1, threads);
         const int n_slots = 3;  // stream slots per GPU: copy-in, kernels and copy-out of consecutive chunks overlap
-        const int n_format = std::max(1, std::min(4, n_parse / 2));
+        const int n_format = std::max(2, std::min(8, n_parse));  // PAF formatters (the reader threads of a mapped FASTA file have next to nothing to do)
         feeder::Feeder feed(reads_path, !reads_fasta, o.batch_bases, n_parse, n_parse + o.gpus * (n_slots + 1) + n_format + 2);
+        // An uncompressed FASTA file goes to the GPU as it lies in the file: the reader threads only copy file bytes into page-locked
+        // chunks (pread, cut at record starts), the records are found on the device (mq_ctx_submit_fasta) and the host reads a header
+        // only to print it.  MQ_DRIVER_HOST_PARSE=1: every chunk is parsed by the reader threads as in earlier rounds (same PAF; tests compare).
+        feed.leave_unparsed(reads_fasta && getenv("MQ_DRIVER_HOST_PARSE") == nullptr);
         // The read feeder starts when the index is ready.  MQ_DRIVER_PREFETCH=1 starts it while the reference is still being indexed
         // (it then allocates its page-locked chunk buffers and parses the first chunks early): that was the default while pinning
         // the pool was the read phase's start-up cost; with the huge-page pool it makes the map phase 15 % shorter and the index
@@ -150,6 +156,16 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         std::vector<std::unique_ptr<Index>> building(1);
         building[0].reset(new Index(P, dev_of(0)));
         const bool ref_plain = ref_fasta && !ends_with(o.reference, ".gz") && !ends_with(o.reference, ".lz4");
+        if (ref_plain && getenv("MQ_DRIVER_NO_RESERVE") == nullptr) {
+            // Index::new sizes its map before the first insert (src/index.rs:83: with_capacity(39,821,990), CHM13 at the defaults); here the
+            // expected count follows from the reference's size: canonical selection keeps 1 - (1 - d)^2 of the l-mers, homopolymer
+            // compression about three quarters of the bases.  The table is allocated in the background while the reference is read and seeded.
+            struct stat rst;
+            if (stat(o.reference.c_str(), &rst) == 0 && rst.st_size > 0) {
+                const double d = std::min(1.0, std::max(0.0, P.density));
+                building[0]->with_capacity((uint64_t)((double)rst.st_size * (1.0 - (1.0 - d) * (1.0 - d)) * (P.use_hpc ? 0.75 : 1.0)) + 1);
+            }
+        }
         if (ref_plain) {
             // an uncompressed FASTA: the whole file read once by all threads, records handed over whole and in order (ref_loader.hpp)
             feeder::RefLoader rl(o.reference, n_parse);
@@ -165,7 +181,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             // the device exactly once)
             if (prefetch) start_feed();
             feeder::Feeder rfeed(o.reference, !ref_fasta, 1ull << 28, n_parse, n_parse + 4, [](size_t n) { return malloc(n); },
-                                 [](void *q) { free(q); });
+                                 [](void *q) { free(q); }, [](void *, size_t) { return 0; }, [](void *) { return 0; });
             rfeed.start();
             std::map<size_t, Chunk *> held;
             size_t next = 0, ref_idx = 0;
@@ -205,6 +221,33 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             for (auto &t : th) t.join();
             for (auto &e : errs) if (!e.empty()) throw Error(e);
         }
+        // The stream slots of the map phase (device staging, minimizer lists, Match scratch: a few hundred MB of device memory per
+        // submitting thread) are set up here, at the end of the reference phase: none of it depends on the reads.
+        const int n_sub = feed.mapped_views() ? 2 : 1;  // submitting threads per GPU (see below)
+        std::vector<std::vector<mq_ctx *>> slots((size_t)(o.gpus * n_sub), std::vector<mq_ctx *>((size_t)n_slots, nullptr));
+        {
+            std::vector<std::string> errs(slots.size());
+            std::vector<std::thread> th;
+            for (size_t gw = 0; gw < slots.size(); ++gw)
+                th.emplace_back([&, gw]() {
+                    for (int sl = 0; sl < n_slots; ++sl) {
+                        slots[gw][sl] = mq_ctx_new(ro[gw / (size_t)n_sub]->handle());
+                        if (!slots[gw][sl]) { errs[gw] = std::string("mq_ctx_new: ") + last_error(); return; }
+                        const uint64_t cb = std::min<uint64_t>(o.batch_bases + o.batch_bases / 8 + (1u << 20), feed.bytes_in() + 64);
+                        if (mq_ctx_reserve(slots[gw][sl], (uint32_t)std::min<uint64_t>(cb / 16000 + 512, 1u << 24), cb) != MQ_OK) {  // (sized for long reads; a chunk of short reads makes its slot grow once)
+                            errs[gw] = std::string("mq_ctx_reserve: ") + last_error();
+                            return;
+                        }
+                    }
+                });
+            if (!prefetch) th.emplace_back([&]() { feed.preallocate(n_parse + n_slots); });  // and the first page-locked chunk buffers
+            for (auto &t : th) t.join();
+            for (auto &e : errs)
+                if (!e.empty()) {
+                    for (auto &v : slots) for (auto c : v) mq_ctx_free(c);
+                    throw Error(e);
+                }
+        }
         printf("Indexed %llu unique k-min-mers in %s.\n", (unsigned long long)ro[0]->unique_count(), rust_duration(secs(t0)).c_str());
 
         t0 = Clock::now();
@@ -214,7 +257,9 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         std::condition_variable cv;
         std::deque<Chunk *> to_format;               // mapped, waiting for a formatter
         std::map<size_t, Chunk *> done;              // formatted, waiting for their turn in the output
-        int gpu_workers_left = o.gpus;
+        // Submitting threads per GPU (n_sub).  Chunks that are views of the mapped file are copied to the device from pageable memory: that
+        // copy occupies the thread that asks for it, and two threads keep the link full (profiles/r04_file_h2d.txt: one 14.6, two 48 GB/s).
+        int gpu_workers_left = o.gpus * n_sub;
         int formatting = 0;                          // chunks a formatter is working on right now
         std::string werr;
         auto fail = [&](const std::string &m) {
@@ -228,24 +273,52 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             std::lock_guard<std::mutex> lk(mu);
             return !werr.empty();
         };
+        const bool drv_timing = getenv("MQ_DRIVER_TIMING") != nullptr;  // diagnostic: where the map phase's threads spend their time (stderr)
+        std::atomic<long long> t_submit_us{0}, t_finish_us{0}, t_fetch_us{0}, t_format_us{0}, t_write_us{0};
+        auto us_since = [](Clock::time_point a) { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - a).count(); };
         const char *fail_at_env = getenv("MQ_DRIVER_FAIL_AT");  // test hook: the worker that takes this chunk number reports a failure
         const long fail_at = fail_at_env ? atol(fail_at_env) : -1;
         std::vector<std::thread> workers;
-        for (int g = 0; g < o.gpus; ++g)
-            workers.emplace_back([&, g]() {
-                std::vector<mq_ctx *> ctx((size_t)n_slots, nullptr);
+        for (int gw = 0; gw < o.gpus * n_sub; ++gw)
+            workers.emplace_back([&, gw]() {
+                std::vector<mq_ctx *> &ctx = slots[(size_t)gw];
                 std::vector<Chunk *> inflight((size_t)n_slots, nullptr);
                 std::vector<size_t> age((size_t)n_slots, 0);  // submit order of the chunk in the slot
                 size_t submitted = 0;
                 auto finish_slot = [&](int sl) {
                     if (!inflight[sl]) return;
-                    if (mq_ctx_wait(ctx[sl]) != MQ_OK) fail(std::string("mq_ctx_wait: ") + last_error());
+                    const auto tf0 = Clock::now();
+                    Chunk *fc = inflight[sl];
+                    if (fc->unparsed) {  // records found on the device: hits and line ends come back together
+                        uint32_t n = 0, n_lines = 0, flags = 0;
+                        const uint32_t *line_ends = nullptr;
+                        const mq_hit *hits = nullptr;
+                        if (mq_ctx_wait_fasta(ctx[sl], &n, &line_ends, &n_lines, &hits, &flags) != MQ_OK) {
+                            fail(std::string("mq_ctx_wait_fasta: ") + last_error());
+                        } else if (flags & MQ_FASTA_IRREGULAR) {
+                            // sequences over several lines, blank lines, ...: this chunk the old way (parsed here, spans to the device)
+                            try {
+                                fc->materialize();  // a view of the mapped file: the parser compacts sequence lines in place
+                                feeder::parse_chunk(*fc, false);
+                                fc->hits.resize(fc->starts.size());
+                                if (!fc->starts.empty() &&
+                                    (mq_ctx_submit_spans(ctx[sl], fc->buf, fc->bytes, fc->starts.data(), fc->lens.data(), (uint32_t)fc->starts.size(), fc->hits.data()) != MQ_OK ||
+                                     mq_ctx_wait(ctx[sl]) != MQ_OK))
+                                    fail(std::string("mq_ctx_submit_spans: ") + last_error());
+                            } catch (const std::exception &e) { fail(e.what()); }
+                        } else {
+                            feeder::spans_from_line_ends(*fc, line_ends, n_lines);
+                            fc->hits.assign(hits, hits + n);
+                        }
+                        fc->unparsed = false;
+                    } else if (mq_ctx_wait(ctx[sl]) != MQ_OK) fail(std::string("mq_ctx_wait: ") + last_error());
                     {
                         std::lock_guard<std::mutex> lk(mu);
                         to_format.push_back(inflight[sl]);
                     }
                     inflight[sl] = nullptr;
                     cv.notify_all();
+                    t_finish_us += us_since(tf0);
                 };
                 // the slot to use next: a free one, else the one submitted longest ago (-1 with free_only when none is free)
                 auto oldest_busy = [&]() {
@@ -255,13 +328,6 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                     return best;
                 };
                 try {
-                    for (int sl = 0; sl < n_slots; ++sl) {
-                        ctx[sl] = mq_ctx_new(ro[g]->handle());
-                        if (!ctx[sl]) throw Error(std::string("mq_ctx_new: ") + last_error());
-                        const uint64_t cb = std::min<uint64_t>(o.batch_bases + o.batch_bases / 8 + (1u << 20), feed.bytes_in() + 64);
-                        if (mq_ctx_reserve(ctx[sl], (uint32_t)std::min<uint64_t>(cb / 2000 + 1024, 1u << 24), cb) != MQ_OK)
-                            throw Error(std::string("mq_ctx_reserve: ") + last_error());
-                    }
                     for (;;) {
                         if (failed()) break;  // somebody failed: stop pulling chunks
                         // Never wait for a new chunk while holding submitted ones: the writer may be waiting for exactly one of
@@ -276,7 +342,9 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                                 finish_slot(busy);
                                 continue;
                             }
+                            const auto tq0 = Clock::now();
                             c = feed.next();
+                            t_fetch_us += us_since(tq0);
                             if (!c) break;
                         }
                         if (fail_at >= 0 && (long)c->seq_no == fail_at) throw Error("injected failure (MQ_DRIVER_FAIL_AT)");
@@ -287,6 +355,14 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                             sl = oldest_busy();
                             finish_slot(sl);
                         }
+                        if (c->unparsed) {
+                            const auto ts0 = Clock::now();
+                            if (mq_ctx_submit_fasta(ctx[sl], c->buf, c->begin, c->bytes) != MQ_OK) throw Error(std::string("mq_ctx_submit_fasta: ") + last_error());
+                            t_submit_us += us_since(ts0);
+                            inflight[sl] = c;
+                            age[sl] = submitted++;
+                            continue;
+                        }
                         c->hits.resize(c->starts.size());
                         if (c->starts.empty()) {  // nothing to map in this chunk (the middle of a very long record)
                             std::lock_guard<std::mutex> lk(mu);
@@ -294,15 +370,16 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                             cv.notify_all();
                             continue;
                         }
+                        const auto ts0 = Clock::now();
                         if (mq_ctx_submit_spans(ctx[sl], c->buf, c->bytes, c->starts.data(), c->lens.data(), (uint32_t)c->starts.size(),
                                                 c->hits.data()) != MQ_OK)
                             throw Error(std::string("mq_ctx_submit_spans: ") + last_error());
+                        t_submit_us += us_since(ts0);
                         inflight[sl] = c;
                         age[sl] = submitted++;
                     }
                     for (int q = oldest_busy(); q >= 0; q = oldest_busy()) finish_slot(q);
                 } catch (const std::exception &e) { fail(e.what()); }
-                for (auto c : ctx) mq_ctx_free(c);
                 {
                     std::lock_guard<std::mutex> lk(mu);
                     gpu_workers_left--;
@@ -313,7 +390,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         for (int f = 0; f < n_format; ++f)
             formatters.emplace_back([&]() {
                 std::string id;
-                std::vector<char> buf(4096);
+                PafWriter pw(*ro[0]);
                 for (;;) {
                     Chunk *c = nullptr;
                     {
@@ -324,19 +401,17 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                         to_format.pop_front();
                         formatting++;
                     }
+                    const auto tm0 = Clock::now();
+                    try {
+                    c->paf.reserve(c->starts.size() * 96);
                     for (size_t i = 0; i < c->starts.size(); ++i) {
                         const mq_hit &h = c->hits[i];
-                        id.assign((const char *)c->buf + c->ids[i].off, c->ids[i].len);
                         if (h.status == MQ_HIT_MAPPED) {
-                            int w = mq_format_paf(ro[0]->handle(), id.c_str(), c->lens[i], &h, buf.data(), buf.size());
-                            if (w >= (int)buf.size()) {
-                                buf.resize((size_t)w + 1);
-                                w = mq_format_paf(ro[0]->handle(), id.c_str(), c->lens[i], &h, buf.data(), buf.size());
-                            }
-                            if (w < 0) { fail(std::string("find_coords: ") + last_error()); break; }
-                            c->paf.append(buf.data(), (size_t)w);
-                            c->paf.push_back('\n');
-                        } else if (h.status == MQ_HIT_UNMAPPED) {
+                            pw.append(c->paf, (const char *)c->buf + c->ids[i].off, c->ids[i].len, c->lens[i], h);  // src/mers.rs:181
+                            continue;
+                        }
+                        id.assign((const char *)c->buf + c->ids[i].off, c->ids[i].len);
+                        if (h.status == MQ_HIT_UNMAPPED) {
                             if (unm) { c->unmapped += id; c->unmapped.push_back('\n'); }
                             if (ufa) {
                                 c->unmapped_fa.push_back('>');
@@ -350,6 +425,8 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                             break;
                         }
                     }
+                    } catch (const std::exception &e) { fail(e.what()); }
+                    t_format_us += us_since(tm0);
                     {
                         std::lock_guard<std::mutex> lk(mu);
                         done[c->seq_no] = c;
@@ -371,10 +448,12 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                 c = it->second;
                 done.erase(it);
             }
+            const auto tw0 = Clock::now();
             if (!c->paf.empty()) fwrite(c->paf.data(), 1, c->paf.size(), paf);
             if (unm && !c->unmapped.empty()) fwrite(c->unmapped.data(), 1, c->unmapped.size(), unm);
             if (ufa && !c->unmapped_fa.empty()) fwrite(c->unmapped_fa.data(), 1, c->unmapped_fa.size(), ufa);
             feed.recycle(c);
+            t_write_us += us_since(tw0);
             ++next_out;
         }
         // On a failure the chunks in flight are never recycled, so the feeder's workers (waiting for a buffer) and the GPU workers
@@ -384,6 +463,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         cv.notify_all();
         for (auto &t : formatters) if (t.joinable()) t.join();
         if (!werr.empty()) {
+            for (auto &v : slots) for (auto c : v) mq_ctx_free(c);
             fclose(paf);
             if (unm) fclose(unm);
             if (ufa) fclose(ufa);
@@ -393,7 +473,12 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         fclose(paf);
         if (unm) fclose(unm);
         if (ufa) fclose(ufa);
+        if (drv_timing)
+            fprintf(stderr, "map phase %.3f s; summed over threads: submit %.3f s, finish (wait + spans) %.3f s, waiting for a chunk %.3f s (%d submitters), "
+                            "format %.3f s (%d formatters), write + recycle %.3f s\n", secs(t0), t_submit_us / 1e6, t_finish_us / 1e6, t_fetch_us / 1e6, o.gpus * n_sub,
+                    t_format_us / 1e6, n_format, t_write_us / 1e6);
         printf("Mapped query sequences in %s.\n", rust_duration(secs(t0)).c_str());  // src/closures.rs:211
+        for (auto &v : slots) for (auto c : v) mq_ctx_free(c);
     return 0;
 }
 

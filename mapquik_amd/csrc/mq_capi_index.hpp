@@ -1,0 +1,323 @@
+// mq_capi_index.hpp -- C ABI, index side: mq_index_new .. mq_index_finalize (Index::new, ref_extract + add_with_mer, get_count +
+// into_read_only; src/index.rs:78-116, src/mers.rs:15-38) (part of the one translation unit mq_capi.hip).
+#pragma once
+
+extern "C" {
+
+mq_index *mq_index_new(const mq_params *params, int device) try {
+    if (!params) {
+        set_err(MQ_EINVAL, "params is NULL");
+        return nullptr;
+    }
+    if (params->l < 1 || params->l > MAX_L || params->k < 1 || params->k > MAX_K) {
+        set_err(MQ_EINVAL, "unsupported k/l: need 1 <= l <= 64 and 1 <= k <= 32");
+        return nullptr;
+    }
+    int n = mq_device_count();
+    if (n <= 0) {
+        set_err(MQ_ENODEVICE, "no HIP device: the mapquik HIP path has no CPU fallback");
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        set_err(MQ_EINVAL, "device ordinal out of range");
+        return nullptr;
+    }
+    mq_index *idx = new mq_index();
+    idx->params = *params;
+    idx->device = device;
+    idx->dp.bound = density_bound(params->density);
+    idx->dp.k = params->k;
+    idx->dp.l = params->l;
+    idx->dp.use_hpc = params->use_hpc ? 1 : 0;
+    idx->dp.c = params->c;
+    idx->dp.s = params->s;
+    idx->dp.g = params->g;
+    idx->dp.fold = (params->flags & MQ_FLAG_FOLD_CASE) ? 1u : 0u;
+    const char *cc = getenv("MQ_CHAIN_CHUNK");
+    if (cc && atoi(cc) == 4) idx->chain_chunk = 4;
+    const char *fg = getenv("MQ_FORCE_GENERAL");
+    idx->force_general = fg && atoi(fg) != 0;
+    const char *pl = getenv("MQ_PIPELINE");
+    idx->split = pl && strcmp(pl, "split") == 0;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        set_err(MQ_EHIP, "hipSetDevice/hipGetDeviceProperties failed");
+        delete idx;
+        return nullptr;
+    }
+    idx->n_cu = prop.multiProcessorCount;
+    // an empty one-bucket table so that seeding-only calls work before finalize
+    if (alloc_table(idx, 2) != MQ_OK) {
+        delete idx;
+        return nullptr;
+    }
+    idx->def_ctx = ctx_create(idx);
+    if (!idx->def_ctx) {
+        hipFree(idx->table);
+        delete idx;
+        return nullptr;
+    }
+    return idx;
+} catch (const std::bad_alloc &) {
+    set_err(MQ_ENOMEM, "out of host memory");
+    return nullptr;
+} catch (const std::exception &e) {
+    set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+    return nullptr;
+}
+
+void mq_index_free(mq_index *idx) {
+    if (!idx) return;
+    rsv_join(idx);
+    hipSetDevice(idx->device);
+    if (idx->rsv_table) hipFree(idx->rsv_table);
+    for (auto &c : idx->chunks)
+        if (c.d) hipFree(c.d);
+    free_build_scratch(idx);
+    if (idx->table) hipFree(idx->table);
+    if (idx->d_ref_lens) hipFree(idx->d_ref_lens);
+    ctx_release(idx->def_ctx);
+    delete idx;
+}
+
+static int64_t add_ref_device_locked(mq_index *idx, uint32_t ref_id, const char *name, const uint8_t *d_seq, uint64_t len) {
+    if (!idx || (!d_seq && len)) return set_err(MQ_EINVAL, "bad arguments");
+    if (idx->finalized) return set_err(MQ_ESTATE, "index already finalized");
+    if (len >= (1ull << 32)) return set_err(MQ_EINVAL, "sequence length must be < 2^32");
+    if (ref_id >= MQ_MAX_REF_ID) return set_err(MQ_EINVAL, "ref_id must be < 2^24 (reference lengths are kept in a dense device array)");
+    if (idx->refs.count(ref_id)) return set_err(MQ_EINVAL, "duplicate ref_id");
+    int rc = use_device(idx);
+    if (rc) return rc;
+    idx->refs[ref_id] = std::make_pair(std::string(name ? name : ""), len);
+    const DevParams &P = idx->dp;
+    if (len < (uint64_t)P.l + P.k - 1) return 0;  // src/mers.rs:18
+
+    const uint32_t n_seg = (uint32_t)((len + REF_SEG - 1) / REF_SEG);
+    // expected minimizers per segment: 2 * density of the compressed l-mers; cap with slack, worst case on retry
+    double dens = idx->params.density;
+    if (!(dens > 0)) dens = 0;
+    if (dens > 1) dens = 1;
+    uint32_t cap = (uint32_t)std::min<double>((double)REF_SEG, 3.0 * 2.0 * dens * (double)REF_SEG + 256.0);
+    if ((rc = grow(idx->bld_counts, idx->bld_counts_cap, n_seg))) return rc;
+    if ((rc = grow(idx->bld_queue, idx->bld_queue_cap, n_seg))) return rc;
+    if ((rc = grow(idx->bld_seg_off, idx->bld_seg_off_cap, (uint64_t)n_seg + 1))) return rc;
+    if (!idx->bld_info) HIPCHK(hipMalloc((void **)&idx->bld_info, 64));
+    if (!idx->grid_ref) {
+        int occ = 0;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)seed_ref_kernel, 64 * SEED_WAVES, 0));
+        idx->grid_ref = std::max(1, occ) * idx->n_cu;
+    }
+    unsigned long long info[2] = {0, 0};
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if ((rc = grow(idx->bld_seg_hash, idx->bld_seg_hash_cap, (uint64_t)n_seg * cap))) return rc;
+        if ((rc = grow(idx->bld_seg_pos, idx->bld_seg_pos_cap, (uint64_t)n_seg * cap))) return rc;
+        HIPCHK(hipMemsetAsync(idx->bld_info, 0, 64, 0));
+        RefSeedArgs A;
+        A.seq = d_seq;
+        A.len = len;
+        A.n_seg = n_seg;
+        A.P = P;
+        A.seg_hash = idx->bld_seg_hash;
+        A.seg_pos = idx->bld_seg_pos;
+        A.cap = cap;
+        A.counts = idx->bld_counts;
+        A.queue = idx->bld_queue;
+        A.counters = reinterpret_cast<uint32_t *>(idx->bld_info + 2);
+        A.force_general = idx->force_general ? 1u : 0u;
+        const uint32_t g1 = std::min<uint32_t>((uint32_t)idx->grid_ref, (n_seg + SEED_WAVES - 1) / SEED_WAVES);
+        hipLaunchKernelGGL(seed_ref_kernel, dim3(g1), dim3(64 * SEED_WAVES), 0, 0, A);
+        HIPCHK(hipGetLastError());
+        // the queue's length lives on the device: a fixed grid, waves that find the queue empty leave at once
+        hipLaunchKernelGGL(seed_ref_general_kernel, dim3(std::min<uint32_t>((uint32_t)idx->n_cu * 32u, n_seg)), dim3(64), 0, 0, A);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, 0, idx->bld_counts, n_seg, cap, idx->bld_seg_off, idx->bld_info);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(info, idx->bld_info, 16, hipMemcpyDeviceToHost));
+        if (!info[1]) break;
+        if (attempt == 1) return set_err(MQ_EOVERFLOW, "minimizer list overflow at worst-case capacity (internal error)");
+        cap = REF_SEG;  // a segment cannot list more minimizers than it has bases
+    }
+    const uint64_t n_mz = info[0];
+    int64_t n_kmm = 0;
+    if (n_mz >= P.k) {
+        n_kmm = (int64_t)(n_mz - P.k + 1);
+        if ((rc = grow(idx->bld_dense_hash, idx->bld_dense_hash_cap, n_mz))) return rc;
+        if ((rc = grow(idx->bld_dense_pos, idx->bld_dense_pos_cap, n_mz))) return rc;
+        hipLaunchKernelGGL(compact_lists_kernel, dim3(std::min<uint32_t>(n_seg, 65535u)), dim3(64), 0, 0, idx->bld_seg_hash, idx->bld_seg_pos, cap,
+                           idx->bld_counts, idx->bld_seg_off, n_seg, idx->bld_dense_hash, idx->bld_dense_pos);
+        HIPCHK(hipGetLastError());
+        // the reference's k-min-mers go behind those of the previous references in the current chunk while it has room
+        if (idx->chunks.empty() || idx->chunks.back().n + (uint64_t)n_kmm > idx->chunks.back().cap) {
+            KmmChunk ch;
+            ch.cap = std::max<uint64_t>((uint64_t)n_kmm, 16ull << 20);
+            HIPCHK(hipMalloc((void **)&ch.d, (size_t)ch.cap * sizeof(RefKmm)));
+            idx->chunks.push_back(ch);
+        }
+        KmmChunk &ch = idx->chunks.back();
+        const uint32_t kb = (uint32_t)std::min<uint64_t>(((uint64_t)n_kmm + 255) / 256, 65535ull);
+        hipLaunchKernelGGL(ref_kminmers_kernel, dim3(kb), dim3(256), 0, 0, idx->bld_dense_hash, idx->bld_dense_pos, n_mz, P, ref_id, ch.d + ch.n);
+        HIPCHK(hipGetLastError());
+        ch.n += (uint64_t)n_kmm;
+        idx->n_kmm_total += (uint64_t)n_kmm;
+    }
+    return n_kmm;  // everything above runs on the null stream: the next call's kernels (and finalize) are ordered behind it
+}
+
+int64_t mq_index_add_ref_device(mq_index *idx, uint32_t ref_id, const char *name, const uint8_t *d_seq, uint64_t len) try {
+    if (!idx) return set_err(MQ_EINVAL, "idx is NULL");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (!getenv("MQ_BUILD_TIMING")) return add_ref_device_locked(idx, ref_id, name, d_seq, len);
+    hipDeviceSynchronize();
+    const auto t0 = std::chrono::steady_clock::now();
+    const int64_t r = add_ref_device_locked(idx, ref_id, name, d_seq, len);
+    hipDeviceSynchronize();
+    idx->t_add_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return r;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+}
+
+int64_t mq_index_add_ref(mq_index *idx, uint32_t ref_id, const char *name, const uint8_t *seq, uint64_t len) try {
+    if (!idx || (!seq && len)) return set_err(MQ_EINVAL, "bad arguments");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    int rc = use_device(idx);
+    if (rc) return rc;
+    if (len >= (1ull << 32)) return set_err(MQ_EINVAL, "sequence length must be < 2^32");
+    if ((rc = grow(idx->bld_seq, idx->bld_seq_cap, len + 64))) return rc;
+    if (len) HIPCHK(hipMemcpy(idx->bld_seq, seq, len, hipMemcpyHostToDevice));
+    return add_ref_device_locked(idx, ref_id, name, idx->bld_seq, len);
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+}
+
+// DashMap::with_capacity at Index::new (src/index.rs:83 sizes the map for 39,821,990 k-min-mers before the first insert): the table
+// for `expected_kminmers` inserted k-min-mers is allocated and cleared by a thread of its own, while the caller reads, uploads and
+// seeds the reference -- fresh device memory costs ~30 ms per GB on this platform (tools/alloc_probe.hip: 485 ms for the 17 GB table
+// of a human genome), more than every kernel of the build together.  A hint only: mq_index_finalize allocates again when the
+// reference turns out to need another size.
+int mq_index_reserve(mq_index *idx, uint64_t expected_kminmers) try {
+    if (!idx) return set_err(MQ_EINVAL, "idx is NULL");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (idx->finalized) return set_err(MQ_ESTATE, "index already finalized");
+    if (idx->rsv_thread.joinable() || idx->rsv_table) return MQ_OK;  // one reservation per index
+    const uint64_t nslots = table_slots_for(expected_kminmers);
+    idx->rsv_nslots = nslots;
+    const int device = idx->device;
+    idx->rsv_thread = std::thread([idx, nslots, device]() {
+        hipError_t e = hipSetDevice(device);
+        void *p = nullptr;
+        if (e == hipSuccess) e = hipMalloc(&p, table_bytes_of(nslots));
+        hipStream_t st = nullptr;
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);  // not the null stream: the build's kernels run there
+        if (e == hipSuccess) e = hipMemsetAsync(p, 0, table_bytes_of(nslots), st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (st) hipStreamDestroy(st);
+        if (e != hipSuccess && p) {
+            hipFree(p);
+            p = nullptr;
+        }
+        idx->rsv_table = (Bucket *)p;
+        idx->rsv_err = (int)e;
+    });
+    return MQ_OK;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+}
+
+int64_t mq_index_finalize(mq_index *idx) try {
+    if (!idx) return set_err(MQ_EINVAL, "idx is NULL");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (idx->finalized) return (int64_t)idx->n_unique;
+    int rc = use_device(idx);
+    if (rc) return rc;
+    const bool timing = getenv("MQ_BUILD_TIMING") != nullptr;  // diagnostic: where the wall time of finalize goes (stderr)
+    auto tnow = [&]() {
+        if (timing) hipDeviceSynchronize();
+        return std::chrono::steady_clock::now();
+    };
+    auto t_0 = tnow();
+    // slots per inserted k-min-mer (power-of-two rounding on top); default 8 => load <= 0.125 (17 GB for a human genome, 6 % of
+    // the HBM).  ~85 % of a read's lookups miss, a miss walks to the first empty slot, and every extra step is one more dependent
+    // random access of a memory system that sustains ~52 G of them per second (tools/probe_rate.py).  Measured on the CHM13-like
+    // bench: factor 2: 926, 4: 1000, 8: 1034, 16: 1044, 32: 1051 Gbases/s.
+    const uint64_t nslots = table_slots_for(idx->n_kmm_total);
+    rsv_join(idx);
+    if (idx->rsv_table && idx->rsv_nslots == nslots && idx->rsv_err == 0) {  // the table mq_index_reserve allocated and cleared
+        if (idx->table) HIPCHK(hipFree(idx->table));
+        idx->table = idx->rsv_table;
+        idx->nslots = nslots;
+        idx->rsv_table = nullptr;
+    } else {
+        if (idx->rsv_table) {
+            HIPCHK(hipFree(idx->rsv_table));  // the estimate was off: the table is allocated now, at the size the reference needs
+            idx->rsv_table = nullptr;
+        }
+        rc = alloc_table(idx, nslots);
+        if (rc) return rc;
+    }
+    auto t_1 = tnow();
+    unsigned long long *d_acc = nullptr;
+    HIPCHK(hipMalloc((void **)&d_acc, 24));
+    HIPCHK(hipMemset(d_acc, 0, 24));
+    for (auto &c : idx->chunks) {
+        if (!c.n) continue;
+        const uint32_t nb = (uint32_t)std::min<uint64_t>((c.n + 255) / 256, 1u << 20);
+        hipLaunchKernelGGL(insert_kernel, dim3(nb), dim3(256), 0, 0, c.d, c.n, idx->table, nslots - 1, d_acc);
+        HIPCHK(hipGetLastError());
+    }
+    auto t_2 = tnow();
+    // Index::get_count (src/index.rs:90-92): keys claimed minus keys that turned dead, counted by the insertions themselves
+    unsigned long long acc[3] = {0, 0, 0};
+    HIPCHK(hipMemcpy(acc, d_acc, 24, hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(d_acc));
+    idx->n_keys = acc[0];
+    idx->n_unique = acc[0] - acc[1];
+    auto t_3 = tnow();
+    for (auto &c : idx->chunks)
+        if (c.d) hipFree(c.d);
+    idx->chunks.clear();
+    free_build_scratch(idx);
+    if (timing) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "mq_index_add_ref_device calls so far: %.2f ms\n", idx->t_add_ms);
+        fprintf(stderr, "mq_index_finalize: table alloc + clear %.2f ms (%.1f GB), insert %.2f ms (%llu k-min-mers), read back %.2f ms, free scratch %.2f ms\n", ms(t_0, t_1),
+                table_bytes_of(nslots) / 1e9, ms(t_1, t_2), (unsigned long long)idx->n_kmm_total, ms(t_2, t_3), ms(t_3, tnow()));
+    }
+    // ref_map lengths (src/closures.rs:49), dense by ref id
+    uint32_t max_id = 0;
+    for (auto &kv : idx->refs) max_id = std::max(max_id, kv.first);
+    std::vector<uint64_t> lens((size_t)max_id + 1, 0);
+    for (auto &kv : idx->refs) lens[kv.first] = kv.second.second;
+    HIPCHK(hipMalloc((void **)&idx->d_ref_lens, lens.size() * sizeof(uint64_t)));
+    HIPCHK(hipMemcpy(idx->d_ref_lens, lens.data(), lens.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    idx->finalized = true;
+    return (int64_t)idx->n_unique;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+}
+
+int mq_index_get_stats(const mq_index *idx, mq_index_stats *out) try {
+    if (!idx || !out) return set_err(MQ_EINVAL, "bad arguments");
+    out->n_refs = idx->refs.size();
+    out->n_kminmers = idx->n_kmm_total;
+    out->n_keys = idx->n_keys;
+    out->n_unique = idx->n_unique;
+    out->table_slots = idx->nslots;
+    out->table_bytes = table_bytes_of(idx->nslots);
+    out->slot_bytes = SLOT_BYTES;
+    return MQ_OK;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+}
+
+}  // extern "C"

@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include "../../include/mapquik_hip.h"
+#include "../../include/mapquik_hip_diag.h"
 
 namespace mq {
 
@@ -42,20 +43,23 @@ struct DevParams {
 //   slot s = bucket s >> 1, way s & 1;  key == 0 <=> empty (a real key 0 lives in way 0 of one extra bucket behind the table).
 // Probe sequence of a key (insert and lookup walk the same one; src/index.rs:11-39's identity hasher gives the home slot):
 //   home slot (key & mask), the other way of the home bucket, then the following buckets way 0, way 1, ...
-// A slot is live iff its key matches and pay.end != 0: finalize zeroes `end` of every slot whose key was inserted more than once
-// (the order-independent form of "second insert => tombstone", src/index.rs:94-104; is_empty <=> end == 0, src/index.rs:67-69),
-// so a lookup needs the 16 payload bytes only, and only for a key that matched.
+// A slot is live iff its key matches, pay.end != 0 and ENTRY_DUP is not set in pay.id_rc: a key inserted more than once gets the
+// bit while the table is built (the order-independent form of "second insert => tombstone", src/index.rs:94-104; is_empty <=>
+// end == 0, src/index.rs:67-69), so a lookup needs the 16 payload bytes only, and only for a key that matched.
 struct alignas(16) Entry {
     uint32_t start, end, offset, id_rc;
 };
 struct alignas(64) Bucket {
     unsigned long long key[2];
     Entry pay[2];
-    uint32_t count[2];  // times the key was inserted (kept for the statistics and the on-disk form)
     uint32_t claims;    // extra bucket only: insertions of the key 0 (its key field cannot tell "present" from "empty")
-    uint32_t pad;
+    uint32_t pad[3];
 };
 static_assert(sizeof(Bucket) == 64, "bucket size");
+// Entry::id_rc bit 31: the key was inserted more than once (or its entry's end is 0): the reference's tombstone, an entry that
+// compares as empty (src/index.rs:67-69, 94-104).  Set while the table is built (table_insert); reference ids stay below 2^24.
+constexpr uint32_t ENTRY_DUP = 0x80000000u;
+__device__ __forceinline__ bool entry_live(const Entry &e) { return e.end != 0u && !(e.id_rc & ENTRY_DUP); }
 constexpr uint32_t SLOT_BYTES = 32;  // table bytes per slot
 
 // reference k-min-mer waiting for insertion (same layout as mq_kminmer, rev field = id<<1|rc)
@@ -64,12 +68,6 @@ struct alignas(8) RefKmm {
     uint32_t start, end, offset, id_rc;
 };
 static_assert(sizeof(RefKmm) == 24, "RefKmm size");
-
-struct alignas(16) Minimizer {
-    unsigned long long hash;
-    uint32_t pos;
-    uint32_t pad;
-};
 
 // src/match.rs:10-18 plus the ref id of the run's first entry (src/mers.rs:68) and a "grouped" flag
 struct alignas(16) MatchRec {
@@ -273,7 +271,7 @@ __device__ __forceinline__ bool probe_table(const Bucket *__restrict__ table, ui
     const uint64_t nb = (mask + 1) >> 1;
     if (key == 0) {
         out = table[nb].pay[0];
-        return out.end != 0;
+        return entry_live(out);
     }
     const uint64_t s0 = key & mask;
     uint64_t b = s0 >> 1;
@@ -282,7 +280,7 @@ __device__ __forceinline__ bool probe_table(const Bucket *__restrict__ table, ui
         const unsigned long long k = table[b].key[w];
         if (k == key) {
             out = table[b].pay[w];
-            return out.end != 0;
+            return entry_live(out);
         }
         if (k == 0) return false;
         if (step == 0) {
@@ -378,7 +376,9 @@ __device__ __forceinline__ void seed_segment(const uint8_t *__restrict__ seq, ui
             hproc += 64u;
         }
         const bool end_of_seq = pos + 64 >= len;
-        const bool past = (pos + 64 >= b) && (hbase >= s_elig + l - 1u);
+        // behind b: done once the last eligible window is complete -- or at once when no run head lies in [a, b) at all (a segment inside
+        // a long homopolymer run has nothing to seed; without this it would read on to the end of the run, however far that is)
+        const bool past = (pos + 64 >= b) && (s_elig == 0u || hbase >= s_elig + l - 1u);
         if (end_of_seq || past) break;
     }
     if (hbase > hproc) process_block(hbase - hproc);
@@ -580,7 +580,9 @@ struct MapSink {
         q_start = q_end = 0;
         if (act) {
             auto get = [&](uint32_t i) { return (uint64_t)mzh[i0 + i]; };
-            key = P.k == 5u ? kminmer_hash_fixed<5>(get, rev) : kminmer_hash(P.k, get, rev);  // 5: the reference's default k (src/main.rs: -k 5)
+            // 5: the reference's default k (src/main.rs: -k 5); 7: experiments/table1.sh:50; 8: example/run_ecoli.sh:26
+            key = P.k == 5u ? kminmer_hash_fixed<5>(get, rev) : P.k == 7u ? kminmer_hash_fixed<7>(get, rev) : P.k == 8u ? kminmer_hash_fixed<8>(get, rev)
+                                                                                                              : kminmer_hash(P.k, get, rev);
             q_start = mzp[i0];
             q_end = mzp[i0 + P.k - 1] + P.l - 1u;
         }
@@ -827,7 +829,7 @@ struct MapSink {
                 e.end = kk[c].y;
                 e.offset = kk[c].z;
                 e.id_rc = kk[c].w;
-                const bool hit = ((st >> (2 * c)) & 3u) == 1u && e.end != 0;
+                const bool hit = ((st >> (2 * c)) & 3u) == 1u && entry_live(e);
                 batch_runs(n, key[c], ((revbits >> c) & 1u) != 0, qs, qe, hit, e);
             }
         }
@@ -845,31 +847,8 @@ struct MapSink {
 
 };
 
-// ------------------------------------------------------------------ sink of the reference path: ordered minimizers to HBM
-struct ListSink {
-    Minimizer *__restrict__ out;
-    uint32_t cap;
-    uint32_t written = 0;  // may exceed cap (overflow detected by the host)
-    __device__ ListSink(Minimizer *o, uint32_t c) : out(o), cap(c) {}
-    __device__ __forceinline__ void on_minimizers(WaveLds &S, uint32_t &mz_count) {
-        const uint32_t lane = lane_id();
-        for (uint32_t base = 0; base < mz_count; base += 64u) {
-            const uint32_t i = base + lane;
-            if (i < mz_count && written + i < cap) {
-                Minimizer m;
-                m.hash = S.mz_hash[i];
-                m.pos = S.mz_pos[i];
-                m.pad = 0;
-                out[written + i] = m;
-            }
-        }
-        written += mz_count;
-        mz_count = 0;
-        wave_sync();
-    }
-};
-
-// sink of the split pipeline's general seeder: ordered minimizers to the read's SoA list region (hash[], pos[])
+// sink of the general seeder when it writes lists: ordered minimizers to an SoA list region (hash[], pos[]) -- the split
+// pipeline's reads and the reference segments the fast seeder declined
 struct SoaListSink {
     unsigned long long *__restrict__ out_hash;
     uint32_t *__restrict__ out_pos;

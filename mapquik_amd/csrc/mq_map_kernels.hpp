@@ -1,0 +1,420 @@
+// mq_map_kernels.hpp -- the map path's kernels (part of the one translation unit mq_capi.hip): map_kernel (fused: seed + map phases of a read
+// back to back in one wave) and the same device functions as separate launches (MQ_PIPELINE=split, diagnostic).
+#pragma once
+
+// =================================================================== kernels
+
+// The map path.  One wave per read, persistent waves pulling read indices from an atomic counter.  Two phases per read:
+//   seed   read -> ordered minimizer list {hash, raw position} in the read's HBM region     (mq_seed.hpp for ACGT-only reads,
+//          the general streaming seeder seed_segment of mq_device.hpp for the rest)
+//   map    list -> k-min-mers -> index probe -> Match runs -> chain -> mq_hit                (MapSink, chain_stage)
+// map_kernel runs both phases back to back in the same wave (default): while one wave waits for its index probes (random
+// 32-B slot reads: ~42 G lookups/s is all the memory system gives, tools/probe_rate.py) the other waves of the SIMD seed.
+// MQ_PIPELINE=split runs the phases as three launches (seed_reads_kernel, seed_general_kernel, map_lists_kernel) so that a
+// profiler prices each phase by itself; same device functions, same results.
+// Read r's list lives at entries [base_r, base_r + cap_r) of mz_hash[] / mz_pos[]:
+//   base_r = ((o0_r - o0_0) * f16 >> 16) + slack * r,   cap_r = (len_r * f16 >> 16) + slack
+// (regions never overlap; f16/65536 = list entries reserved per base).  A list that outgrows its region (a read inside a
+// short-period tandem array can be far denser than 2 d) is written again, at its now known size, into an exact-size region
+// taken from a shared pool behind the regular regions.  Only when the pool is exhausted too does the read come back as
+// MQ_HIT_OVERFLOW (the host-buffer entry points then redo it with f16 = 65536).
+struct SplitArgs {
+    const uint8_t *bases;
+    const uint64_t *offsets;  // n + 1: read r starts at offsets[r]; offsets[n] = end of the buffer
+    const uint32_t *lens;     // null: read r ends at offsets[r + 1]; else its length (raw FASTX buffers: headers and quality lines in between)
+    uint32_t n;
+    DevParams P;
+    unsigned long long *mz_hash;
+    uint32_t *mz_pos;
+    uint32_t *mz_count;    // split pipeline only: list length of read r (or NOT_FAST / LIST_OVERFLOW)
+    uint64_t *mz_base;     // split pipeline only: where read r's list starts (its regular region or a pool region)
+    uint64_t pool_base, pool_cap;  // the pool: entries [pool_base, pool_base + pool_cap)
+    uint32_t f16, slack;
+    uint32_t *queue;       // split pipeline only: reads for the general seeder
+    uint32_t *counters;    // [0] seed work, [1] map work, [2] queue length, [3] general work, [4] fast reads, [5] general reads,
+                           // [6] lists moved to the pool, [12..13] 64-bit pool cursor
+    uint32_t force_general;
+    const Bucket *table;
+    uint64_t mask;
+    const uint64_t *ref_lens;
+    MatchRec *scratch_all;  // per mapping wave: cap_matches records
+    uint32_t cap_matches;
+    mq_hit *out;
+    mq_kminmer *dump;
+    const uint64_t *dump_off;
+    uint32_t *dump_counts;
+    unsigned long long *stats64;  // instrumented launch only: [0] slots visited beyond the home slot, [1] lookups
+};
+
+__device__ __forceinline__ void list_region(const SplitArgs &A, uint64_t o0_rel, uint64_t len, uint32_t r, uint64_t &base, uint32_t &cap) {
+    base = ((o0_rel * A.f16) >> 16) + (uint64_t)A.slack * r;
+    const uint64_t c = ((len * A.f16) >> 16) + A.slack;
+    cap = c > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)c;
+}
+constexpr uint32_t LIST_OVERFLOW = 0xFFFFFFFEu;  // list length value: the list fits neither its region nor the pool
+// an exact-size pool region for a list of cnt entries (wave-uniform); false when the pool is exhausted
+__device__ __forceinline__ bool pool_take(const SplitArgs &A, uint32_t cnt, uint64_t &base) {
+    unsigned long long at = 0;
+    if (lane_id() == 0) at = atomicAdd(reinterpret_cast<unsigned long long *>(A.counters + 12), (unsigned long long)cnt);
+    at = rdlane64(at, 0);
+    base = A.pool_base + at;
+    return at + cnt <= A.pool_cap;
+}
+
+// seed phase, fast seeder: list length, SD_NOT_FAST (declined: non-ACGT byte, ...) or LIST_OVERFLOW; base moves with the list
+template <int STOP = 0>
+__device__ __forceinline__ uint32_t seed_read_fast(const SplitArgs &A, const SeedTables &T, SeedLds &S, const uint8_t *seq,
+                                                   uint32_t len, uint64_t &base, uint32_t cap, uint32_t &n_moved, APre &pre, bool pre_valid) {
+    uint32_t cnt = seed_sequence_fast<STOP>(seq, len, A.P, T, S, A.mz_hash + base, A.mz_pos + base, cap, pre, pre_valid);
+    if (cnt != SD_NOT_FAST && cnt > cap) {  // denser than its region: once more, into an exact-size pool region
+        if (pool_take(A, cnt, base)) {
+            seed_sequence_fast(seq, len, A.P, T, S, A.mz_hash + base, A.mz_pos + base, cnt, pre, false);
+            n_moved++;
+        } else {
+            cnt = LIST_OVERFLOW;
+        }
+    }
+    return cnt;
+}
+
+// seed phase, general streaming seeder (any bytes, any length)
+__device__ __forceinline__ uint32_t seed_read_general(const SplitArgs &A, WaveLds &S, const uint8_t *seq, uint64_t len, uint64_t &base,
+                                                      uint32_t cap, uint32_t &n_moved) {
+    uint32_t cnt;
+    {
+        SoaListSink sink(A.mz_hash + base, A.mz_pos + base, cap);
+        uint32_t mz_count = 0;
+        seed_segment(seq, len, 0, len, A.P, S, sink, mz_count);
+        cnt = sink.written;
+    }
+    if (cnt > cap) {
+        if (pool_take(A, cnt, base)) {
+            SoaListSink sink(A.mz_hash + base, A.mz_pos + base, cnt);
+            uint32_t mz_count = 0;
+            seed_segment(seq, len, 0, len, A.P, S, sink, mz_count);
+            n_moved++;
+        } else {
+            cnt = LIST_OVERFLOW;
+        }
+    }
+    return cnt;
+}
+
+#ifndef MQ_ML_NB
+#define MQ_ML_NB 7
+#endif
+constexpr int ML_NB = MQ_ML_NB;                              // lane-batches of 64 k-min-mers hashed and probed together
+constexpr uint32_t ML_LIST_CAP = 64 * ML_NB + 64;      // minimizers staged in LDS at a time (64 * ML_NB + k - 1 used)
+struct MapListLds {
+    unsigned long long h[ML_LIST_CAP];
+    uint32_t p[ML_LIST_CAP];
+};
+
+// map phase of read r: its list (cnt entries at base) -> mq_hit
+// the read's result is left in h (all lanes hold it); store_hit() writes it: the fused kernel does that after it has taken the
+// prefetched offsets of its next read out of their registers, so that this store's acknowledgement is nothing a wave waits for
+__device__ __forceinline__ void store_hit(const SplitArgs &A, uint32_t r, const mq_hit &h) {
+    if (lane_id() == 0) {
+        A.out[r] = h;
+        if (A.dump_counts) A.dump_counts[r] = h.n_kminmers;
+    }
+}
+
+template <int CH, bool TIMING>
+__device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, MatchRec *scratch, uint32_t r, uint64_t len, uint32_t cnt,
+                                         uint64_t base, unsigned long long &t_steps, unsigned long long &t_lookups, mq_hit &h) {
+    const uint32_t lane = lane_id();
+    const DevParams &P = A.P;
+    h.status = MQ_HIT_UNMAPPED;
+    h.ref_id = h.rc = h.mapq = h.q_start = h.q_end = h.r_start = h.r_end = h.score = h.n_kminmers = h.q_start_hi = h.q_end_hi = 0;
+    uint32_t n_kmm = 0;
+    if (cnt == LIST_OVERFLOW) {
+        h.status = MQ_HIT_OVERFLOW;  // the list fits neither its region nor the pool: nothing was computed for this read
+    } else if (cnt >= P.k) {
+        mq_kminmer *d = nullptr;
+        uint32_t dcap = 0;
+        if (A.dump) {
+            d = A.dump + A.dump_off[r];
+            dcap = (uint32_t)(A.dump_off[r + 1] - A.dump_off[r]);
+        }
+        MapSink sink(A.table, A.mask, P, scratch, A.cap_matches, d, dcap);
+        const unsigned long long *lh = A.mz_hash + base;
+        const uint32_t *lp = A.mz_pos + base;
+        const uint32_t chunk = 64u * (uint32_t)ML_NB + P.k - 1u;
+        for (uint32_t g = 0; g + P.k <= cnt;) {
+            const uint32_t have = cnt - g < chunk ? cnt - g : chunk;
+            {  // L2-served loads (the list may have been written by this very wave), ALL in flight before the first is stored: one L2
+               // round trip per chunk (a loop that loads and stores 64 entries at a time exposes one per 64 entries)
+                unsigned long long hv[ML_NB + 1];
+                uint32_t pv[ML_NB + 1];
+#pragma unroll
+                for (int j = 0; j <= ML_NB; ++j) {
+                    const uint32_t i = lane + 64u * (uint32_t)j;
+                    hv[j] = 0;
+                    pv[j] = 0;
+                    if (i < have) {
+                        hv[j] = ld_sc1_u64(lh + g + i);
+                        pv[j] = ld_sc1_u32(lp + g + i);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j <= ML_NB; ++j) {
+                    const uint32_t i = lane + 64u * (uint32_t)j;
+                    if (i < have) {
+                        S.h[i] = hv[j];
+                        S.p[i] = pv[j];
+                    }
+                }
+            }
+            wave_sync();
+            mq_clk(5);
+            sink.template consume_list<ML_NB>(S.h, S.p, have);
+            wave_sync();
+            g += have - (P.k - 1u);
+        }
+        sink.finish_runs();
+        n_kmm = sink.kmm_count;
+        if (sink.n_matches > A.cap_matches) {
+            h.status = MQ_HIT_OVERFLOW;
+        } else if (sink.n_matches > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Match records written by this wave are in L2
+            wave_sync();
+            mq_clk(8);
+            chain_stage<CH>(scratch, sink.n_matches, P, len, A.ref_lens, h);
+        }
+        if (TIMING) {
+            t_steps += wave_sum_u32(sink.probe_steps);
+            t_lookups += n_kmm;
+        }
+    }
+    h.n_kminmers = n_kmm;
+    mq_clk(9);
+}
+
+#ifndef MQ_MAP_WAVES
+#define MQ_MAP_WAVES 8
+#endif
+#ifndef MQ_MAP_MIN_WAVES
+#define MQ_MAP_MIN_WAVES 4
+#endif
+constexpr int MAP_WAVES = MQ_MAP_WAVES;
+
+// per-wave LDS of the fused kernel: the phases of one read follow each other, so they share the memory
+union MapWaveLds {
+    SeedLds seed;
+    WaveLds general;
+    MapListLds map;
+};
+
+// CH: lanes per chunk in the chain stage (64 in production; 4 only in tests so that ordinary reads take the multi-chunk path)
+template <int CH, bool TIMING = false>
+__global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(const SplitArgs A) {
+    // one block of LDS with the tables FIRST: T.rot's entries are addressed through the 16-bit immediate offset of ds_read_b128
+    __shared__ struct {
+        SeedTables T;
+        MapWaveLds SS[MAP_WAVES];
+    } W;
+    SeedTables &T = W.T;
+    MapWaveLds(&SS)[MAP_WAVES] = W.SS;
+    build_seed_tables(T, A.P.l);
+    __syncthreads();  // the only workgroup-wide rendezvous; waves are independent from here on
+    const uint32_t lane = lane_id();
+    const uint32_t wv = rdfirst(threadIdx.x >> 6);  // wave-uniform: per-wave bases stay in SGPRs
+    MapWaveLds &S = SS[wv];
+    const size_t wave_gid = (size_t)blockIdx.x * MAP_WAVES + wv;
+    MatchRec *scratch = A.scratch_all + wave_gid * A.cap_matches;
+    const DevParams &P = A.P;
+    const uint64_t o_base = A.offsets[0];
+    uint32_t n_fast = 0, n_general = 0, n_moved = 0;
+    unsigned long long t_steps = 0, t_lookups = 0;
+#ifdef MQ_STAGE_CLOCKS
+    if (lane == 0)
+        for (int i = 0; i < MQ_N_CLK; ++i) mq_clk_lds().acc[wv][i] = 0;
+    mq_clk(-1);
+#endif
+    // The work item after the current one is fetched while the current one is processed: its index (one atomic) during the seed
+    // phase, its offsets during the map phase -- two dependent memory round trips per read that no wave waits for.  (Requesting
+    // the next read's first super-row across the map phase as well was measured at -3 %: a wave's loads return in order, so the
+    // map phase's first wait -- an L2 round trip for the list -- then sits behind an HBM one.)
+    uint32_t r = 0;
+    if (lane == 0) r = atomicAdd(&A.counters[0], 1u);
+    r = rdfirst(r);
+    uint64_t o0 = 0, len = 0;
+    if (r < A.n) {
+        o0 = A.offsets[r];
+        len = A.lens ? (uint64_t)A.lens[r] : A.offsets[r + 1] - o0;
+    }
+    while (r < A.n) {
+        uint32_t rn_v = 0;
+        if (lane == 0) rn_v = atomicAdd(&A.counters[0], 1u);
+        uint32_t cnt = 0;
+        uint64_t base = 0;
+        mq_clk(11);
+        // extract(): len < l + k - 1 => None (src/mers.rs:44)
+        if (len >> 32) {
+            cnt = LIST_OVERFLOW;  // beyond the documented limit (checked on the host where the host sees the lengths): loud, not wrong
+        } else if (len >= (uint64_t)P.l + P.k - 1u) {
+            uint32_t cap;
+            list_region(A, o0 - o_base, len, r, base, cap);
+            APre pre;
+            cnt = A.force_general ? SD_NOT_FAST : seed_read_fast(A, T, S.seed, A.bases + o0, (uint32_t)len, base, cap, n_moved, pre, false);
+            if (cnt == SD_NOT_FAST) {
+                n_general++;
+                wave_sync();
+                cnt = seed_read_general(A, S.general, A.bases + o0, len, base, cap, n_moved);
+                mq_clk(10);
+            } else {
+                n_fast++;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have reached L2
+            wave_sync();
+            mq_clk(4);
+        }
+        const uint32_t rn = rdfirst(rn_v);
+        unsigned long long n_o0 = 0, n_o1 = 0;
+        uint32_t n_len = 0;
+        if (lane == 0 && rn < A.n) {  // vector loads by one lane: in flight through the map phase (scalar loads would be waited for at its first LDS wait)
+            n_o0 = A.offsets[rn];
+            if (A.lens) n_len = A.lens[rn];
+            else n_o1 = A.offsets[rn + 1];
+        }
+        mq_hit h;
+        map_read<CH, TIMING>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h);
+        wave_sync();
+        const uint32_t r_done = r;
+        r = rn;
+        o0 = rdlane64(n_o0, 0);
+        len = A.lens ? (uint64_t)rdfirst(n_len) : rdlane64(n_o1, 0) - o0;
+        asm volatile("" ::: "memory");  // the prefetched offsets are out of their registers before the result's store is issued
+        store_hit(A, r_done, h);
+    }
+    if (lane == 0) {
+        if (n_fast) atomicAdd(&A.counters[4], n_fast);
+        if (n_general) atomicAdd(&A.counters[5], n_general);
+        if (n_moved) atomicAdd(&A.counters[6], n_moved);
+        if (TIMING) {
+            atomicAdd(&A.stats64[0], t_steps);
+            atomicAdd(&A.stats64[1], t_lookups);
+        }
+#ifdef MQ_STAGE_CLOCKS
+        for (int i = 0; i < MQ_N_CLK; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(A.counters + 16) + i, mq_clk_lds().acc[wv][i]);
+#endif
+    }
+}
+
+// ------------------------------------------------------------------- the same phases as separate launches (MQ_PIPELINE=split)
+#ifndef MQ_SEED_MIN_WAVES
+#define MQ_SEED_MIN_WAVES 4
+#endif
+#ifndef MQ_SEED_WAVES
+#define MQ_SEED_WAVES 8
+#endif
+constexpr int SEED_WAVES = MQ_SEED_WAVES;
+
+template <int STOP = 0>
+__global__ __launch_bounds__(64 * SEED_WAVES, MQ_SEED_MIN_WAVES) void seed_reads_kernel(const SplitArgs A) {
+    __shared__ struct {
+        SeedTables T;
+        SeedLds SS[SEED_WAVES];
+    } W;
+    SeedTables &T = W.T;
+    SeedLds(&SS)[SEED_WAVES] = W.SS;
+    build_seed_tables(T, A.P.l);
+    __syncthreads();
+    const uint32_t lane = lane_id();
+    const uint32_t wv = rdfirst(threadIdx.x >> 6);  // wave-uniform: per-wave bases stay in SGPRs
+    SeedLds &S = SS[wv];
+    const size_t wave_gid = (size_t)blockIdx.x * SEED_WAVES + wv;
+    const DevParams &P = A.P;
+    const uint64_t o_base = A.offsets[0];
+    uint32_t n_fast = 0, n_general = 0, n_moved = 0;
+    for (;;) {
+        uint32_t r = 0;
+        if (lane == 0) r = atomicAdd(&A.counters[0], 1u);
+        r = rdfirst(r);
+        if (r >= A.n) break;
+        const uint64_t o0 = A.offsets[r];
+        const uint64_t len = A.lens ? (uint64_t)A.lens[r] : A.offsets[r + 1] - o0;
+        uint32_t cnt = 0;
+        uint64_t base = 0;
+        if (len >> 32) {
+            cnt = LIST_OVERFLOW;
+        } else if (len >= (uint64_t)P.l + P.k - 1u) {
+            uint32_t cap;
+            list_region(A, o0 - o_base, len, r, base, cap);
+            APre pre;
+            cnt = A.force_general ? SD_NOT_FAST : seed_read_fast<STOP>(A, T, S, A.bases + o0, (uint32_t)len, base, cap, n_moved, pre, false);
+            if (cnt == SD_NOT_FAST) n_general++;
+            else n_fast++;
+        }
+        if (lane == 0) {
+            A.mz_count[r] = cnt;
+            A.mz_base[r] = base;
+            if (cnt == SD_NOT_FAST) A.queue[atomicAdd(&A.counters[2], 1u)] = r;
+        }
+        wave_sync();
+    }
+    if (lane == 0) {
+        if (n_fast) atomicAdd(&A.counters[4], n_fast);
+        if (n_general) atomicAdd(&A.counters[5], n_general);
+        if (n_moved) atomicAdd(&A.counters[6], n_moved);
+    }
+}
+
+// the reads queued by seed_reads_kernel, through the general streaming seeder
+__global__ __launch_bounds__(64) void seed_general_kernel(const SplitArgs A) {
+    __shared__ WaveLds S;
+    const uint32_t lane = lane_id();
+    const uint32_t nq = A.counters[2];
+    const uint64_t o_base = A.offsets[0];
+    uint32_t n_moved = 0;
+    for (;;) {
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(&A.counters[3], 1u);
+        i = rdfirst(i);
+        if (i >= nq) break;
+        const uint32_t r = A.queue[i];
+        const uint64_t o0 = A.offsets[r];
+        const uint64_t len = A.lens ? (uint64_t)A.lens[r] : A.offsets[r + 1] - o0;
+        uint64_t base;
+        uint32_t cap;
+        list_region(A, o0 - o_base, len, r, base, cap);
+        const uint32_t cnt = seed_read_general(A, S, A.bases + o0, len, base, cap, n_moved);
+        if (lane == 0) {
+            A.mz_count[r] = cnt;
+            A.mz_base[r] = base;
+        }
+        wave_sync();
+    }
+    if (lane == 0 && n_moved) atomicAdd(&A.counters[6], n_moved);
+}
+
+#ifndef MQ_ML_MIN_WAVES
+#define MQ_ML_MIN_WAVES 5
+#endif
+constexpr int ML_WAVES = 4;
+
+template <int CH, bool TIMING = false>
+__global__ __launch_bounds__(64 * ML_WAVES, MQ_ML_MIN_WAVES) void map_lists_kernel(const SplitArgs A) {
+    __shared__ MapListLds SS[ML_WAVES];
+    const uint32_t lane = lane_id();
+    const uint32_t wv = rdfirst(threadIdx.x >> 6);  // wave-uniform: per-wave bases stay in SGPRs
+    const size_t wave_gid = (size_t)blockIdx.x * ML_WAVES + wv;
+    MatchRec *scratch = A.scratch_all + wave_gid * A.cap_matches;
+    unsigned long long t_steps = 0, t_lookups = 0;
+    for (;;) {
+        uint32_t r = 0;
+        if (lane == 0) r = atomicAdd(&A.counters[1], 1u);
+        r = rdfirst(r);
+        if (r >= A.n) break;
+        const uint64_t len = A.lens ? (uint64_t)A.lens[r] : A.offsets[r + 1] - A.offsets[r];
+        mq_hit h;
+        map_read<CH, TIMING>(A, SS[wv], scratch, r, len, A.mz_count[r], A.mz_base[r], t_steps, t_lookups, h);
+        store_hit(A, r, h);
+        wave_sync();
+    }
+    if (TIMING && lane == 0) {
+        atomicAdd(&A.stats64[0], t_steps);
+        atomicAdd(&A.stats64[1], t_lookups);
+    }
+}

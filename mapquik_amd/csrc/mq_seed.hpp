@@ -176,6 +176,13 @@ __device__ __forceinline__ uint4 load_piece(const uint8_t *__restrict__ seq, uin
 struct APre {
     uint4 nx0, nx1, nx2, nx3;
 };
+// A window of a longer sequence seeded as a sequence of its own (the reference segments of the index build): what differs from a read.
+struct SeedView {
+    uint32_t first_prev;  // 2-bit code of the base in front of the view; 4: none, or not A C G T (the view's first base is a run head)
+    uint32_t elig_end;    // only minimizers whose l-mer starts at a view-relative raw position < elig_end are listed (a multiple of 64)
+    uint32_t pos_add;     // added to every listed position: the view's offset in the sequence
+    uint32_t more_after;  // the sequence goes on behind the view: the bases from elig_end on must hold l - 1 run heads (else: declined)
+};
 __device__ __forceinline__ void stage_a_request(const uint8_t *__restrict__ seq, uint32_t len, uint32_t raw0, APre &pre) {
     const uint32_t pos = raw0 + lane_id() * 64u;
     pre.nx0 = load_piece(seq, len, pos);
@@ -189,7 +196,7 @@ __device__ __forceinline__ void stage_a_request(const uint8_t *__restrict__ seq,
 // Returns false on a byte other than A C G T.
 __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, uint32_t len, uint32_t raw0, uint32_t carry_n,
                                              uint32_t &carry_prev, bool use_hpc, bool fold, const SeedTables &T, SeedLds &S, uint32_t &n_codes,
-                                             uint32_t &n_blocks, uint32_t &raw_end, APre &pre) {
+                                             uint32_t &n_blocks, uint32_t &raw_end, APre &pre, bool first_is_head = true) {
     const uint32_t lane = lane_id();
     uint32_t n_sr = (len - raw0 + SD_SR_RAW - 1u) / SD_SR_RAW;
     if (n_sr > SD_MAX_SR) n_sr = SD_MAX_SR;
@@ -225,7 +232,8 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
         if (use_hpc) {
             // code of the base before this lane's block: the previous lane's last base (DPP wave_shr:1), lane 0 takes the carry
             uint32_t pc = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(p[3] >> 30), 0x138, 0xf, 0xf, false);
-            if (lane == 0) pc = (sr == 0 && raw0 == 0) ? ((p[0] & 3u) ^ 1u) : carry_prev;  // first base of the sequence is always a head
+            // first base of the sequence is always a head (a view's: unless the base in front of it is the same, carried in carry_prev)
+            if (lane == 0) pc = (sr == 0 && raw0 == 0 && first_is_head) ? ((p[0] & 3u) ^ 1u) : carry_prev;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t q = (p[j] << 2) | pc;
@@ -322,8 +330,55 @@ __device__ __forceinline__ Hash2 window_hash_fixed(const SeedTables &T, const Se
     return h;
 }
 
+// The same for l = 4 NQ + r, NQ known at compile time, r = l mod 4 at run time (wave-uniform): the NQ quad look-ups and the
+// remainder's are in flight together; nothing loops.
+template <uint32_t NQ>
+__device__ __forceinline__ Hash2 window_hash_q(const SeedTables &T, const SeedLds &S, uint32_t l, uint32_t a) {
+    constexpr uint32_t NDW = (4u * NQ + 3u + 15u) / 16u;
+    const uint32_t rem = l & 3u;
+    uint32_t c[NDW + 1];
+#pragma unroll
+    for (uint32_t m = 0; m <= NDW; ++m) c[m] = S.codes[(a >> 4) + m];
+    uint32_t dw[NDW];
+#pragma unroll
+    for (uint32_t m = 0; m < NDW; ++m) dw[m] = __builtin_amdgcn_alignbit(c[m + 1], c[m], 2u * (a & 15u));
+    uint4 tv[NQ + 1];
+#pragma unroll
+    for (uint32_t q = 0; q < NQ; ++q) tv[q] = T.quad[(dw[q >> 2] >> (8u * (q & 3u))) & 0xFFu];
+    tv[NQ] = T.rem[(dw[NQ >> 2] >> (8u * (NQ & 3u))) & ((1u << (2u * rem)) - 1u)];  // entry 0 (unused) when rem == 0
+    Hash2 h = {tv[0].x, tv[0].y, tv[0].z, tv[0].w};
+#pragma unroll
+    for (uint32_t q = 1; q < NQ; ++q) {
+        const uint32_t nfhi = __builtin_amdgcn_alignbit(h.fhi, h.flo, 28), nflo = __builtin_amdgcn_alignbit(h.flo, h.fhi, 28);  // rol 4
+        const uint32_t nrlo = __builtin_amdgcn_alignbit(h.rhi, h.rlo, 4), nrhi = __builtin_amdgcn_alignbit(h.rlo, h.rhi, 4);    // ror 4
+        h.flo = nflo ^ tv[q].x;
+        h.fhi = nfhi ^ tv[q].y;
+        h.rlo = nrlo ^ tv[q].z;
+        h.rhi = nrhi ^ tv[q].w;
+    }
+    if (rem) {
+        const uint32_t nfhi = __builtin_amdgcn_alignbit(h.fhi, h.flo, 32u - rem), nflo = __builtin_amdgcn_alignbit(h.flo, h.fhi, 32u - rem);
+        const uint32_t nrlo = __builtin_amdgcn_alignbit(h.rhi, h.rlo, rem), nrhi = __builtin_amdgcn_alignbit(h.rlo, h.rhi, rem);
+        h.flo = nflo ^ tv[NQ].x;
+        h.fhi = nfhi ^ tv[NQ].y;
+        h.rlo = nrlo ^ tv[NQ].z;
+        h.rhi = nrhi ^ tv[NQ].w;
+    }
+    return h;
+}
+
 __device__ __forceinline__ Hash2 window_hash(const SeedTables &T, const SeedLds &S, uint32_t l, uint32_t a) {
     if (l == 31u) return window_hash_fixed<31>(T, S, a);  // the reference's default l (src/main.rs: -l 31) and every BASELINE configuration
+    // the other window lengths the reference's scripts use (example/run_ecoli.sh:26 -l 16, the second pass's -l 14, the l sweep of
+    // experiments/figure-k-l): 12 <= l < 32 by the number of whole quads; anything else through the loop below
+    switch (l >> 2) {
+        case 3: return window_hash_q<3>(T, S, l, a);
+        case 4: return window_hash_q<4>(T, S, l, a);
+        case 5: return window_hash_q<5>(T, S, l, a);
+        case 6: return window_hash_q<6>(T, S, l, a);
+        case 7: return window_hash_q<7>(T, S, l, a);
+        default: break;
+    }
     Hash2 h = {0, 0, 0, 0};
     for (uint32_t m0 = 0; m0 < l; m0 += 16u) {
         const uint32_t d = (a + m0) >> 4;
@@ -397,11 +452,24 @@ __device__ __forceinline__ uint32_t stage_b_block(const SeedTables &T, uint32_t 
             const uint32_t fh = TT == 0 ? ghi : TT < 32 ? __builtin_amdgcn_alignbit(ghi, glo, 32u - TT) : TT == 32 ? glo : __builtin_amdgcn_alignbit(glo, ghi, 64u - TT);
             const uint32_t rh = TT == 0 ? hhi : TT < 32 ? __builtin_amdgcn_alignbit(hlo, hhi, TT) : TT == 32 ? hlo : __builtin_amdgcn_alignbit(hhi, hlo, TT - 32u);
             const uint32_t mhi = fh < rh ? fh : rh;
-            // fbits = 2 * fbits + (mhi <= bhi): v_cmp into vcc, v_addc with vcc as carry-in (high words only; the exact test runs in stage R)
-            asm("v_cmp_ge_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(fbits) : "v"(mhi), "s"(bhi) : "vcc");
             const uint4 e = tv[t & 3u];
-            // four plain v_xor_b32 (as asm: left to itself the SLP vectoriser pairs the words and, for the swapped halves,
-            // first materialises the swap with two v_pk_mov_b32 per step -- 1 more VALU per step on average)
+            // fbits = 2 * fbits + (mhi <= bhi): v_cmp into vcc, v_addc with vcc as carry-in (high words only; the exact test runs in
+            // stage R) -- with the step's four xors BETWEEN the two: back to back the pair costs a third of the step (an instruction that
+            // reads vcc right behind the one that wrote it; tools/valu_enc.hip, profiles/r04_valu_enc_stepb.txt: 30 -> 22 cycles per step).
+            // The xors are plain v_xor_b32 in asm anyway: left to itself the SLP vectoriser pairs the words and, for the swapped halves,
+            // first materialises the swap with two v_pk_mov_b32 per step.
+#ifndef MQ_SD_FLAG_PAIR_ADJACENT
+            if (((TT + 1u) & 63u) < 32u) {
+                asm("v_cmp_ge_u32_e32 vcc, %10, %9\n\tv_xor_b32 %0, %0, %5\n\tv_xor_b32 %1, %1, %6\n\tv_xor_b32 %2, %2, %7\n\tv_xor_b32 %3, %3, %8\n\t"
+                    "v_addc_co_u32_e32 %4, vcc, %4, %4, vcc"
+                    : "+v"(glo), "+v"(ghi), "+v"(hlo), "+v"(hhi), "+v"(fbits) : "v"(e.x), "v"(e.y), "v"(e.z), "v"(e.w), "v"(mhi), "s"(bhi) : "vcc");
+            } else {  // rotation by s + 32: the stored entry with its halves swapped
+                asm("v_cmp_ge_u32_e32 vcc, %10, %9\n\tv_xor_b32 %0, %0, %5\n\tv_xor_b32 %1, %1, %6\n\tv_xor_b32 %2, %2, %7\n\tv_xor_b32 %3, %3, %8\n\t"
+                    "v_addc_co_u32_e32 %4, vcc, %4, %4, vcc"
+                    : "+v"(glo), "+v"(ghi), "+v"(hlo), "+v"(hhi), "+v"(fbits) : "v"(e.y), "v"(e.x), "v"(e.w), "v"(e.z), "v"(mhi), "s"(bhi) : "vcc");
+            }
+#else
+            asm("v_cmp_ge_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(fbits) : "v"(mhi), "s"(bhi) : "vcc");
             if (((TT + 1u) & 63u) < 32u) {
                 asm("v_xor_b32 %0, %0, %4\n\tv_xor_b32 %1, %1, %5\n\tv_xor_b32 %2, %2, %6\n\tv_xor_b32 %3, %3, %7"
                     : "+v"(glo), "+v"(ghi), "+v"(hlo), "+v"(hhi) : "v"(e.x), "v"(e.y), "v"(e.z), "v"(e.w));
@@ -409,6 +477,7 @@ __device__ __forceinline__ uint32_t stage_b_block(const SeedTables &T, uint32_t 
                 asm("v_xor_b32 %0, %0, %4\n\tv_xor_b32 %1, %1, %5\n\tv_xor_b32 %2, %2, %6\n\tv_xor_b32 %3, %3, %7"
                     : "+v"(glo), "+v"(ghi), "+v"(hlo), "+v"(hhi) : "v"(e.y), "v"(e.x), "v"(e.w), "v"(e.z));
             }
+#endif
             // the look-up of step t + 4 (rotation (TT + 5) mod 64), in flight while the next steps run
             const uint32_t s4 = (TT + 5u) & 31u;
             tv[t & 3u] = (t + 4u < 16u) ? rot_at(s4, off16(xe, xo, t + 4u)) : rot_at(s4, off16(xe_n, xo_n, t + 4u - 16u));
@@ -571,12 +640,14 @@ __device__ __forceinline__ uint32_t seed_rawpos_batch(const SeedLds &S, uint32_t
 // Every lane first writes the windows of its own candidates to their places in the list (its flags are in registers: lowest
 // set bit, clear, next), so that a candidate's lane afterwards reads ONE value and starts its look-ups -- no search for the owning
 // lane, no bit select in another lane's flags.
+template <bool VIEW = false>
 __device__ __forceinline__ uint32_t seed_stage_r(const SeedTables &T, SeedLds &S, const DevParams &P, uint32_t w_eff,
                                                  uint32_t n_blocks, uint32_t n_codes, uint32_t raw_base, uint32_t carry_n,
                                                  unsigned long long *__restrict__ mz_hash, uint32_t *__restrict__ mz_pos, uint32_t out_base,
-                                                 uint32_t out_cap, bool &inexact) {
+                                                 uint32_t out_cap, bool &inexact, const SeedView &V = SeedView()) {
     const uint32_t lane = lane_id();
     const uint32_t lc = (w_eff + 63u) >> 6;
+    uint32_t n_listed = 0;  // VIEW: candidates that start before V.elig_end (positions ascend: they come first)
     // this lane's flags as 32-step words, masked to its real windows (steps [0, nv)): words and lanes stage B did not write hold
     // stale bits, all of them beyond nv
     constexpr uint32_t NW = SD_FLAG_WORDS;
@@ -623,16 +694,18 @@ __device__ __forceinline__ uint32_t seed_stage_r(const SeedTables &T, SeedLds &S
                 const uint64_t hv = F < R ? F : R;
                 if (hv > P.bound) inexact = true;
                 const uint32_t dest = out_base + i;
-                if (dest < out_cap) {
+                const bool listed = !VIEW || pos < V.elig_end;
+                if (listed && dest < out_cap) {
                     mz_hash[dest] = hv;
-                    mz_pos[dest] = pos;
+                    mz_pos[dest] = VIEW ? pos + V.pos_add : pos;
                 }
+                if (VIEW) n_listed += (uint32_t)__popcll(__ballot(listed));
             }
         }
         wave_sync();
     }
     inexact = __ballot(inexact) != 0;
-    return total;
+    return VIEW ? rdfirst(n_listed) : total;
 }
 
 // Whole sequence through the fast path, tile by tile.  Returns the number of minimizers (may exceed out_cap: overflow, the
@@ -643,19 +716,30 @@ constexpr uint32_t SD_NOT_FAST = 0xFFFFFFFFu;
 // a sequence the fast path takes at all (stage A reads whole 16-byte pieces; its tail piece is the 16 bytes that end at len)
 __device__ __forceinline__ bool seed_fast_eligible(uint64_t len) { return len >= 16u && (len >> 32) == 0; }
 // pre / pre_valid: the sequence's first super-row already requested by the caller (stage_a_request); else it is requested here.
-template <int STOP = 0>
+// VIEW: seq[0, len) is a window of a longer sequence (SeedView): only the minimizers that start before V.elig_end are listed and
+// counted, positions are shifted by V.pos_add, the base in front of the view decides whether its first base is a run head.
+template <int STOP = 0, bool VIEW = false>
 __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict__ seq, uint32_t len, const DevParams &P, const SeedTables &T,
                                                        SeedLds &S, unsigned long long *__restrict__ mz_hash,
-                                                       uint32_t *__restrict__ mz_pos, uint32_t out_cap, APre &pre, bool pre_valid) {
+                                                       uint32_t *__restrict__ mz_pos, uint32_t out_cap, APre &pre, bool pre_valid,
+                                                       const SeedView &V = SeedView()) {
     const uint32_t lane = lane_id();
-    uint32_t raw0 = 0, carry_n = 0, carry_prev = 0, n_out = 0;
+    uint32_t raw0 = 0, carry_n = 0, carry_prev = VIEW ? (V.first_prev & 3u) : 0u, n_out = 0;
+    uint32_t halo_heads = 0;  // VIEW: run heads at or behind V.elig_end
     if (!seed_fast_eligible(len)) return SD_NOT_FAST;
     if (!pre_valid) stage_a_request(seq, len, 0, pre);
     while (raw0 < len) {
         uint32_t n_codes = 0, n_blocks = 0, raw_end = 0;
-        const bool ok = seed_stage_a(seq, len, raw0, carry_n, carry_prev, P.use_hpc != 0, P.fold != 0, T, S, n_codes, n_blocks, raw_end, pre);
+        const bool ok = seed_stage_a(seq, len, raw0, carry_n, carry_prev, P.use_hpc != 0, P.fold != 0, T, S, n_codes, n_blocks, raw_end, pre,
+                                     !VIEW || V.first_prev >= 4u);
         mq_clk(0);
         if (!ok) return SD_NOT_FAST;
+        if (VIEW && V.more_after) {  // every l-mer that starts before elig_end must END inside the view: l - 1 run heads behind elig_end do it
+            uint32_t c = 0;
+            for (uint32_t k = lane; k < n_blocks; k += 64u)
+                if (raw0 + 64u * k >= V.elig_end) c += (uint32_t)__popcll(S.heads[k]);
+            halo_heads += wave_sum_u32(c);
+        }
         const bool more = raw_end < len;
         if (STOP != 1 && n_codes >= P.l) {
             const uint32_t w_eff = n_codes - P.l + 1u;
@@ -663,7 +747,7 @@ __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict
             mq_clk(1);
             if (STOP != 2) {
                 bool inexact = false;
-                n_out += seed_stage_r(T, S, P, w_eff, n_blocks, n_codes, raw0, carry_n, mz_hash, mz_pos, n_out, out_cap, inexact);
+                n_out += seed_stage_r<VIEW>(T, S, P, w_eff, n_blocks, n_codes, raw0, carry_n, mz_hash, mz_pos, n_out, out_cap, inexact, V);
                 mq_clk(2);
                 if (inexact) return SD_NOT_FAST;
             }
@@ -689,6 +773,7 @@ __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict
         raw0 = raw_end;
         mq_clk(3);
     }
+    if (VIEW && V.more_after && halo_heads + 1u < P.l) return SD_NOT_FAST;  // too few run heads behind elig_end (long homopolymer runs): the general seeder takes the segment
     return n_out;
 }
 

@@ -27,6 +27,10 @@ struct mq_ctx {
     mq_index *idx;
     std::thread worker;
     bool pending = false;
+    // mq_ctx_submit_fasta / mq_ctx_wait_fasta: line ends and hits of the chunk in flight
+    std::vector<uint32_t> fx_lines;
+    std::vector<mq_hit> fx_hits;
+    uint32_t fx_flags = 0;
 };
 static thread_local std::string g_err;
 
@@ -76,6 +80,7 @@ int64_t mq_index_add_ref(mq_index *i, uint32_t id, const char *name, const uint8
     i->n_kmm += len / 100 + (sum & 1);
     return (int64_t)(len / 100);
 }
+int mq_index_reserve(mq_index *, uint64_t) { return MQ_OK; }
 int64_t mq_index_finalize(mq_index *i) { i->finalized = true; return (int64_t)i->n_kmm; }
 mq_index *mq_index_clone(const mq_index *s, int device) {
     mq_index *i = new mq_index(*s);
@@ -86,6 +91,13 @@ int mq_index_get_stats(const mq_index *i, mq_index_stats *o) {
     memset(o, 0, sizeof(*o));
     o->n_refs = i->refs.size();
     o->n_unique = i->n_kmm;
+    return MQ_OK;
+}
+int mq_index_ref_info(const mq_index *i, uint32_t ref_id, const char **name, uint64_t *len) {
+    auto it = i->refs.find(ref_id);
+    if (it == i->refs.end()) { g_err = "unknown ref_id"; return MQ_EINVAL; }
+    if (name) *name = it->second.first.c_str();
+    if (len) *len = it->second.second;
     return MQ_OK;
 }
 int mq_index_save(const mq_index *, const char *) { g_err = "stub"; return MQ_EINVAL; }
@@ -111,6 +123,44 @@ int mq_ctx_submit_spans(mq_ctx *c, const uint8_t *buf, uint64_t bytes, const uin
     });
     return MQ_OK;
 }
+// the device's record scan, on the host: line ends of buf[begin, bytes), two lines per record, '>' in front of every header
+int mq_ctx_submit_fasta(mq_ctx *c, const uint8_t *buf, uint64_t begin, uint64_t bytes) {
+    if (c->pending) { g_err = "context has a submitted batch"; return MQ_ESTATE; }
+    c->pending = true;
+    c->worker = std::thread([=]() {
+        c->fx_lines.clear();
+        c->fx_hits.clear();
+        c->fx_flags = 0;
+        for (uint64_t p = begin; p < bytes; ++p)
+            if (buf[p] == '\n') c->fx_lines.push_back((uint32_t)p);
+        if (bytes > begin && buf[bytes - 1] != '\n') c->fx_lines.push_back((uint32_t)bytes);
+        if (c->fx_lines.size() & 1) c->fx_flags = MQ_FASTA_IRREGULAR;
+        const size_t n = c->fx_lines.size() / 2;
+        for (size_t i = 0; i < n && !c->fx_flags; ++i) {
+            const uint64_t hs = i ? (uint64_t)c->fx_lines[2 * i - 1] + 1 : begin, he = c->fx_lines[2 * i], ss = he + 1;
+            if (hs >= he || buf[hs] != '>' || (ss < c->fx_lines[2 * i + 1] && buf[ss] == '>')) c->fx_flags = MQ_FASTA_IRREGULAR;
+        }
+        if (c->fx_flags) return;
+        c->fx_hits.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            const uint64_t ss = (uint64_t)c->fx_lines[2 * i] + 1;
+            uint64_t e = c->fx_lines[2 * i + 1];
+            if (e > ss && buf[e - 1] == '\r') --e;
+            canned(c->idx, buf, ss, (uint32_t)(e - ss), &c->fx_hits[i]);
+        }
+    });
+    return MQ_OK;
+}
+int mq_ctx_wait_fasta(mq_ctx *c, uint32_t *n_reads, const uint32_t **line_ends, uint32_t *n_lines, const mq_hit **hits, uint32_t *flags) {
+    if (c->worker.joinable()) c->worker.join();
+    c->pending = false;
+    *flags = c->fx_flags;
+    *n_reads = c->fx_flags ? 0 : (uint32_t)c->fx_hits.size();
+    *n_lines = c->fx_flags ? 0 : (uint32_t)c->fx_lines.size();
+    *line_ends = c->fx_flags ? nullptr : c->fx_lines.data();
+    *hits = c->fx_flags ? nullptr : c->fx_hits.data();
+    return MQ_OK;
+}
 int mq_ctx_wait(mq_ctx *c) {
     if (c->worker.joinable()) c->worker.join();
     c->pending = false;
@@ -126,4 +176,6 @@ int mq_format_paf(const mq_index *i, const char *q_id, uint64_t q_len, const mq_
 }
 void *mq_host_alloc(size_t n) { return malloc(n ? n : 1); }
 void mq_host_free(void *p) { free(p); }
+int mq_host_register(void *, size_t) { return MQ_OK; }
+int mq_host_unregister(void *) { return MQ_OK; }
 }

@@ -16,11 +16,29 @@ def lib():
     return mapquik_amd.load_library()
 
 
-def _declared_functions():
-    txt = open(os.path.join(ROOT, "include", "mapquik_hip.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    names = set(re.findall(r"\b(mq_[a-z0-9_]+)\s*\(", txt))
+def _declared_functions(headers=("mapquik_hip.h", "mapquik_hip_diag.h")):
+    names = set()
+    for h in headers:
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(mq_[a-z0-9_]+)\s*\(", txt))
     return sorted(names)
+
+
+def test_seam_header_holds_no_diagnostics():
+    """include/mapquik_hip.h is the seam INTEGRATION.md mirrors; probe statistics, stage clocks and launch timers live in
+    include/mapquik_hip_diag.h.  Together they are everything the library exports under the mq_ prefix."""
+    seam, diag = set(_declared_functions(("mapquik_hip.h",))), set(_declared_functions(("mapquik_hip_diag.h",)))
+    assert not (seam & diag)
+    assert diag == {"mq_last_map_path_counts", "mq_map_probe_stats", "mq_probe_rate", "mq_last_stage_clocks", "mq_last_map_ms", "mq_ctx_last_map_ms"}
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name in sorted(seam):
+        assert name in integ, "INTEGRATION.md does not bind %s" % name
+    import subprocess
+    import mapquik_amd
+    out = subprocess.run(["nm", "-D", "--defined-only", mapquik_amd.build.LIB], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("mq_")}
+    assert exported == seam | diag, sorted(exported ^ (seam | diag))
 
 
 def test_every_declared_symbol_is_exported(lib):

@@ -1,0 +1,145 @@
+"""GPU: FASTA records found on the device (mq_ctx_submit_fasta / mq_ctx_wait_fasta, mapquik_amd/csrc/mq_fastx.hpp) against the
+host parser and the oracle: what closures.rs:100-123 hands to find_matches (id, sequence) must not depend on who found the
+record.  Also the native driver's FASTA -> PAF with the records found on the device, on the host, and through the irregular-chunk
+fallback (sequences over several lines), all byte-identical to the oracle's PAF."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mq():
+    import mapquik_amd
+    if mapquik_amd.device_count() <= 0:
+        pytest.fail("no HIP device visible: GPU tests must run on the GPU box")
+    return mapquik_amd
+
+
+@pytest.fixture(scope="module")
+def world(mq, oracle, simlib):
+    g, off, names = simlib.make_genome([700000, 400000], seed=91, repeat_frac=0.1, tandem_frac=0.02)
+    P, po = mq.Params(fold_case=True), oracle.params()
+    ix, ox = mq.Index(P), oracle.Index()
+    for r in range(2):
+        s = g[int(off[r]):int(off[r + 1])]
+        assert ix.add_ref(r, names[r], s) == ox.add_ref(r, names[r], s, po)
+    assert ix.finalize() == ox.count()
+    reads = simlib.make_reads(g, off, 700, seed=12, len_mean=9000, len_sd=5000, len_min=1)
+    return dict(ix=ix, ox=ox, po=po, reads=reads, names=simlib.read_names(reads, names))
+
+
+def _fasta(world, nl=b"\n", final_newline=True, lower_every=0, extra_empty=False):
+    rd, rn = world["reads"], world["names"]
+    offs = rd["offsets"]
+    parts, seqs = [], []
+    for i, n in enumerate(rn):
+        s = rd["bases"][int(offs[i]):int(offs[i + 1])].tobytes()
+        if lower_every and i % lower_every == 0:
+            s = s.lower()
+        if extra_empty and i == 5:
+            parts.append(b">empty some description" + nl + b"" + nl)
+            seqs.append(b"")
+        parts.append(b">" + n.encode() + b" len=%d" % len(s) + nl + s + nl)
+        seqs.append(s)
+    txt = b"".join(parts)
+    if not final_newline:
+        txt = txt[:-len(nl)]
+    return txt, seqs
+
+
+@pytest.mark.parametrize("nl,final_newline", [(b"\n", True), (b"\r\n", True), (b"\n", False), (b"\r\n", False)])
+def test_records_found_on_the_device(mq, world, nl, final_newline):
+    txt, seqs = _fasta(world, nl, final_newline, lower_every=3, extra_empty=True)
+    ix = world["ix"]
+    # what the host-parsed path gives for the same sequences
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+    offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in seqs])
+    want = ix.map_batch(bases, offs)
+    for pad in (0, 37):  # the records need not start the buffer (a reader leaves the byte before its first record in front)
+        buf = np.frombuffer(b"x" * (pad - 1) + b"\n" if pad else b"", dtype=np.uint8)
+        buf = np.concatenate([buf, np.frombuffer(txt, dtype=np.uint8)])
+        ctx = ix.context()
+        ctx.submit_fasta(buf, begin=pad)
+        hits, lines, flags = ctx.wait_fasta()
+        ctx.close()
+        assert flags == 0 and hits.size == len(seqs) and lines.size == 2 * len(seqs)
+        assert np.array_equal(hits.view(np.uint8), want.view(np.uint8))
+        # the line ends are where a host parser finds them
+        pos = [pad + i for i, c in enumerate(txt) if c == 0x0A]
+        if not final_newline:
+            pos.append(pad + len(txt))
+        assert lines.tolist() == pos
+    assert (want["status"] == 1).sum() > 500
+
+
+def test_irregular_pieces_are_handed_back(mq, world):
+    ix = world["ix"]
+    txt, _ = _fasta(world)
+    recs = txt.split(b">")[1:]
+    ctx = ix.context()
+    # a sequence over several lines
+    h, s = recs[0].split(b"\n")[:2]
+    multi = b">" + h + b"\n" + s[:60] + b"\n" + s[60:] + b"\n" + b">".join([b""] + recs[1:20])
+    # a blank line between records; a header without its sequence line; a piece that does not start with '>'
+    blank = b">" + recs[0] + b"\n>" + recs[1]
+    nohdr = b">" + recs[0] + b">lonely header\n"
+    nogt = recs[0]
+    for piece in (multi, blank, nohdr, nogt):
+        ctx.submit_fasta(np.frombuffer(piece, dtype=np.uint8))
+        hits, lines, flags = ctx.wait_fasta()
+        assert flags & 1 and hits.size == 0
+    # and the context is as good as new afterwards
+    ok = b">" + b">".join(recs[:50])
+    ctx.submit_fasta(np.frombuffer(ok, dtype=np.uint8))
+    hits, lines, flags = ctx.wait_fasta()
+    assert flags == 0 and hits.size == 50
+    ctx.close()
+
+
+def test_native_driver_fasta_device_and_host_parse(mq, oracle, world, tmp_path):
+    """FASTA file -> PAF through the native driver: records found on the device (default), parsed by the reader threads
+    (MQ_DRIVER_HOST_PARSE=1), and a multi-line FASTA whose chunks all come back irregular -- the oracle's PAF every time, at chunk
+    sizes that put boundaries everywhere."""
+    from mapquik_amd import build
+    exe = build.build_cli()
+    ox, po, rd, rn = world["ox"], world["po"], world["reads"], world["names"]
+    g_names = ["chr1", "chr2"]
+    # reference file from the oracle's own sequences is not kept: write the genome again
+    from tools import sim
+    g, off, names = sim.make_genome([700000, 400000], seed=91, repeat_frac=0.1, tandem_frac=0.02)
+    ref = tmp_path / "ref.fa"
+    with open(ref, "wb") as w:
+        for r in range(2):
+            w.write(b">" + names[r].encode() + b"\n" + g[int(off[r]):int(off[r + 1])].tobytes() + b"\n")
+    want = ox.map_batch(rd["bases"], rd["offsets"], po, threads=4)
+    want_txt = "".join(x + "\n" for x in oracle.paf_lines(ox, rn, want))
+    assert len(want_txt) > 10000
+    txt, _ = _fasta(world)
+    single = tmp_path / "reads.fa"
+    single.write_bytes(txt)
+    crlf = tmp_path / "reads_crlf.fa"
+    crlf.write_bytes(_fasta(world, b"\r\n", False)[0])
+    multi = tmp_path / "reads_multi.fa"
+    with open(multi, "wb") as w:
+        offs = rd["offsets"]
+        for i, n in enumerate(rn):
+            s = rd["bases"][int(offs[i]):int(offs[i + 1])].tobytes()
+            w.write(b">" + n.encode() + b" d\n")
+            for j in range(0, max(len(s), 1), 70):
+                w.write(s[j:j + 70] + b"\n")
+    k = 0
+    for path in (single, crlf, multi):
+        for chunk in ("20000", "300000", "33554432"):
+            for env in ({}, {"MQ_DRIVER_HOST_PARSE": "1"}):
+                k += 1
+                prefix = str(tmp_path / ("o%d" % k))
+                r = subprocess.run([exe, str(path), "--reference", str(ref), "-p", prefix, "--batch-bases", chunk, "--threads", "3", "--unmapped"],
+                                   capture_output=True, text=True, env=dict(os.environ, **env))
+                assert r.returncode == 0, r.stderr
+                assert open(prefix + ".paf").read() == want_txt, (str(path), chunk, env)
+                assert open(prefix + ".unmapped.out").read().split() == [n for n, w_ in zip(rn, want) if not w_["mapped"]]

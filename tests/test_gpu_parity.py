@@ -636,3 +636,65 @@ def test_no_device_memory_growth(mq, simlib):
         cycle()
     after = free_bytes()
     assert before - after < (64 << 20), (before, after)
+
+
+def _index_eq_oracle(mq, oracle, seqs, ps, fold=False):
+    """Index the sequences on the GPU and in the oracle: per-reference k-min-mer counts, key / live counts and the answer to every key."""
+    P, po = mq.Params(**ps, **({"fold_case": True} if fold else {})), oracle.params(**ps)
+    ix, ox = mq.Index(P), oracle.Index()
+    all_h = []
+    for r, s in enumerate(seqs):
+        su = np.frombuffer(bytes(s).upper(), dtype=np.uint8) if fold else s
+        assert ix.add_ref(r, "c%d" % r, s) == ox.add_ref(r, "c%d" % r, su, po), r
+        if su.size >= po.l + po.k - 1:
+            all_h.append(oracle.kminmers(su, po)["hash"])
+    assert ix.finalize() == ox.count()
+    st = ix.stats()
+    assert st["n_keys"] == ox.keys() and st["n_unique"] == ox.count()
+    hs = np.unique(np.concatenate(all_h)) if all_h else np.zeros(0, np.uint64)
+    if hs.size > 60000:
+        hs = hs[np.random.default_rng(3).choice(hs.size, 60000, replace=False)]
+    found, ent, ids = ix.lookup(hs)
+    for i, h in enumerate(hs):
+        e = ox.get(int(h))
+        assert bool(found[i]) == (e is not None)
+        if e is not None:
+            assert (int(ids[i]), int(ent[i]["start"]), int(ent[i]["end"]), int(ent[i]["offset"]), int(ent[i]["rev"])) == \
+                   (int(e["id"]), int(e["start"]), int(e["end"]), int(e["offset"]), int(e["rc"]))
+    ix.close()
+    return st
+
+
+@pytest.mark.parametrize("ps", [dict(), dict(k=3, l=12, density=0.05), dict(use_hpc=False, density=0.02)])
+def test_reference_segments_borders(mq, oracle, simlib, monkeypatch, ps):
+    """The index build seeds a reference in segments of 22,528 bases (views of two tiles with a 2,048-base halo, fast seeder) and sends
+    what the fast seeder declines to the general one: runs of N, homopolymer runs and lower-case bases placed ON the segment borders,
+    a homopolymer run longer than the halo (too few run heads behind the border: declined), contigs that end just before / at / just
+    after a border, and the same references with every segment forced through the general seeder -- all equal to the oracle."""
+    SEG = 22528
+    rng = np.random.default_rng(5)
+    g, off, _ = simlib.make_genome([5 * SEG + 777, 3 * SEG, 3 * SEG + 1, 3 * SEG - 1, SEG + 2048, 2 * SEG + 2047, 40, 31 + 4], seed=23, repeat_frac=0.1, tandem_frac=0.05)
+    seqs = [g[int(off[r]):int(off[r + 1])].copy() for r in range(off.size - 1)]
+    a = seqs[0]
+    a[SEG - 3:SEG + 5] = ord("N")              # a run of N across the first border
+    a[2 * SEG - 40:2 * SEG + 40] = ord("A")    # a homopolymer run across the second
+    a[3 * SEG - 1] = a[3 * SEG]                # the border falls inside a run of two
+    a[4 * SEG:4 * SEG + 3000] = ord("C")       # a run longer than the halo right behind a border: the view before it has too few run heads
+    a[4 * SEG + 3000] = ord("G")
+    b = seqs[1]
+    b[SEG - 1] = ord("T")
+    b[SEG] = ord("T")
+    b[2 * SEG - 2000:2 * SEG - 1990] = ord("N")  # N inside a halo only
+    st = _index_eq_oracle(mq, oracle, seqs, ps)
+    assert st["n_keys"] > 1000
+    # lower case with folding, on and around a border
+    lower = [s.copy() for s in seqs[:3]]
+    for s in lower:
+        m = (s != ord("N"))
+        idx = np.arange(s.size)
+        sel = m & (((idx // 97) % 2) == 0)
+        s[sel] = np.frombuffer(bytes(s[sel]).lower(), dtype=np.uint8)
+    _index_eq_oracle(mq, oracle, lower, ps, fold=True)
+    monkeypatch.setenv("MQ_FORCE_GENERAL", "1")
+    st2 = _index_eq_oracle(mq, oracle, seqs, ps)
+    assert st2 == st

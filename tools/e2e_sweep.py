@@ -37,6 +37,9 @@ with tempfile.TemporaryDirectory(dir=base) as wd:
         m = re.search(r"Mapped query sequences in ([0-9.]+)(s|ms|µs|ns)", r.stdout)
         t = float(m.group(1)) * {"s": 1, "ms": 1e-3, "µs": 1e-6, "ns": 1e-9}[m.group(2)] if m else float("nan")
         print("%-44s map phase %.3f s = %.2f Gbases/s   wall %.1f s  rc %d %s" % (tag, t, nb / t / 1e9, wall, r.returncode, r.stderr[-200:] if r.returncode else ""), flush=True)
+        for ln in r.stderr.splitlines():
+            if ln.startswith("map phase "):
+                print("      " + ln, flush=True)
 
     NP = {"MQ_DRIVER_NO_PREFETCH": "1"}
     if os.environ.get("E2E_BGZF"):  # a bgzip'ed FASTA of a quarter of the reads: blocks inflated in parallel by the reader threads
@@ -61,6 +64,31 @@ with tempfile.TemporaryDirectory(dir=base) as wd:
         for th in (16, 8, 4):
             run(bz, int(o[nq]), ["--threads", str(th)], "FASTA bgzf (quarter of the reads), %d threads, no prefetch" % th, NP)
         run(bz, int(o[nq]), ["--threads", "16"], "FASTA bgzf (quarter of the reads), 16 threads, prefetch")
+        sys.exit(0)
+    if os.environ.get("E2E_R4T"):  # where the threads' time goes (MQ_DRIVER_TIMING)
+        T = {"MQ_DRIVER_TIMING": "1"}
+        run(rd, bases, ["--threads", "4"], "warm-up")
+        run(rd, bases, ["--threads", "4"], "FASTA 4 threads, mapped file, device records", dict(T, MQ_FEEDER_MAPPED_FASTA="1"))
+        run(rd, bases, ["--threads", "8"], "FASTA 8 threads, mapped file, device records", dict(T, MQ_FEEDER_MAPPED_FASTA="1"))
+        run(rd, bases, ["--threads", "4"], "FASTA 4 threads, pread chunks, device records", T)
+        run(rd, bases, ["--threads", "8"], "FASTA 8 threads, pread chunks, device records", T)
+        run(rd, bases, ["--threads", "4"], "FASTA 4 threads, host parse", dict(T, MQ_DRIVER_HOST_PARSE="1"))
+        run(rd, bases, ["--threads", "8"], "FASTA 8 threads, host parse", dict(T, MQ_DRIVER_HOST_PARSE="1"))
+        sys.exit(0)
+    if os.environ.get("E2E_R4"):  # round 4 (profiles/r04_feeder_scaling.txt): records found on the device from views of the mapped file
+        run(rd, bases, ["--threads", "4"], "warm-up (files into the page cache)")
+        for th in (1, 2, 4, 8, 16):
+            run(rd, bases, ["--threads", str(th)], "FASTA %2d threads, records found on the device (mapped file, pages locked)" % th, {"MQ_FEEDER_MAPPED_FASTA": "1"})
+        for th in (4, 8, 16):
+            run(rd, bases, ["--threads", str(th)], "FASTA %2d threads, records found on the device (pread chunks)" % th, {})
+        for th in (4, 8, 16):
+            run(rd, bases, ["--threads", str(th)], "FASTA %2d threads, parsed by the reader threads (round 3's path)" % th, {"MQ_DRIVER_HOST_PARSE": "1"})
+        for cb in (1 << 23, 1 << 24, 1 << 26, 1 << 27):
+            run(rd, bases, ["--threads", "4", "--batch-bases", str(cb)], "FASTA  4 threads, device records, chunks of %d MB" % (cb >> 20))
+        for g in (2, 4):
+            run(rd, bases, ["--threads", "8", "--gpus", str(g)], "FASTA  8 threads, %d workers on ONE device (MQ_FAKE_MULTI)" % g, {"MQ_FAKE_MULTI": "1"})
+        run(fq, qbases, ["--threads", "4"], "FASTQ  4 threads (quarter of the reads; header + sequence lines copied by the readers)")
+        run(fq, qbases, ["--threads", "16"], "FASTQ 16 threads (quarter of the reads)")
         sys.exit(0)
     if os.environ.get("E2E_BIG"):  # steady state: an input several times the size of the feeder's buffer pool
         reps = int(os.environ["E2E_BIG"])

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CHECK(x)                                                                                \
@@ -40,7 +41,7 @@ constexpr int ITER = 400;
         lds[threadIdx.x] = seed;                                                                      \
         __syncthreads();                                                                              \
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                   \
-        for (int it = 0; it < ITER; ++it) asm volatile(BODY : OPS_IO : "v"(other), "s"(seed) : "memory", "vcc", "s20", "s21"); \
+        for (int it = 0; it < ITER; ++it) asm volatile(BODY : OPS_IO : "v"(other), "s"(seed) : "memory", "vcc", "scc", "s20", "s21", "s22", "s23"); \
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                   \
         STAMP(t0)                                                                                     \
     }
@@ -140,6 +141,116 @@ constexpr int ITER = 400;
     "v_xor_b32 %2, %2, %5\n"                       \
     "v_xor_b32 %3, %3, %7\n"
 
+// candidates for the step's test: (a) as built; (b) the two high words by v_lshlrev + v_lshrrev + v_or each (VOP2 only) -- the same
+// arithmetic as v_alignbit; (c) cmp into an SGPR pair + addc from it (VOP3 forms); (d) bound test by subtraction: (bhi - m) sign bit
+#define STEP_B_SHIFTS                              \
+    "v_lshlrev_b32 %4, 13, %1\n"                   \
+    "v_lshrrev_b32 %5, 19, %0\n"                   \
+    "v_or_b32 %4, %4, %5\n"                        \
+    "v_lshrrev_b32 %5, 19, %2\n"                   \
+    "v_lshlrev_b32 %6, 13, %3\n"                   \
+    "v_or_b32 %5, %5, %6\n"                        \
+    "v_min_u32 %4, %4, %5\n"                       \
+    "v_cmp_ge_u32 vcc, %8, %4\n"                   \
+    "v_addc_co_u32 %6, vcc, %6, %6, vcc\n"         \
+    "v_lshrrev_b32 %5, 8, %7\n"                    \
+    "v_and_b32 %5, 0xf0, %5\n"                     \
+    "v_xor_b32 %0, %0, %5\n"                       \
+    "v_xor_b32 %1, %1, %7\n"                       \
+    "v_xor_b32 %2, %2, %5\n"                       \
+    "v_xor_b32 %3, %3, %7\n"
+#define STEP_B_SUBSIGN                             \
+    "v_alignbit_b32 %4, %1, %0, 13\n"              \
+    "v_alignbit_b32 %5, %2, %3, 19\n"              \
+    "v_min_u32 %4, %4, %5\n"                       \
+    "v_sub_u32 %4, %8, %4\n"                       \
+    "v_lshrrev_b32 %4, 31, %4\n"                   \
+    "v_add_u32 %6, %6, %6\n"                       \
+    "v_or_b32 %6, %6, %4\n"                        \
+    "v_lshrrev_b32 %5, 8, %7\n"                    \
+    "v_and_b32 %5, 0xf0, %5\n"                     \
+    "v_xor_b32 %0, %0, %5\n"                       \
+    "v_xor_b32 %1, %1, %7\n"                       \
+    "v_xor_b32 %2, %2, %5\n"                       \
+    "v_xor_b32 %3, %3, %7\n"
+// the four xors alone / the test alone: what each half of the step costs by itself
+#define STEP_B_XORS "v_xor_b32 %0, %0, %5\nv_xor_b32 %1, %1, %7\nv_xor_b32 %2, %2, %5\nv_xor_b32 %3, %3, %7\n"
+#define STEP_B_TEST "v_alignbit_b32 %4, %1, %0, 13\nv_alignbit_b32 %5, %2, %3, 19\nv_min_u32 %4, %4, %5\nv_cmp_ge_u32 vcc, %8, %4\nv_addc_co_u32 %6, vcc, %6, %6, vcc\n"
+// (e) cmp into an SGPR pair, the four xors, then addc from the pair: the flag pair no longer back to back
+#define STEP_B_SPLIT                               \
+    "v_alignbit_b32 %4, %1, %0, 13\n"              \
+    "v_alignbit_b32 %5, %2, %3, 19\n"              \
+    "v_min_u32 %4, %4, %5\n"                       \
+    "v_cmp_ge_u32_e64 s[20:21], %8, %4\n"          \
+    "v_lshrrev_b32 %5, 8, %7\n"                    \
+    "v_and_b32 %5, 0xf0, %5\n"                     \
+    "v_xor_b32 %0, %0, %5\n"                       \
+    "v_xor_b32 %1, %1, %7\n"                       \
+    "v_xor_b32 %2, %2, %5\n"                       \
+    "v_xor_b32 %3, %3, %7\n"                       \
+    "v_addc_co_u32_e64 %6, s[22:23], %6, %6, s[20:21]\n"
+// (f) the same with vcc (e32 forms), the pair apart
+#define STEP_B_SPLITVCC                            \
+    "v_alignbit_b32 %4, %1, %0, 13\n"              \
+    "v_alignbit_b32 %5, %2, %3, 19\n"              \
+    "v_min_u32 %4, %4, %5\n"                       \
+    "v_cmp_ge_u32 vcc, %8, %4\n"                   \
+    "v_lshrrev_b32 %5, 8, %7\n"                    \
+    "v_and_b32 %5, 0xf0, %5\n"                     \
+    "v_xor_b32 %0, %0, %5\n"                       \
+    "v_xor_b32 %1, %1, %7\n"                       \
+    "v_xor_b32 %2, %2, %5\n"                       \
+    "v_xor_b32 %3, %3, %7\n"                       \
+    "v_addc_co_u32 %6, vcc, %6, %6, vcc\n"
+// (g) min3 with a clamp constant, sub, then ONE alignbit shifts the sign bit into the flag word (12 VALU... 11: no cmp/addc)
+#define STEP_B_SUBALIGN                            \
+    "v_alignbit_b32 %4, %1, %0, 13\n"              \
+    "v_alignbit_b32 %5, %2, %3, 19\n"              \
+    "v_min3_u32 %4, %4, %5, %8\n"                  \
+    "v_sub_u32 %4, %8, %4\n"                       \
+    "v_alignbit_b32 %6, %6, %4, 31\n"              \
+    "v_lshrrev_b32 %5, 8, %7\n"                    \
+    "v_and_b32 %5, 0xf0, %5\n"                     \
+    "v_xor_b32 %0, %0, %5\n"                       \
+    "v_xor_b32 %1, %1, %7\n"                       \
+    "v_xor_b32 %2, %2, %5\n"                       \
+    "v_xor_b32 %3, %3, %7\n"
+// (h) min3 clamp, sub, lshr, add, or (13 VALU)
+#define STEP_B_SUBSIGN3                            \
+    "v_alignbit_b32 %4, %1, %0, 13\n"              \
+    "v_alignbit_b32 %5, %2, %3, 19\n"              \
+    "v_min3_u32 %4, %4, %5, %8\n"                  \
+    "v_sub_u32 %4, %8, %4\n"                       \
+    "v_lshrrev_b32 %4, 31, %4\n"                   \
+    "v_add_u32 %6, %6, %6\n"                       \
+    "v_or_b32 %6, %6, %4\n"                        \
+    "v_lshrrev_b32 %5, 8, %7\n"                    \
+    "v_and_b32 %5, 0xf0, %5\n"                     \
+    "v_xor_b32 %0, %0, %5\n"                       \
+    "v_xor_b32 %1, %1, %7\n"                       \
+    "v_xor_b32 %2, %2, %5\n"                       \
+    "v_xor_b32 %3, %3, %7\n"
+// (i) as built, with the real step's SDWA offset instead of lshr + and (10 VALU)
+#define STEP_B_REAL                                \
+    "v_alignbit_b32 %4, %1, %0, 13\n"              \
+    "v_alignbit_b32 %5, %2, %3, 19\n"              \
+    "v_min_u32 %4, %4, %5\n"                       \
+    "v_cmp_ge_u32 vcc, %8, %4\n"                   \
+    "v_addc_co_u32 %6, vcc, %6, %6, vcc\n"         \
+    "v_and_b32_sdwa %5, %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n" \
+    "v_xor_b32 %0, %0, %5\n"                       \
+    "v_xor_b32 %1, %1, %7\n"                       \
+    "v_xor_b32 %2, %2, %5\n"                       \
+    "v_xor_b32 %3, %3, %7\n"
+DEF_KERNEL(k_stepb_split, MIX8(STEP_B_SPLIT))
+DEF_KERNEL(k_stepb_splitvcc, MIX8(STEP_B_SPLITVCC))
+DEF_KERNEL(k_stepb_subalign, MIX8(STEP_B_SUBALIGN))
+DEF_KERNEL(k_stepb_subsign3, MIX8(STEP_B_SUBSIGN3))
+DEF_KERNEL(k_stepb_real, MIX8(STEP_B_REAL))
+DEF_KERNEL(k_stepb_shifts, MIX8(STEP_B_SHIFTS))
+DEF_KERNEL(k_stepb_subsign, MIX8(STEP_B_SUBSIGN))
+DEF_KERNEL(k_stepb_xors, MIX8(STEP_B_XORS))
+DEF_KERNEL(k_stepb_test, MIX8(STEP_B_TEST))
 DEF_KERNEL(k_xor_e32, BODY64(I_XOR_E32))
 DEF_KERNEL(k_xor_e64, BODY64(I_XOR_E64))
 DEF_KERNEL(k_xor_lit, BODY64(I_XOR_LIT))
@@ -184,7 +295,7 @@ struct Test {
     int per_iter;
 };
 
-int main() {
+int main(int argc, char **argv) {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int n_cu = prop.multiProcessorCount;
@@ -228,12 +339,26 @@ int main() {
         {"stage-B step, cmp/addc -> two v_xor", k_stepb_novcc, 88},
         {"stage-B step, v_alignbit -> one VOP2 shift (not the same arithmetic)", k_stepb_novop3, 88},
         {"stage-B step, all VOP2, no vcc", k_stepb_allvop2, 88},
+        {"stage-B step, high words by shl + shr + or (VOP2 only, same arithmetic), 15 VALU: cycles per STEP / 11", k_stepb_shifts, 88},
+        {"stage-B step, flag by sub + shr + add + or instead of cmp/addc, 13 VALU: cycles per STEP / 11", k_stepb_subsign, 88},
+        {"stage-B step (e): cmp_e64 -> SGPR pair, xors, addc_e64 from the pair (11 VALU)", k_stepb_split, 88},
+        {"stage-B step (f): cmp -> vcc, xors, addc from vcc: the pair apart (11 VALU)", k_stepb_splitvcc, 88},
+        {"stage-B step (g): min3 clamp + sub + alignbit into the flag word (11 VALU)", k_stepb_subalign, 88},
+        {"stage-B step (h): min3 clamp + sub + shr + add + or (13 VALU): cycles per STEP / 11", k_stepb_subsign3, 88},
+        {"stage-B step (i): as built with the SDWA table offset (10 VALU): cycles per STEP / 11", k_stepb_real, 88},
+        {"stage-B step: the four xors alone (per instruction)", k_stepb_xors, 32},
+        {"stage-B step: the test alone, 2 alignbit + min + cmp + addc (per instruction)", k_stepb_test, 40},
     };
     struct Cfg { int wpb, bpc; };
     const std::vector<Cfg> cfgs = {{1, 1}, {2, 2}, {3, 2}, {4, 2}};
     unsigned long long *d_out = nullptr;
     CHECK(hipMalloc((void **)&d_out, (1 + 8 * 4 * 1024) * sizeof(unsigned long long)));
     for (const Test &t : tests) {
+        if (argc > 1) {  // run only the tests whose name contains one of the arguments
+            bool hit = false;
+            for (int a = 1; a < argc; ++a) hit |= strstr(t.name, argv[a]) != nullptr;
+            if (!hit) continue;
+        }
         printf("%s\n", t.name);
         for (const Cfg &c : cfgs) {
             const int w = c.wpb * c.bpc, threads = 256 * c.wpb;
