@@ -189,16 +189,16 @@ __device__ __forceinline__ void table_insert(Bucket *__restrict__ table, uint64_
             }
         }
     }
-    uint32_t bits = ENTRY_DUP;
+    // the claimant: one 8-byte store (start, end) and one 64-bit OR into the zeroed (offset, id_rc) pair; a duplicate: the flag alone
+    unsigned long long bits = (unsigned long long)ENTRY_DUP << 32;
     if (won) {
         n_claimed++;
-        table[b].pay[w].start = e.start;
-        table[b].pay[w].end = e.end;
-        table[b].pay[w].offset = e.offset;
-        bits = (e.id_rc & ~ENTRY_DUP) | ((times > 1u || e.end == 0u) ? ENTRY_DUP : 0u);
+        *reinterpret_cast<unsigned long long *>(&table[b].pay[w].start) = (unsigned long long)e.start | ((unsigned long long)e.end << 32);
+        const uint32_t idb = (e.id_rc & ~ENTRY_DUP) | ((times > 1u || e.end == 0u) ? ENTRY_DUP : 0u);
+        bits = (unsigned long long)e.offset | ((unsigned long long)idb << 32);
     }
-    const uint32_t old = atomicOr(&table[b].pay[w].id_rc, bits);
-    if ((bits & ENTRY_DUP) && !(old & ENTRY_DUP)) n_dead++;
+    const unsigned long long old = atomicOr(reinterpret_cast<unsigned long long *>(&table[b].pay[w].offset), bits);
+    if (((bits >> 32) & ENTRY_DUP) && !((old >> 32) & ENTRY_DUP)) n_dead++;
 }
 __device__ __forceinline__ void flush_insert_counts(uint32_t n_claimed, uint32_t n_dead, unsigned long long *__restrict__ acc) {
     const uint32_t c = wave_sum_u32(n_claimed), d = wave_sum_u32(n_dead);

@@ -725,7 +725,7 @@ __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict
                                                        const SeedView &V = SeedView()) {
     const uint32_t lane = lane_id();
     uint32_t raw0 = 0, carry_n = 0, carry_prev = VIEW ? (V.first_prev & 3u) : 0u, n_out = 0;
-    uint32_t halo_heads = 0;  // VIEW: run heads at or behind V.elig_end
+    uint32_t halo_heads = 0, seg_heads = 0;  // VIEW: run heads at or behind V.elig_end / in front of it
     if (!seed_fast_eligible(len)) return SD_NOT_FAST;
     if (!pre_valid) stage_a_request(seq, len, 0, pre);
     while (raw0 < len) {
@@ -735,10 +735,14 @@ __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict
         mq_clk(0);
         if (!ok) return SD_NOT_FAST;
         if (VIEW && V.more_after) {  // every l-mer that starts before elig_end must END inside the view: l - 1 run heads behind elig_end do it
-            uint32_t c = 0;
-            for (uint32_t k = lane; k < n_blocks; k += 64u)
-                if (raw0 + 64u * k >= V.elig_end) c += (uint32_t)__popcll(S.heads[k]);
+            uint32_t c = 0, c0 = 0;
+            for (uint32_t k = lane; k < n_blocks; k += 64u) {
+                const uint32_t n = (uint32_t)__popcll(S.heads[k]);
+                if (raw0 + 64u * k >= V.elig_end) c += n;
+                else c0 += n;
+            }
             halo_heads += wave_sum_u32(c);
+            seg_heads += wave_sum_u32(c0);
         }
         const bool more = raw_end < len;
         if (STOP != 1 && n_codes >= P.l) {
@@ -773,7 +777,8 @@ __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict
         raw0 = raw_end;
         mq_clk(3);
     }
-    if (VIEW && V.more_after && halo_heads + 1u < P.l) return SD_NOT_FAST;  // too few run heads behind elig_end (long homopolymer runs): the general seeder takes the segment
+    // too few run heads behind elig_end (long homopolymer runs): the general seeder takes the segment -- unless no l-mer starts in it at all
+    if (VIEW && V.more_after && halo_heads + 1u < P.l && seg_heads != 0u) return SD_NOT_FAST;
     return n_out;
 }
 
