@@ -479,16 +479,23 @@ def main():
             ij = json.load(open(ipath))
             if ij.get("reads") == n and abs(ij.get("genome_scale", -1) - args.genome_scale) < 1e-9 and ij.get("k") == args.k and not strong:
                 n_simd = int(ij["n_simd"])
-                cyc = avg_kern_s * float(ij["shader_clock_mhz"]) * 1e6
+                # cycles: the launch's busy cycles as the counters gave them (GRBM_GUI_ACTIVE / 8 XCDs) -- a property of the kernel on this
+                # workload; this run's launch time only says what shader clock that implies here (the clock moves with the power state:
+                # 1.95 GHz under the profiler, ~2.15 GHz in a plain run)
+                cyc = float(ij["busy_cycles_per_launch"])
                 cpi = cyc * n_simd / float(ij["wave_instructions_per_launch"])
                 roofline["secondary"] = dict(bound="valu_issue", wave_instructions_per_launch=int(ij["wave_instructions_per_launch"]),
                                              valu=int(ij["valu"]), salu=int(ij["salu"]), lds=int(ij["lds"]), vmem=int(ij["vmem"]), n_simd=n_simd,
-                                             shader_clock_mhz=ij["shader_clock_mhz"], cycles_per_instruction=round(cpi, 3),
+                                             busy_cycles_per_launch=int(cyc), cycles_per_instruction=round(cpi, 3),
                                              ceiling_cycles_per_instruction=ij["ceiling_cycles_per_instruction"],
                                              frac=round(float(ij["ceiling_cycles_per_instruction"]) / cpi, 4), waves_per_simd=ij.get("waves_per_simd"),
+                                             implied_shader_clock_mhz_this_run=round(cyc / avg_kern_s / 1e6, 1),
+                                             shader_clock_mhz_in_counter_pass=ij["shader_clock_mhz"],
                                              counters_taken_at_commit=ij.get("commit"), ceiling_source=ij.get("ceiling_source"),
-                                             note="cycles per wave-instruction per SIMD = this run's launch time x measured shader clock x SIMDs / "
-                                                  "instructions counted by rocprofv3 --pmc on the same workload; frac = ceiling / achieved")
+                                             wait_share=ij.get("wait_share"), lds_bank_conflict_share=ij.get("lds_bank_conflict_share"),
+                                             note="cycles per wave-instruction per SIMD = busy cycles x SIMDs / instructions, both counted by rocprofv3 --pmc "
+                                                  "on this workload (separate passes); frac = ceiling / achieved: how close the kernel is to what a SIMD "
+                                                  "can issue on stage B's instruction mix at this occupancy")
         except Exception as ex:  # noqa: BLE001
             roofline["secondary"] = {"error": repr(ex)[:200]}
 

@@ -89,17 +89,18 @@ __global__ __launch_bounds__(64) void seed_ref_general_kernel(const RefSeedArgs 
 }
 
 // Stage 2: where every segment's list goes in the reference's dense list (exclusive scan of the counts, one workgroup), the total,
-// and whether any list outgrew its region.  info: [0] total, [1] overflow flag (zeroed by the host).
+// and the segments whose list outgrew its region (their counts are the true ones: they are seeded again, straight into their place in
+// the dense list, by seed_ref_redo_kernel).  info: [0] total, [1] number of such segments (zeroed by the host); over_queue: their numbers.
 __global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t *__restrict__ counts, uint32_t n_seg, uint32_t cap,
-                                                           unsigned long long *__restrict__ seg_off, unsigned long long *__restrict__ info) {
+                                                           unsigned long long *__restrict__ seg_off, unsigned long long *__restrict__ info,
+                                                           uint32_t *__restrict__ over_queue) {
     __shared__ unsigned long long part[1024];
     const uint32_t t = threadIdx.x, per = (n_seg + 1023u) / 1024u;
     const uint32_t lo = t * per < n_seg ? t * per : n_seg, hi = lo + per < n_seg ? lo + per : n_seg;
     unsigned long long sum = 0;
-    bool over = false;
     for (uint32_t i = lo; i < hi; ++i) {
         const uint32_t c = counts[i];
-        over |= c > cap;
+        if (c > cap) over_queue[atomicAdd(&info[1], 1ull)] = i;
         sum += c;
     }
     part[t] = sum;
@@ -119,7 +120,23 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t *__res
         seg_off[n_seg] = part[1023];
         info[0] = part[1023];
     }
-    if (over) atomicOr(&info[1], 1ull);
+}
+
+// a segment whose list did not fit its region (a short-period tandem array can be far denser than 2 d): once more through the general
+// seeder, into its exact-size place in the dense list
+__global__ __launch_bounds__(64) void seed_ref_redo_kernel(const RefSeedArgs A, const uint32_t *__restrict__ over_queue, uint32_t n_over,
+                                                           const unsigned long long *__restrict__ seg_off, unsigned long long *__restrict__ dense_hash,
+                                                           uint32_t *__restrict__ dense_pos) {
+    __shared__ WaveLds S;
+    for (uint32_t i = blockIdx.x; i < n_over; i += gridDim.x) {
+        const uint32_t s = over_queue[i];
+        const uint64_t a = (uint64_t)s * REF_SEG;
+        const uint64_t b = a + REF_SEG < A.len ? a + REF_SEG : A.len;
+        SoaListSink sink(dense_hash + seg_off[s], dense_pos + seg_off[s], A.counts[s]);
+        uint32_t mz_count = 0;
+        seed_segment(A.seq, A.len, a, b, A.P, S, sink, mz_count);
+        wave_sync();
+    }
 }
 
 // Stage 3: segment lists -> one dense ordered list
@@ -128,6 +145,7 @@ __global__ void compact_lists_kernel(const unsigned long long *__restrict__ seg_
                                      unsigned long long *__restrict__ dense_hash, uint32_t *__restrict__ dense_pos) {
     for (uint32_t s = blockIdx.x; s < n_seg; s += gridDim.x) {
         const uint32_t c = counts[s];
+        if (c > cap) continue;  // seeded again into its place (seed_ref_redo_kernel)
         const size_t src = (size_t)s * cap;
         const unsigned long long dst = seg_off[s];
         for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) {

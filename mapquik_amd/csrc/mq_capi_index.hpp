@@ -98,6 +98,7 @@ static int64_t add_ref_device_locked(mq_index *idx, uint32_t ref_id, const char 
     if (!(dens > 0)) dens = 0;
     if (dens > 1) dens = 1;
     uint32_t cap = (uint32_t)std::min<double>((double)REF_SEG, 3.0 * 2.0 * dens * (double)REF_SEG + 256.0);
+    if (const char *e = getenv("MQ_REF_CAP")) cap = (uint32_t)std::max(1, atoi(e));  // test hook: tiny regions, so that segments take the redo path
     if ((rc = grow(idx->bld_counts, idx->bld_counts_cap, n_seg))) return rc;
     if ((rc = grow(idx->bld_queue, idx->bld_queue_cap, n_seg))) return rc;
     if ((rc = grow(idx->bld_seg_off, idx->bld_seg_off_cap, (uint64_t)n_seg + 1))) return rc;
@@ -108,35 +109,34 @@ static int64_t add_ref_device_locked(mq_index *idx, uint32_t ref_id, const char 
         idx->grid_ref = std::max(1, occ) * idx->n_cu;
     }
     unsigned long long info[2] = {0, 0};
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if ((rc = grow(idx->bld_seg_hash, idx->bld_seg_hash_cap, (uint64_t)n_seg * cap))) return rc;
-        if ((rc = grow(idx->bld_seg_pos, idx->bld_seg_pos_cap, (uint64_t)n_seg * cap))) return rc;
-        HIPCHK(hipMemsetAsync(idx->bld_info, 0, 64, 0));
-        RefSeedArgs A;
-        A.seq = d_seq;
-        A.len = len;
-        A.n_seg = n_seg;
-        A.P = P;
-        A.seg_hash = idx->bld_seg_hash;
-        A.seg_pos = idx->bld_seg_pos;
-        A.cap = cap;
-        A.counts = idx->bld_counts;
-        A.queue = idx->bld_queue;
-        A.counters = reinterpret_cast<uint32_t *>(idx->bld_info + 2);
-        A.force_general = idx->force_general ? 1u : 0u;
+    if ((rc = grow(idx->bld_seg_hash, idx->bld_seg_hash_cap, (uint64_t)n_seg * cap))) return rc;
+    if ((rc = grow(idx->bld_seg_pos, idx->bld_seg_pos_cap, (uint64_t)n_seg * cap))) return rc;
+    HIPCHK(hipMemsetAsync(idx->bld_info, 0, 64, 0));
+    RefSeedArgs A;
+    A.seq = d_seq;
+    A.len = len;
+    A.n_seg = n_seg;
+    A.P = P;
+    A.seg_hash = idx->bld_seg_hash;
+    A.seg_pos = idx->bld_seg_pos;
+    A.cap = cap;
+    A.counts = idx->bld_counts;
+    A.queue = idx->bld_queue;
+    A.counters = reinterpret_cast<uint32_t *>(idx->bld_info + 2);
+    A.force_general = idx->force_general ? 1u : 0u;
+    {
         const uint32_t g1 = std::min<uint32_t>((uint32_t)idx->grid_ref, (n_seg + SEED_WAVES - 1) / SEED_WAVES);
         hipLaunchKernelGGL(seed_ref_kernel, dim3(g1), dim3(64 * SEED_WAVES), 0, 0, A);
         HIPCHK(hipGetLastError());
         // the queue's length lives on the device: a fixed grid, waves that find the queue empty leave at once
         hipLaunchKernelGGL(seed_ref_general_kernel, dim3(std::min<uint32_t>((uint32_t)idx->n_cu * 32u, n_seg)), dim3(64), 0, 0, A);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, 0, idx->bld_counts, n_seg, cap, idx->bld_seg_off, idx->bld_info);
+        // (the fast seeder's queue is consumed by now: the same array takes the numbers of the segments whose list outgrew its region)
+        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, 0, idx->bld_counts, n_seg, cap, idx->bld_seg_off, idx->bld_info, idx->bld_queue);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy(info, idx->bld_info, 16, hipMemcpyDeviceToHost));
-        if (!info[1]) break;
-        if (attempt == 1) return set_err(MQ_EOVERFLOW, "minimizer list overflow at worst-case capacity (internal error)");
-        cap = REF_SEG;  // a segment cannot list more minimizers than it has bases
     }
+    const uint32_t n_over = (uint32_t)info[1];
     const uint64_t n_mz = info[0];
     int64_t n_kmm = 0;
     if (n_mz >= P.k) {
@@ -146,6 +146,11 @@ static int64_t add_ref_device_locked(mq_index *idx, uint32_t ref_id, const char 
         hipLaunchKernelGGL(compact_lists_kernel, dim3(std::min<uint32_t>(n_seg, 65535u)), dim3(64), 0, 0, idx->bld_seg_hash, idx->bld_seg_pos, cap,
                            idx->bld_counts, idx->bld_seg_off, n_seg, idx->bld_dense_hash, idx->bld_dense_pos);
         HIPCHK(hipGetLastError());
+        if (n_over) {
+            hipLaunchKernelGGL(seed_ref_redo_kernel, dim3(std::min<uint32_t>(n_over, (uint32_t)idx->n_cu * 32u)), dim3(64), 0, 0, A, idx->bld_queue, n_over,
+                               idx->bld_seg_off, idx->bld_dense_hash, idx->bld_dense_pos);
+            HIPCHK(hipGetLastError());
+        }
         // the reference's k-min-mers go behind those of the previous references in the current chunk while it has room
         if (idx->chunks.empty() || idx->chunks.back().n + (uint64_t)n_kmm > idx->chunks.back().cap) {
             KmmChunk ch;

@@ -698,3 +698,39 @@ def test_reference_segments_borders(mq, oracle, simlib, monkeypatch, ps):
     monkeypatch.setenv("MQ_FORCE_GENERAL", "1")
     st2 = _index_eq_oracle(mq, oracle, seqs, ps)
     assert st2 == st
+    # list regions of 8 entries per segment: nearly every segment's list outgrows its region and is seeded again into its place
+    monkeypatch.delenv("MQ_FORCE_GENERAL")
+    monkeypatch.setenv("MQ_REF_CAP", "8")
+    assert _index_eq_oracle(mq, oracle, seqs, ps) == st
+
+
+def test_reserve_table_hint_is_only_a_hint(mq, oracle, simlib):
+    """mq_index_reserve (DashMap::with_capacity, src/index.rs:83): the table is allocated in the background for the EXPECTED count;
+    a hint far too small, far too large, exact, or none at all gives the same index, and an index freed before finalize leaves nothing behind."""
+    g, off, names = simlib.make_genome([400000, 250000], seed=77, repeat_frac=0.1)
+    po = oracle.params()
+    ox = oracle.Index()
+    for r in range(2):
+        ox.add_ref(r, names[r], g[int(off[r]):int(off[r + 1])], po)
+    reads = simlib.make_reads(g, off, 300, seed=5)
+    want = ox.map_batch(reads["bases"], reads["offsets"], po, threads=4)
+    stats = []
+    for hint in (None, 1, 9000, 10**7):
+        ix = mq.Index(mq.Params())
+        if hint is not None:
+            ix.reserve_table(hint)
+            ix.reserve_table(hint * 2 + 5)  # a second call is ignored: one reservation per index
+        for r in range(2):
+            ix.add_ref(r, names[r], g[int(off[r]):int(off[r + 1])])
+        assert ix.finalize() == ox.count()
+        stats.append(ix.stats())
+        hits = ix.map_batch(reads["bases"], reads["offsets"])
+        assert np.array_equal(hits["status"] == 1, want["mapped"] != 0)
+        m = want["mapped"] != 0
+        for a in ("ref_id", "rc", "mapq", "q_start", "q_end", "r_start", "r_end", "score"):
+            assert np.array_equal(mq.hit_column(hits, a)[m], want[a][m].astype(np.uint64)), (hint, a)
+        ix.close()
+    assert all(s == stats[0] for s in stats)
+    ix = mq.Index(mq.Params())
+    ix.reserve_table(5 * 10**6)
+    ix.close()  # freed with the background allocation possibly still running
