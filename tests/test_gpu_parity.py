@@ -578,6 +578,21 @@ def test_fuzz_params_and_sequences(mq, oracle, simlib):
                                            tandem_frac=float(rng.choice([0, 0.1])), threads=2)
         reads = simlib.make_reads(g, off, 40, seed=int(rng.integers(1, 1 << 30)), len_mean=float(rng.choice([300, 3000, 20000])),
                                   len_sd=2000, len_min=1, len_max=60000, err=float(rng.choice([0, 0.01, 0.05])), threads=2)
+        if it % 2 == 1:  # damage the REFERENCE too (after the reads were drawn): runs of N, homopolymer and dinucleotide stretches, some of them
+            g = g.copy()  # on the borders of the index build's 22,528-base segments: fast views, declined views and the general seeder must agree
+            for _ in range(int(rng.integers(1, 6))):
+                a = int(rng.integers(0, max(1, g.size - 10)))
+                if rng.integers(0, 2):
+                    a = min(g.size - 1, (a // 22528) * 22528 + int(rng.integers(-40, 40)) % 22528)
+                n = int(rng.choice([1, 7, 40, 600, 3000, 9000]))
+                kind = int(rng.integers(0, 3))
+                seg = g[a:a + n]
+                if kind == 0:
+                    seg[:] = ord("N")
+                elif kind == 1:
+                    seg[:] = ord("ACGT"[int(rng.integers(0, 4))])
+                else:
+                    seg[:] = np.where(np.arange(seg.size) % 2 == 0, ord("T"), ord("G"))
         bases = reads["bases"].copy()
         offs = reads["offsets"]
         for i in range(0, 40, 7):  # damage some reads: N run, lowercase, homopolymer, dinucleotide repeat
