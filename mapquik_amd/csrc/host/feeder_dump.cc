@@ -64,8 +64,34 @@ int main(int argc, char **argv) {
         }
         Feeder f(argv[1], std::string(argv[2]) == "fastq", strtoull(argv[3], nullptr, 10), atoi(argv[4]), atoi(argv[4]) + 4,
                  [](size_t n) { return malloc(n); }, [](void *p) { free(p); }, [](void *, size_t) { return 0; }, [](void *) { return 0; });
+        // FEEDER_DUMP_UNPARSED=1: what the native driver does for an uncompressed FASTA file, with the device's part done here: chunks
+        // come unparsed (FEEDER_DUMP_MAPPED=1: as views of the mapped file), the line ends are found by a plain scan, a chunk that is not
+        // "header line, sequence line" all through is parsed by parse_chunk after all (materialized first when it is a view)
+        const bool unparsed_mode = getenv("FEEDER_DUMP_UNPARSED") != nullptr;
+        if (unparsed_mode) f.leave_unparsed(true);
         if (getenv("FEEDER_DUMP_KIND")) fprintf(stderr, "kind=%s\n", f.kind_name());
         f.start();
+        unsigned long long n_unparsed = 0, n_irregular = 0;
+        auto host_scan = [&](Chunk *c) {
+            ++n_unparsed;
+            std::vector<uint32_t> le;
+            for (uint64_t p = c->begin; p < c->bytes; ++p)
+                if (c->buf[p] == '\n') le.push_back((uint32_t)p);
+            if (c->bytes > c->begin && c->buf[c->bytes - 1] != '\n') le.push_back((uint32_t)c->bytes);
+            bool irregular = (le.size() & 1) != 0;
+            for (size_t i = 0; !irregular && i < le.size() / 2; ++i) {
+                const uint64_t hs = i ? (uint64_t)le[2 * i - 1] + 1 : c->begin, he = le[2 * i], ss = he + 1;
+                irregular = hs >= he || c->buf[hs] != '>' || (ss < le[2 * i + 1] && c->buf[ss] == '>');
+            }
+            if (irregular) {
+                ++n_irregular;
+                c->materialize();
+                parse_chunk(*c, false);
+            } else {
+                spans_from_line_ends(*c, le.data(), (uint32_t)le.size());
+            }
+            c->unparsed = false;
+        };
         std::map<size_t, Chunk *> held;
         size_t next = 0;
         const bool quiet = getenv("FEEDER_DUMP_QUIET") != nullptr;
@@ -90,10 +116,12 @@ int main(int argc, char **argv) {
             }
         };
         while (Chunk *c = f.next()) {
+            if (c->unparsed) host_scan(c);
             held[c->seq_no] = c;
             flush();
         }
         flush();
+        if (unparsed_mode) fprintf(stderr, "unparsed chunks %llu irregular %llu mapped %d\n", n_unparsed, n_irregular, f.mapped_views() ? 1 : 0);
         if (!held.empty()) {
             fprintf(stderr, "missing chunk %zu\n", next);
             return 1;

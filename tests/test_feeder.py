@@ -255,3 +255,30 @@ def test_feeder_last_quality_line_starting_with_at(tool, tmp_path, crlf):
                 assert _dump(tool, gz, True, chunk, th, {"MQ_GZ_WHOLE_LIMIT": "0"}) == want, ("gz-stream", chunk, th, trailing)
                 assert _dump(tool, gz, True, chunk, th, {"MQ_FEEDER_NO_LIBDEFLATE": "1"}) == want, ("gz-zlib", chunk, th, trailing)
                 assert _dump(tool, bg, True, chunk, th) == want, ("bgzf", chunk, th, trailing)
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+def test_feeder_unparsed_fasta_chunks(tool, tmp_path, crlf):
+    """The driver's FASTA path with the device's share done on the host (feeder_dump FEEDER_DUMP_UNPARSED=1): chunks are handed over
+    unparsed -- read with pread, or as views of the mapped file -- their line ends found by a plain scan and turned into spans
+    (spans_from_line_ends); chunks that are not two lines per record go through parse_chunk after all.  Same records as the parser."""
+    import os
+    rng = random.Random(31 + crlf)
+    for multiline in (False, True):
+        recs, text = _make(300, False, multiline, crlf, rng)
+        want = [[a, str(len(b)), b] for a, b in recs]
+        for trailing in (True, False):
+            t = text if trailing else text.rstrip("\r\n")
+            p = tmp_path / "u.fa"
+            p.write_text(t, newline="")
+            for chunk, th in ((64, 3), (777, 1), (5000, 4), (1 << 20, 2)):
+                for extra in ({}, {"MQ_FEEDER_MAPPED_FASTA": "1"}, {"MQ_FEEDER_MAPPED_FASTA": "1", "MQ_FEEDER_NO_PAGE_LOCK": "1"}):
+                    env = dict(os.environ, FEEDER_DUMP_UNPARSED="1", **extra)
+                    r = subprocess.run([tool, str(p), "fasta", str(chunk), str(th)], capture_output=True, text=True, timeout=60, env=env)
+                    assert r.returncode == 0, r.stderr
+                    got = [ln.split("\t") for ln in r.stdout.split("\n") if ln != ""]
+                    got = [g if len(g) == 3 else g + [""] for g in got]
+                    assert got == want, (multiline, trailing, chunk, th, extra)
+                    assert ("mapped 1" in r.stderr) == bool(extra)
+                    if multiline:
+                        assert "irregular 0" not in r.stderr  # sequences over several lines: handed back to the parser
