@@ -152,14 +152,20 @@ struct Hash2 {
 };
 
 // ------------------------------------------------------------------ stage A
-// 16 bases at pos; bytes past the end repeat the last base (never a run head under HPC; masked without HPC).  A piece that
-// reaches past the end (only in the sequence's last super-row) is cut out of the 16 bytes that END at len (len >= 16 is the
-// caller's precondition): one load, never a byte beyond the sequence.
+// 16 bases at pos.  The load itself never branches: its address is clamped to len - 16 (len >= 16 is the caller's precondition), so a
+// piece that reaches past the end comes back as the 16 bytes that END at len -- never a byte beyond the sequence -- and fix_piece()
+// shifts it into place (bytes past the end repeat the last base: never a run head under HPC; masked without HPC).  Only a sequence's
+// last super-row has such pieces, so the fix-up sits behind a wave-uniform test; everywhere else a piece costs a v_min and a load
+// (it used to cost a divergent if / else per piece: ~14 instructions and two register copies, a ninth of stage A).
 __device__ __forceinline__ uint4 load_piece(const uint8_t *__restrict__ seq, uint32_t len, uint32_t pos) {
-    if (pos + 16u <= len) return *reinterpret_cast<const uint4_unaligned *>(seq + pos);
-    const uint4 v = *reinterpret_cast<const uint4_unaligned *>(seq + (len - 16u));
-    const uint32_t fill = (uint32_t)seq[len - 1] * 0x01010101u;
-    const uint32_t nv = pos < len ? len - pos : 0u;  // valid bytes: 0..15
+    const uint32_t p = pos < len - 16u ? pos : len - 16u;
+    return *reinterpret_cast<const uint4_unaligned *>(seq + p);
+}
+// v = load_piece(seq, len, pos) of a piece with pos + 16 > len: the piece as stage A wants it
+__device__ __forceinline__ uint4 fix_piece(const uint4 v, uint32_t len, uint32_t pos) {
+    if (pos + 16u <= len) return v;
+    const uint32_t fill = (v.w >> 24) * 0x01010101u;  // seq[len - 1] is the last of the 16 bytes that end at len
+    const uint32_t nv = pos < len ? len - pos : 0u;   // valid bytes: 0..15
     const uint32_t s = 16u - nv;                      // shift the 32-byte value [v, fill...] right by s bytes
     uint32_t w0 = v.x, w1 = v.y, w2 = v.z, w3 = v.w;
     if (s & 4u) { w0 = w1; w1 = w2; w2 = w3; w3 = fill; }
@@ -213,16 +219,24 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
     for (uint32_t sr = 0; sr < n_sr; ++sr) {
         const uint32_t pos = raw0 + sr * SD_SR_RAW + lane * 64u;
         const bool more_sr = sr + 1u < n_sr || (SD_CROSS_PREFETCH && tile_end < len);  // the tile's last super-row requests the next tile's first
+        if (raw0 + (sr + 1u) * SD_SR_RAW > len) {  // the sequence ends inside this super-row (wave-uniform, once per sequence): pieces past the end
+            nx0 = fix_piece(nx0, len, pos);
+            nx1 = fix_piece(nx1, len, pos + 16u);
+            nx2 = fix_piece(nx2, len, pos + 32u);
+            nx3 = fix_piece(nx3, len, pos + 48u);
+        }
         uint32_t p[4];
         // decode piece j, then send the load of the NEXT super-row's piece j into the registers just freed: 16 registers of
-        // bases in flight plus the piece being decoded, instead of two whole super-rows
+        // bases in flight plus the piece being decoded, instead of two whole super-rows.  (When nothing follows the load is made all
+        // the same, from a clamped address: a handful of wasted loads per sequence instead of a branch and register copies per piece.)
+        (void)more_sr;
         auto decode = [&](uint4 &nx, uint32_t j) {
             const uint32_t t0 = nx.x & 0x06060606u, t1 = nx.y & 0x06060606u, t2 = nx.z & 0x06060606u, t3 = nx.w & 0x06060606u;
             // reconstructs each byte iff it was A/C/G/T
             bad |= (__builtin_amdgcn_perm(S0, S1, t0) ^ nx.x) | (__builtin_amdgcn_perm(S0, S1, t1) ^ nx.y) |
                    (__builtin_amdgcn_perm(S0, S1, t2) ^ nx.z) | (__builtin_amdgcn_perm(S0, S1, t3) ^ nx.w);
             p[j] = pack16(t0, t1, t2, t3);
-            if (more_sr) nx = load_piece(seq, len, pos + SD_SR_RAW + 16u * j);
+            nx = load_piece(seq, len, pos + SD_SR_RAW + 16u * j);
         };
         decode(nx0, 0);
         decode(nx1, 1);
