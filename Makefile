@@ -9,7 +9,7 @@ all: $(LIBDIR)/libmapquik_hip.so $(LIBDIR)/mapquik
 
 $(LIBDIR)/libmapquik_hip.so: $(CSRC)/mq_capi.hip $(CSRC)/mq_device.hpp $(CSRC)/mq_seed.hpp include/mapquik_hip.h
 	mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -Wno-align-mismatch -mllvm -amdgpu-atomic-optimizer-strategy=None -o $@ $(CSRC)/mq_capi.hip
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -Wno-align-mismatch -mllvm -amdgpu-atomic-optimizer-strategy=None -mllvm -pragma-unroll-threshold=65536 -o $@ $(CSRC)/mq_capi.hip
 
 $(LIBDIR)/mapquik: $(CSRC)/host/mapquik_main.cc $(CSRC)/host/mapquik_host.hpp $(CSRC)/host/fastx_feeder.hpp $(CSRC)/host/fastx_records.hpp $(CSRC)/host/par_gzip.hpp $(CSRC)/host/ref_loader.hpp include/mapquik_hip.h $(LIBDIR)/libmapquik_hip.so
 	$(CXX) -O2 -std=c++17 -Wall -o $@ $(CSRC)/host/mapquik_main.cc -L$(LIBDIR) -lmapquik_hip -lz -lpthread -ldl -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib

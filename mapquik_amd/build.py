@@ -91,8 +91,10 @@ def build(force=False, verbose=False):
     # -amdgpu-atomic-optimizer-strategy=None: the optimizer rewrites `if (lane == 0) r = atomicAdd(counter, 1)` into a wave reduction
     # whose result is read back (s_waitcnt vmcnt(0) + v_readfirstlane) right behind the atomic -- which turns map_kernel's prefetch of
     # the next work item (issued a whole seed phase before it is needed) into a memory round trip every wave waits for, per read
+    # -pragma-unroll-threshold: the loop over a chunk's lane-batches (mq_device.hpp map_seeds) holds one tuple hash per supported k;
+    # written on 32-bit halves its unrolled size passes the default 16384, and left rolled its per-batch arrays are indexed dynamically
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Wno-align-mismatch",
-           "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-o", LIB] + SOURCES
+           "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-mllvm", "-pragma-unroll-threshold=65536", "-o", LIB] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -181,47 +181,87 @@ __device__ __forceinline__ uint64_t nt_seed(uint32_t code) {
 __device__ __forceinline__ uint32_t comp_code(uint32_t code) { return code < 4 ? 3u - code : 4u; }
 
 // ------------------------------------------------------------------ SipHash-1-3, key 0 (Rust DefaultHasher) over [len, m_0..m_{k-1}]
-#define MQ_SIPROUND(v0, v1, v2, v3) \
-    do {                            \
-        v0 += v1;                   \
-        v1 = rotl64(v1, 13);        \
-        v1 ^= v0;                   \
-        v0 = rotl64(v0, 32);        \
-        v2 += v3;                   \
-        v3 = rotl64(v3, 16);        \
-        v3 ^= v2;                   \
-        v0 += v3;                   \
-        v3 = rotl64(v3, 21);        \
-        v3 ^= v0;                   \
-        v2 += v1;                   \
-        v1 = rotl64(v1, 17);        \
-        v1 ^= v2;                   \
-        v2 = rotl64(v2, 32);        \
-    } while (0)
+// The state is kept as 32-bit halves: a rotation by 32 is then a renaming, the others are two v_alignbit each, and a 64-bit add is
+// v_add_co + v_addc.  Written on uint64_t the compiler emits v_lshl_add_u64 / v_lshlrev_b64 on aligned register pairs plus the
+// moves that re-pair the halves after every rotation by 32: 35 instructions a round against 28 (tools/sip_enc.hip,
+// profiles/r04_sip_enc.txt: 88 against 79 cycles a round per SIMD at this kernel's occupancy).
+struct U2 {
+    uint32_t lo, hi;
+};
+__device__ __forceinline__ U2 u2_of(uint64_t v) { return {(uint32_t)v, (uint32_t)(v >> 32)}; }
+__device__ __forceinline__ uint64_t u64_of(U2 v) { return ((uint64_t)v.hi << 32) | v.lo; }
+// a += b; b = rotl(b, R), 0 < R < 32 -- every add of a SipHash round is followed by a rotation of its addend.  One asm block: the
+// two v_alignbit sit between v_add_co and v_addc, which covers the two wait states gfx950 wants between a VALU write of vcc and a
+// VALU read of it (the compiler fills them with s_nop), and plain C for the add is fused back into v_lshl_add_u64.
+template <uint32_t R>
+__device__ __forceinline__ void add_rotl_u2(U2 &a, U2 &b) {
+    U2 s, r;
+    asm("v_add_co_u32_e32 %0, vcc, %4, %6\n\tv_alignbit_b32 %2, %6, %7, %8\n\tv_alignbit_b32 %3, %7, %6, %8\n\tv_addc_co_u32_e32 %1, vcc, %5, %7, vcc"
+        : "=&v"(s.lo), "=&v"(s.hi), "=&v"(r.lo), "=&v"(r.hi)
+        : "v"(a.lo), "v"(a.hi), "v"(b.lo), "v"(b.hi), "n"(32u - R)
+        : "vcc");
+    a = s;
+    b = r;
+}
+__device__ __forceinline__ U2 xor_u2(U2 a, U2 b) { return {a.lo ^ b.lo, a.hi ^ b.hi}; }
+__device__ __forceinline__ U2 swap_u2(U2 a) { return {a.hi, a.lo}; }
+
+// the state after init() and the first word (the tuple's length k, the same for every k-min-mer): folded at compile time
+struct SipState {
+    uint64_t v0, v1, v2, v3;
+};
+constexpr uint64_t sip_rotl(uint64_t x, unsigned r) { return (x << r) | (x >> (64u - r)); }
+constexpr SipState sip_round(SipState s) {
+    s.v0 += s.v1; s.v1 = sip_rotl(s.v1, 13); s.v1 ^= s.v0; s.v0 = sip_rotl(s.v0, 32);
+    s.v2 += s.v3; s.v3 = sip_rotl(s.v3, 16); s.v3 ^= s.v2;
+    s.v0 += s.v3; s.v3 = sip_rotl(s.v3, 21); s.v3 ^= s.v0;
+    s.v2 += s.v1; s.v1 = sip_rotl(s.v1, 17); s.v1 ^= s.v2; s.v2 = sip_rotl(s.v2, 32);
+    return s;
+}
+constexpr SipState sip_initial() { return {0x736f6d6570736575ULL, 0x646f72616e646f6dULL, 0x6c7967656e657261ULL, 0x7465646279746573ULL}; }
+constexpr SipState sip_after_word(SipState s, uint64_t m) {
+    s.v3 ^= m;
+    s = sip_round(s);
+    s.v0 ^= m;
+    return s;
+}
 
 struct Sip13 {
-    uint64_t v0, v1, v2, v3;
-    __device__ __forceinline__ void init() {
-        v0 = 0x736f6d6570736575ULL;
-        v1 = 0x646f72616e646f6dULL;
-        v2 = 0x6c7967656e657261ULL;
-        v3 = 0x7465646279746573ULL;
+    U2 v0, v1, v2, v3;
+    __device__ __forceinline__ void set(const SipState &s) {
+        v0 = u2_of(s.v0);
+        v1 = u2_of(s.v1);
+        v2 = u2_of(s.v2);
+        v3 = u2_of(s.v3);
     }
-    __device__ __forceinline__ void word(uint64_t m) {
-        v3 ^= m;
-        MQ_SIPROUND(v0, v1, v2, v3);
-        v0 ^= m;
+    __device__ __forceinline__ void init() { set(sip_initial()); }
+    template <uint64_t FIRST>
+    __device__ __forceinline__ void init_after() {  // init(); word(FIRST);
+        constexpr SipState s = sip_after_word(sip_initial(), FIRST);
+        set(s);
     }
+    __device__ __forceinline__ void round() {
+        add_rotl_u2<13>(v0, v1); v1 = xor_u2(v1, v0); v0 = swap_u2(v0);
+        add_rotl_u2<16>(v2, v3); v3 = xor_u2(v3, v2);
+        add_rotl_u2<21>(v0, v3); v3 = xor_u2(v3, v0);
+        add_rotl_u2<17>(v2, v1); v1 = xor_u2(v1, v2); v2 = swap_u2(v2);
+    }
+    __device__ __forceinline__ void word(U2 m) {
+        v3 = xor_u2(v3, m);
+        round();
+        v0 = xor_u2(v0, m);
+    }
+    __device__ __forceinline__ void word(uint64_t m) { word(u2_of(m)); }
     __device__ __forceinline__ uint64_t finish(uint32_t nbytes) {
-        uint64_t b = (uint64_t)(nbytes & 0xffu) << 56;
-        v3 ^= b;
-        MQ_SIPROUND(v0, v1, v2, v3);
-        v0 ^= b;
-        v2 ^= 0xff;
-        MQ_SIPROUND(v0, v1, v2, v3);
-        MQ_SIPROUND(v0, v1, v2, v3);
-        MQ_SIPROUND(v0, v1, v2, v3);
-        return v0 ^ v1 ^ v2 ^ v3;
+        const uint32_t b = (nbytes & 0xffu) << 24;  // the length byte, bits 56..63
+        v3.hi ^= b;
+        round();
+        v0.hi ^= b;
+        v2.lo ^= 0xffu;
+        round();
+        round();
+        round();
+        return u64_of(xor_u2(xor_u2(v0, v1), xor_u2(v2, v3)));
     }
 };
 
@@ -242,7 +282,9 @@ __device__ __forceinline__ uint64_t kminmer_hash(uint32_t k, Get get, bool &rev)
 }
 
 // The same for a k known at compile time: the k hashes are read once (all reads in flight together), the orientation comes out of
-// k/2 comparisons without a branch (pairs past the middle repeat the earlier ones, which were equal if the loop got that far).
+// k/2 comparisons without a branch (pairs past the middle repeat the earlier ones, which were equal if the loop got that far), and
+// a reverse tuple is the forward one with its pairs (i, k-1-i) exchanged under a lane mask -- three bit operations a half-word.
+// (`r ? w[k-1-i] : w[i]` compiled to a select of the INDEX and a chain of k-1 compare/select pairs per word.)
 template <uint32_t K, class Get>
 __device__ __forceinline__ uint64_t kminmer_hash_fixed(Get get, bool &rev) {
     uint64_t w[K];
@@ -255,11 +297,22 @@ __device__ __forceinline__ uint64_t kminmer_hash_fixed(Get get, bool &rev) {
         decided = decided || (w[K - 1u - i] != w[i]);
     }
     rev = r;
-    Sip13 h;
-    h.init();
-    h.word((uint64_t)K);
+    U2 m[K];
 #pragma unroll
-    for (uint32_t i = 0; i < K; ++i) h.word(r ? w[K - 1u - i] : w[i]);
+    for (uint32_t i = 0; i < K; ++i) m[i] = u2_of(w[i]);
+    const uint32_t swap = r ? ~0u : 0u;
+#pragma unroll
+    for (uint32_t i = 0; i < K / 2u; ++i) {
+        const uint32_t dlo = (m[i].lo ^ m[K - 1u - i].lo) & swap, dhi = (m[i].hi ^ m[K - 1u - i].hi) & swap;
+        m[i].lo ^= dlo;
+        m[i].hi ^= dhi;
+        m[K - 1u - i].lo ^= dlo;
+        m[K - 1u - i].hi ^= dhi;
+    }
+    Sip13 h;
+    h.template init_after<(uint64_t)K>();
+#pragma unroll
+    for (uint32_t i = 0; i < K; ++i) h.word(m[i]);
     return h.finish(8u * (K + 1u));
 }
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # where the spills of map_kernel<64,false> sit: source line + loop depth of every scratch access.  tools/spills.sh [-D...]
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -Wno-align-mismatch -mllvm -amdgpu-atomic-optimizer-strategy=None -gline-tables-only "$@" -S --cuda-device-only -o /tmp/spills.s $ROOT/mapquik_amd/csrc/mq_capi.hip 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -Wno-align-mismatch -mllvm -amdgpu-atomic-optimizer-strategy=None -mllvm -pragma-unroll-threshold=65536 -gline-tables-only "$@" -S --cuda-device-only -o /tmp/spills.s $ROOT/mapquik_amd/csrc/mq_capi.hip 2>/dev/null
 python3 - <<'PY'
 import re,os
 L=open('/tmp/spills.s').read().split('\n')
