@@ -281,8 +281,8 @@ class Feeder {
                     c->bytes = last - first;
                     c->unparsed = true;
                     // Page-lock the chunk's whole pages [floor(first), floor(last)): the copy to the device is then a DMA out of the page cache
-                    // that no thread waits for (tools/file_h2d.hip: 47-50 GB/s against 15 per thread from pageable memory).  The ranges of
-                    // consecutive chunks tile the file, so no page is locked twice; the chunk's last partial page belongs to the next
+                    // that no thread waits for.  (Experimental, off by default: profiles/r04_file_h2d.txt -- locking the pages of a fresh
+                    // mapping runs at 12-17 GB/s whatever the thread count.)  The ranges of consecutive chunks tile the file, so no page is locked twice; the chunk's last partial page belongs to the next
                     // chunk's range, and mq_ctx_submit_fasta moves those < 4 KB through a buffer of its own.  Released by recycle().
                     if (lock_pages_) {
                         const uint64_t a = first / page_ * page_, b = last / page_ * page_;

@@ -258,7 +258,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         std::deque<Chunk *> to_format;               // mapped, waiting for a formatter
         std::map<size_t, Chunk *> done;              // formatted, waiting for their turn in the output
         // Submitting threads per GPU (n_sub).  Chunks that are views of the mapped file are copied to the device from pageable memory: that
-        // copy occupies the thread that asks for it, and two threads keep the link full (profiles/r04_file_h2d.txt: one 14.6, two 48 GB/s).
+        // copy occupies the thread that asks for it, hence two (experimental path, MQ_FEEDER_MAPPED_FASTA=1; profiles/r04_file_h2d.txt: 14-17 GB/s).
         int gpu_workers_left = o.gpus * n_sub;
         int formatting = 0;                          // chunks a formatter is working on right now
         std::string werr;

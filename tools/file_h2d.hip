@@ -47,11 +47,13 @@ int main(int argc, char **argv) {
         close(fd);
     }
     const int fd = open(path.c_str(), O_RDONLY);
-    const uint8_t *map = (const uint8_t *)mmap(nullptr, total, PROT_READ, MAP_SHARED, fd, 0);
-    if (map == MAP_FAILED) { printf("mmap failed\n"); return 1; }
     const size_t n_slices = total / SLICE;
-    for (const char *mode : {"pread-only", "pread", "direct", "reg"}) {
+    // every run maps the file afresh: the page tables of a new mapping are empty, and filling them (one minor fault per 16 pages, or
+    // madvise(MADV_POPULATE_READ) per slice = "pop") is part of what a zero-copy path costs
+    for (const char *mode : {"pread-only", "pread", "direct", "reg", "only-pop", "xpop+direct", "ypop+reg"}) {
         for (int T : {1, 2, 4, 8}) {
+            const uint8_t *map = (const uint8_t *)mmap(nullptr, total, PROT_READ, MAP_SHARED, fd, 0);
+            if (map == MAP_FAILED) { printf("mmap failed\n"); return 1; }
             std::atomic<size_t> next{0};
             std::atomic<int> bad{0};
             const auto t0 = Clock::now();
@@ -81,6 +83,10 @@ int main(int argc, char **argv) {
                             if (reg_prev[b]) { hipHostUnregister((void *)reg_prev[b]); reg_prev[b] = nullptr; }
                         }
                         const uint8_t *src = map + s * SLICE;
+                        if (mode[1] == 'p' || mode[0] == 'o') {
+                            if (madvise((void *)src, SLICE, 22 /* MADV_POPULATE_READ */) != 0) { bad = 3; break; }
+                            if (mode[0] == 'o') { used[b] = false; continue; }
+                        }
                         if (pr) {
                             size_t got = 0;
                             while (got < SLICE) {
@@ -90,7 +96,7 @@ int main(int argc, char **argv) {
                             }
                             if (strcmp(mode, "pread-only") == 0) { used[b] = false; continue; }
                             if (hipMemcpyAsync(d[b], h[b], SLICE, hipMemcpyHostToDevice, st) != hipSuccess) bad = 1;
-                        } else if (mode[0] == 'd') {
+                        } else if (mode[0] == 'd' || mode[0] == 'x') {
                             if (hipMemcpyAsync(d[b], src, SLICE, hipMemcpyHostToDevice, st) != hipSuccess) bad = 1;
                         } else {
                             if (hipHostRegister((void *)src, SLICE, hipHostRegisterDefault) != hipSuccess) { bad = 2; break; }
@@ -112,13 +118,13 @@ int main(int argc, char **argv) {
                 });
             for (auto &x : th) x.join();
             const double dt = secs(t0);
-            printf("%-10s T=%d  %.2f GB/s  (%.3f s)%s\n", mode, T, total / dt / 1e9, dt, bad.load() == 2 ? "  [hipHostRegister on the file mapping FAILED]" : bad.load() ? "  [error]" : "");
+            printf("%-10s T=%d  %.2f GB/s  (%.3f s)%s\n", mode, T, total / dt / 1e9, dt, bad.load() == 2 ? "  [hipHostRegister on the file mapping FAILED]" : bad.load() == 3 ? "  [madvise(MADV_POPULATE_READ) failed]" : bad.load() ? "  [error]" : "");
             fflush(stdout);
             (void)hipGetLastError();
+            munmap((void *)map, total);
             if (bad.load() == 2) break;
         }
     }
-    munmap((void *)map, total);
     close(fd);
     unlink(path.c_str());
     return 0;
