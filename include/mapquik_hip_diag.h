@@ -27,10 +27,10 @@ int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_
 int mq_probe_rate(mq_index *idx, uint32_t blocks, uint32_t per_thread, uint32_t bitmap_log2, uint32_t table_too, float *ms,
                   uint64_t *lookups, uint64_t *extra_steps);
 
-/* Diagnostic: shader-clock cycles the waves of the last map launch of the index's default context spent in each of 12 stages
+/* Diagnostic: shader-clock cycles the waves of the last map launch of the index's default context spent in each of 16 stages
  * (list in mapquik_amd/csrc/mq_device.hpp, mq_clk), summed over waves.  Only a library built with -DMQ_STAGE_CLOCKS fills
  * them (tools/stage_clocks.py builds one beside the product library); the product build returns zeros. */
-int mq_last_stage_clocks(mq_index *idx, uint64_t *out12);
+int mq_last_stage_clocks(mq_index *idx, uint64_t *out16);
 
 /* Time of the last map launch sequence of the index's default context / of a context, from events on its stream. */
 int mq_last_map_ms(mq_index *idx, float *ms);

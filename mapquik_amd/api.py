@@ -280,8 +280,8 @@ class Index:
         return ms.value
 
     def last_stage_clocks(self):
-        """Diagnostic (-DMQ_STAGE_CLOCKS builds): cycles per stage of the last launch, summed over waves (12 stages)."""
-        out = (C.c_uint64 * 12)()
+        """Diagnostic (-DMQ_STAGE_CLOCKS builds): cycles per stage of the last launch, summed over waves (16 stages)."""
+        out = (C.c_uint64 * 16)()
         if self._L.mq_last_stage_clocks(self._h, out) != 0:
             raise _err(self._L, "mq_last_stage_clocks")
         return [int(x) for x in out]

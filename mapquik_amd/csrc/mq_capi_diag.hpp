@@ -117,15 +117,15 @@ int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_
 
 // Diagnostic (-DMQ_STAGE_CLOCKS builds; zeros otherwise): shader-clock cycles the waves of the last map_kernel launch of the default
 // context spent per stage, summed over waves (stage list: mq_device.hpp, mq_clk).
-int mq_last_stage_clocks(mq_index *idx, uint64_t *out12) try {
-    if (!idx || !out12) return set_err(MQ_EINVAL, "bad arguments");
+int mq_last_stage_clocks(mq_index *idx, uint64_t *out16) try {
+    if (!idx || !out16) return set_err(MQ_EINVAL, "bad arguments");
     std::lock_guard<std::mutex> lk(idx->mu);
     mq_ctx *c = idx->def_ctx;
     if (!c->ev_valid) return set_err(MQ_ESTATE, "no map launch recorded");
     int rc = use_device(idx);
     if (rc) return rc;
     HIPCHK(hipEventSynchronize(c->ev1));
-    HIPCHK(hipMemcpy(out12, c->d_counter + 16, MQ_N_CLK * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out16, c->d_counter + 16, MQ_N_CLK * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return MQ_OK;
 } catch (const std::bad_alloc &) {
     return set_err(MQ_ENOMEM, "out of host memory");

@@ -101,7 +101,10 @@ __device__ __forceinline__ uint32_t lane_id() {
 // to stage i; map_kernel adds every wave's totals to counters[16..] at its end (read back by mq_last_stage_clocks).
 //   0 stage A  1 stage B  2 stage R  3 tile carry  4 list stores acknowledged  5 list -> LDS  6 tuple hashes + probe issue
 //   7 probe resolve + runs  8 runs finished, Match records in L2  9 chain + result  10 general seeder  11 next read (atomic, offsets)
-constexpr int MQ_N_CLK = 12;
+//   with -DMQ_STAGE_A_SPLIT stage A's time is charged to: 10 / 13 what precedes the super-row loop in a sequence's first / later
+//   tiles; 0 / 14 the wait for the bases of the first super-row of a first / later tile; 12 that wait for the other super-rows;
+//   15 the work (decode, look-ups, scan, stream) -- three more stamps per super-row, so only for looking inside stage A
+constexpr int MQ_N_CLK = 16;
 #ifdef MQ_STAGE_CLOCKS
 struct StageClkLds {
     unsigned long long acc[16][MQ_N_CLK];  // a workgroup has at most 16 waves (1,024 threads)

@@ -38,6 +38,7 @@ constexpr uint32_t SD_LC_MAX = (SD_CODES_MAX + 63) / 64;   // windows per lane
 constexpr uint32_t SD_FLAG_WORDS = (SD_LC_MAX + 31) / 32;  // 32-step flag words per lane
 constexpr uint32_t SD_CODES_DW = 4 * ((63 * SD_LC_MAX + 16 * ((SD_LC_MAX + 15) / 16) + MAX_L + 32) / 64 + 1);  // packed 2-bit codes + zero read-ahead padding (whole uint4s)
 static_assert((63 * SD_LC_MAX + 16 * ((SD_LC_MAX + 15) / 16) + MAX_L + 32) / 16 < SD_CODES_DW, "code stream read-ahead padding");
+static_assert(2 * SD_CODES_MAX / 32 + 2 < SD_CODES_DW, "stage A writes three dwords from a piece pair's first");
 #ifndef MQ_SD_OWNER_CAP
 #define MQ_SD_OWNER_CAP 256
 #endif
@@ -62,15 +63,17 @@ struct SeedTables {
 };
 
 // per-wave LDS of the seed kernel's fast path
+constexpr uint32_t SD_BLOCK_OF_BYTES = (SD_CODES_MAX / 64 + 3 + 15) / 16 * 16;
 struct SeedLds {
     uint32_t codes[SD_CODES_DW];                 // the tile's 2-bit code stream (carried l-1 codes first)
+    uint8_t block_of[SD_BLOCK_OF_BYTES];         // block_of[c]: the 64-base block that holds code 64 c (the walk to a code's block starts there);
+                                                 // directly behind codes: stage A zeroes both with one loop (block_of[0] must be 0)
     unsigned long long heads[SD_BLOCKS];         // bit b of heads[k]: raw base 64k + b of the tile is a run head
     uint16_t cnt[SD_BLOCKS + 4];                 // index in the code stream of block k's first run head; cnt[n_blocks] = n_codes
     uint32_t flagw[SD_FLAG_WORDS * 64];          // stage B -> stage R: bit t of flagw[w * 64 + L] <=> step 32 w + t of lane L is a candidate (word-major:
                                                  // a wave's write or read of one word index touches 64 consecutive dwords, conflict-free)
     uint32_t carry_codes[4];                     // codes carried into the next tile (<= 63)
     uint32_t carry_pos[64];                      // their raw positions
-    uint8_t block_of[SD_CODES_MAX / 64 + 3];     // block_of[c]: the 64-base block that holds code 64 c (the walk to a code's block starts there)
     uint16_t cand[SD_OWNER_CAP];                 // stage R: candidate (in position order, one round of them) -> its window (code index in the tile)
 };
 
@@ -209,10 +212,12 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
     const uint32_t tile_end = raw0 + n_sr * SD_SR_RAW;  // >= len in the sequence's last tile
     uint4 &nx0 = pre.nx0, &nx1 = pre.nx1, &nx2 = pre.nx2, &nx3 = pre.nx3;
     if (!SD_CROSS_PREFETCH && raw0 != 0) stage_a_request(seq, len, raw0, pre);
-    for (uint32_t i = lane * 4u; i < SD_CODES_DW; i += 256u) *reinterpret_cast<uint4 *>(&S.codes[i]) = make_uint4(0, 0, 0, 0);
+    static_assert(offsetof(SeedLds, block_of) == sizeof(uint32_t) * SD_CODES_DW && SD_CODES_DW % 4 == 0, "block_of is zeroed with the code stream");
+    // block_of[0] = 0 with the rest: codes [carry_n, 64): the walk starts at block 0 (whose range may begin after code 0)
+    for (uint32_t i = lane * 4u; i < SD_CODES_DW + SD_BLOCK_OF_BYTES / 4u; i += 256u)
+        *reinterpret_cast<uint4 *>(reinterpret_cast<uint32_t *>(&S) + i) = make_uint4(0, 0, 0, 0);
     wave_sync();
     if (lane < 4u && carry_n) S.codes[lane] = S.carry_codes[lane];  // the carried codes open the stream
-    if (lane == 0) S.block_of[0] = 0;  // codes [carry_n, 64): the walk starts at block 0 (whose range may begin after code 0)
     uint32_t b2 = 2u * carry_n;  // bits written so far = 2 * codes
     uint32_t bad = 0;
     constexpr uint32_t S1 = 0x00430041u, S0 = 0x00470054u;  // v_perm pool: selector 0,2 -> 'A','C' ; 4,6 -> 'T','G'
@@ -225,6 +230,11 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
             nx2 = fix_piece(nx2, len, pos + 32u);
             nx3 = fix_piece(nx3, len, pos + 48u);
         }
+#ifdef MQ_STAGE_A_SPLIT
+        if (sr == 0) mq_clk(raw0 == 0 ? 10 : 13);  // what precedes the loop (code stream zeroed, carried codes)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        mq_clk(sr == 0 ? (raw0 == 0 ? 0 : 14) : 12);  // the wait for the super-row's bases
+#endif
         uint32_t p[4];
         // decode piece j, then send the load of the NEXT super-row's piece j into the registers just freed: 16 registers of
         // bases in flight plus the piece being decoded, instead of two whole super-rows.  (When nothing follows the load is made all
@@ -236,7 +246,11 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
             bad |= (__builtin_amdgcn_perm(S0, S1, t0) ^ nx.x) | (__builtin_amdgcn_perm(S0, S1, t1) ^ nx.y) |
                    (__builtin_amdgcn_perm(S0, S1, t2) ^ nx.z) | (__builtin_amdgcn_perm(S0, S1, t3) ^ nx.w);
             p[j] = pack16(t0, t1, t2, t3);
+#ifdef MQ_EXPERIMENT_COALESCED  // WRONG RESULTS: timing experiment only (a wave's piece j = 1 KB contiguous)
+            nx = load_piece(seq, len, raw0 + (sr + 1u) * SD_SR_RAW + 1024u * j + 16u * lane);
+#else
             nx = load_piece(seq, len, pos + SD_SR_RAW + 16u * j);
+#endif
         };
         decode(nx0, 0);
         decode(nx1, 1);
@@ -284,18 +298,26 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
             if (m < c1) S.block_of[m >> 6] = (uint8_t)(sr * 64u + lane);
         }
         S.heads[sr * 64u + lane] = (unsigned long long)(hb[0] | (hb[1] << 16)) | ((unsigned long long)(hb[2] | (hb[3] << 16)) << 32);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (n2[j]) {
-                const uint32_t sh = bo & 31u;
-                atomicOr(&S.codes[bo >> 5], out[j] << sh);
-                const uint32_t hi = sh ? out[j] >> (32u - sh) : 0u;
-                if (hi) atomicOr(&S.codes[(bo >> 5) + 1u], hi);
-            }
-            bo += n2[j];
-        }
+        // The lane's codes go into the stream two pieces at a time: the pair joined in registers (<= 64 bits), shifted to its bit offset
+        // (<= 96 bits) and OR-ed into three dwords, whatever their content -- a zero costs an LDS operation, a test costs a branch.
+        // (Piece by piece, each with its two conditional ORs, this was 76 instructions a super-row; now 30.)  The dwords behind the
+        // stream's end that this may touch are padding (SD_CODES_DW) and receive zeros only.
+        auto put_pair = [&](uint32_t o_a, uint32_t n_a, uint32_t o_b, uint32_t bit) {
+            const uint64_t v = (uint64_t)o_a | ((uint64_t)o_b << n_a);  // n_a <= 32
+            const uint32_t sh = bit & 31u;
+            const uint64_t x = (uint64_t)(uint32_t)v << sh, y = (v >> 32) << sh;
+            uint32_t *dst = &S.codes[bit >> 5];
+            atomicOr(dst, (uint32_t)x);
+            atomicOr(dst + 1, (uint32_t)(x >> 32) | (uint32_t)y);
+            atomicOr(dst + 2, (uint32_t)(y >> 32));
+        };
+        put_pair(out[0], n2[0], out[1], bo);
+        put_pair(out[2], n2[2], out[3], bo + n2[0] + n2[1]);
         b2 += total;
         carry_prev = rdlane(p[3], 63) >> 30;
+#ifdef MQ_STAGE_A_SPLIT
+        mq_clk(15);
+#endif
     }
     n_blocks = n_sr * 64u;
     raw_end = raw0 + n_sr * SD_SR_RAW < len ? raw0 + n_sr * SD_SR_RAW : len;
