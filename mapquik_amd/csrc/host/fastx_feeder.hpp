@@ -97,26 +97,44 @@ class Feeder {
     }
     ~Feeder() {
         stop();
+        populate_stop_ = true;
+        if (populate_thread_.joinable()) populate_thread_.join();
         for (auto &c : all_) release_(c->own ? c->own : c->buf);
         if (map_) munmap((void *)map_, map_size_);
         if (fd_ >= 0) close(fd_);
     }
 
-    void start() {
-        if (leave_unparsed_ && kind_ == 0 && !fastq_ && file_size_ > 0 && getenv("MQ_FEEDER_MAPPED_FASTA")) {
-            // MQ_FEEDER_MAPPED_FASTA=1 (experimental; measured slower than pread into page-locked chunks inside the driver, profiles/NOTES.md):
-            // nothing is read here at all -- the file is mapped and a chunk is a view of its records, its whole pages page-locked by the
-            // reader threads so that the copy to the device is a DMA out of the page cache
-            const uint8_t *m = (const uint8_t *)mmap(nullptr, file_size_, PROT_READ, MAP_SHARED, fd_, 0);
-            if (m != MAP_FAILED) {
-                map_ = m;
-                map_size_ = file_size_;
-                mapped_fasta_ = true;
-                // the chunks' pages are locked by the reader threads (MQ_FEEDER_NO_PAGE_LOCK=1: the copies read pageable memory)
-                page_ = (uint64_t)sysconf(_SC_PAGESIZE);
-                lock_pages_ = page_ > 0 && !getenv("MQ_FEEDER_NO_PAGE_LOCK");
+    // EXPERIMENT (MQ_FEEDER_MAPPED_FASTA=1; off by default).  Raw FASTA whose records the consumer finds (leave_unparsed): map the file
+    // now and fill the mapping's page tables in the background -- no byte of the file is read, the kernel only enters the page-cache
+    // pages into this process's address space.  A chunk is then a view of the mapping and its copy to the device a DMA out of the page
+    // cache.  Measured (profiles/r04_file_h2d.txt, profiles/r04_feeder_scaling.txt): a probe copies from a mapping with full page
+    // tables at 46-50 GB/s with two threads and from a fresh one at 12-17; inside the driver, mapped while the reference is indexed,
+    // this path reaches 26-31 Gbases/s against 34-35 for pread into page-locked chunks, which therefore stays the default.
+    void premap() {
+        const char *e = getenv("MQ_FEEDER_MAPPED_FASTA");
+        if (!(leave_unparsed_ && kind_ == 0 && !fastq_ && file_size_ > 0) || !e || atoi(e) == 0 || map_) return;
+        const uint8_t *m = (const uint8_t *)mmap(nullptr, file_size_, PROT_READ, MAP_SHARED, fd_, 0);
+        if (m == MAP_FAILED) return;
+        map_ = m;
+        map_size_ = file_size_;
+        mapped_fasta_ = true;
+        page_ = (uint64_t)sysconf(_SC_PAGESIZE);
+        lock_pages_ = page_ > 0 && getenv("MQ_FEEDER_PAGE_LOCK") != nullptr;  // experiment: the reader threads page-lock each chunk's pages
+        populate_thread_ = std::thread([this] {
+            const uint64_t step = 64ull << 20;
+            for (uint64_t o = 0; o < map_size_ && !populate_stop_.load(std::memory_order_relaxed); o += step) {
+                const uint64_t n = std::min<uint64_t>(step, map_size_ - o);
+#ifdef MADV_POPULATE_READ
+                if (madvise((void *)(map_ + o), n, MADV_POPULATE_READ) != 0) break;  // an older kernel: pages are entered as they are touched
+#else
+                if (madvise((void *)(map_ + o), n, 22) != 0) break;
+#endif
+                populated_.store(o + n, std::memory_order_release);
             }
-        }
+        });
+    }
+
+    void start() {
         if (mapped_fasta_) {
             for (int t = 0; t < n_threads_; ++t) threads_.emplace_back([this] { mapped_fasta_worker(); });
         } else if (lean_fastq_) {
@@ -207,7 +225,7 @@ class Feeder {
     void leave_unparsed(bool on) { leave_unparsed_ = on; }
     bool fastq() const { return fastq_; }
     // chunks will be (after start(): are) views of the mapped file (see start())
-    bool mapped_views() const { return mapped_fasta_ || (leave_unparsed_ && kind_ == 0 && !fastq_ && file_size_ > 0 && getenv("MQ_FEEDER_MAPPED_FASTA")); }
+    bool mapped_views() const { return mapped_fasta_; }
     const char *kind_name() const { return kind_ == 0 ? "raw" : kind_ == 1 ? (gz_whole_ ? "gzip (libdeflate, whole members)" : "gzip") : kind_ == 2 ? "lz4" : "bgzf"; }
 
   private:
@@ -881,6 +899,9 @@ class Feeder {
     std::vector<std::unique_ptr<Chunk>> all_;
     std::deque<Chunk *> free_, ready_, to_parse_;
     std::vector<std::thread> threads_;
+    std::thread populate_thread_;  // premap(): fills the mapping's page tables ahead of the readers
+    std::atomic<bool> populate_stop_{false};
+    std::atomic<uint64_t> populated_{0};
     int done_workers_ = 0;
     bool inflate_done_ = false, stopping_ = false, aborted_ = false;
     std::string error_;

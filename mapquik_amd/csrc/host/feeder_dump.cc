@@ -68,7 +68,10 @@ int main(int argc, char **argv) {
         // come unparsed (FEEDER_DUMP_MAPPED=1: as views of the mapped file), the line ends are found by a plain scan, a chunk that is not
         // "header line, sequence line" all through is parsed by parse_chunk after all (materialized first when it is a view)
         const bool unparsed_mode = getenv("FEEDER_DUMP_UNPARSED") != nullptr;
-        if (unparsed_mode) f.leave_unparsed(true);
+        if (unparsed_mode) {
+            f.leave_unparsed(true);
+            f.premap();
+        }
         if (getenv("FEEDER_DUMP_KIND")) fprintf(stderr, "kind=%s\n", f.kind_name());
         f.start();
         unsigned long long n_unparsed = 0, n_irregular = 0;

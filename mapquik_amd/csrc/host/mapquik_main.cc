@@ -136,6 +136,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         // chunks (pread, cut at record starts), the records are found on the device (mq_ctx_submit_fasta) and the host reads a header
         // only to print it.  MQ_DRIVER_HOST_PARSE=1: every chunk is parsed by the reader threads as in earlier rounds (same PAF; tests compare).
         feed.leave_unparsed(reads_fasta && getenv("MQ_DRIVER_HOST_PARSE") == nullptr);
+        feed.premap();  // MQ_FEEDER_MAPPED_FASTA=1 only (experiment): the file is mapped, not read, while the reference is indexed
         // The read feeder starts when the index is ready.  MQ_DRIVER_PREFETCH=1 starts it while the reference is still being indexed
         // (it then allocates its page-locked chunk buffers and parses the first chunks early): that was the default while pinning
         // the pool was the read phase's start-up cost; with the huge-page pool it makes the map phase 15 % shorter and the index
@@ -258,7 +259,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         std::deque<Chunk *> to_format;               // mapped, waiting for a formatter
         std::map<size_t, Chunk *> done;              // formatted, waiting for their turn in the output
         // Submitting threads per GPU (n_sub).  Chunks that are views of the mapped file are copied to the device from pageable memory: that
-        // copy occupies the thread that asks for it, hence two (experimental path, MQ_FEEDER_MAPPED_FASTA=1; profiles/r04_file_h2d.txt: 14-17 GB/s).
+        // copy occupies the thread that asks for it, hence two (experimental path, MQ_FEEDER_MAPPED_FASTA=1; see Feeder::premap).
         int gpu_workers_left = o.gpus * n_sub;
         int formatting = 0;                          // chunks a formatter is working on right now
         std::string werr;

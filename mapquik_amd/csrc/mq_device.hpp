@@ -104,6 +104,8 @@ __device__ __forceinline__ uint32_t lane_id() {
 //   with -DMQ_STAGE_A_SPLIT stage A's time is charged to: 10 / 13 what precedes the super-row loop in a sequence's first / later
 //   tiles; 0 / 14 the wait for the bases of the first super-row of a first / later tile; 12 that wait for the other super-rows;
 //   15 the work (decode, look-ups, scan, stream) -- three more stamps per super-row, so only for looking inside stage A
+//   with -DMQ_STAGE_MAP_SPLIT stage 7 is split: 12 home buckets' keys arrived and compared, payloads requested; 13 lookups that walk on;
+//   14 payloads arrived; 7 the runs
 constexpr int MQ_N_CLK = 16;
 #ifdef MQ_STAGE_CLOCKS
 struct StageClkLds {
@@ -680,6 +682,9 @@ struct MapSink {
                 st |= s2 << (2 * c);
             }
         }
+#ifdef MQ_STAGE_MAP_SPLIT
+        mq_clk(12);
+#endif
         // walking on (about one lookup in a hundred: both ways of the home bucket hold other keys).  Every lane takes ONE of its
         // walking lookups at a time -- its key by a select over the batches, a loop over the following buckets shared by all lanes,
         // the outcome written back by a select -- so the rare path holds six registers instead of looping over all NB batches.
@@ -869,6 +874,11 @@ struct MapSink {
         mq_clk(6);
         uint32_t st;
         probe_all<NB>(key, kk, actbits, st);
+#ifdef MQ_STAGE_MAP_SPLIT
+        mq_clk(13);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        mq_clk(14);
+#endif
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
             if ((uint32_t)c * 64u < K) {

@@ -272,7 +272,7 @@ def test_feeder_unparsed_fasta_chunks(tool, tmp_path, crlf):
             p = tmp_path / "u.fa"
             p.write_text(t, newline="")
             for chunk, th in ((64, 3), (777, 1), (5000, 4), (1 << 20, 2)):
-                for extra in ({}, {"MQ_FEEDER_MAPPED_FASTA": "1"}, {"MQ_FEEDER_MAPPED_FASTA": "1", "MQ_FEEDER_NO_PAGE_LOCK": "1"}):
+                for extra in ({}, {"MQ_FEEDER_MAPPED_FASTA": "1"}, {"MQ_FEEDER_MAPPED_FASTA": "1", "MQ_FEEDER_PAGE_LOCK": "1"}):
                     env = dict(os.environ, FEEDER_DUMP_UNPARSED="1", **extra)
                     r = subprocess.run([tool, str(p), "fasta", str(chunk), str(th)], capture_output=True, text=True, timeout=60, env=env)
                     assert r.returncode == 0, r.stderr

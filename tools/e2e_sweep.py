@@ -65,6 +65,16 @@ with tempfile.TemporaryDirectory(dir=base) as wd:
             run(bz, int(o[nq]), ["--threads", str(th)], "FASTA bgzf (quarter of the reads), %d threads, no prefetch" % th, NP)
         run(bz, int(o[nq]), ["--threads", "16"], "FASTA bgzf (quarter of the reads), 16 threads, prefetch")
         sys.exit(0)
+    if os.environ.get("E2E_R4M"):  # the mapped file, its page tables filled while the reference is indexed
+        T = {"MQ_DRIVER_TIMING": "1"}
+        run(rd, bases, ["--threads", "4"], "warm-up")
+        for th in (2, 4, 8):
+            run(rd, bases, ["--threads", str(th)], "FASTA %d threads, mapped early, copies from pageable memory" % th, dict(T, MQ_FEEDER_MAPPED_FASTA="1"))
+        for th in (2, 4, 8):
+            run(rd, bases, ["--threads", str(th)], "FASTA %d threads, mapped early, pages locked by the readers" % th, dict(T, MQ_FEEDER_MAPPED_FASTA="1", MQ_FEEDER_PAGE_LOCK="1"))
+        for th in (4, 8):
+            run(rd, bases, ["--threads", str(th)], "FASTA %d threads, pread chunks" % th, T)
+        sys.exit(0)
     if os.environ.get("E2E_R4T"):  # where the threads' time goes (MQ_DRIVER_TIMING)
         T = {"MQ_DRIVER_TIMING": "1"}
         run(rd, bases, ["--threads", "4"], "warm-up")

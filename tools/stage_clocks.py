@@ -16,6 +16,8 @@ sys.path.insert(0, ROOT)
 NAMES = ["stage A decode+HPC", "stage B rolling hash", "stage R candidates", "tile carry", "list stores acknowledged", "list -> LDS",
          "tuple hash + probe issue", "probe resolve + runs", "runs done, Match records in L2", "chain + result", "general seeder", "next read",
          "A*: wait for bases, super-rows 2, 3", "A*: before the loop, later tiles", "A*: wait for bases, later tiles", "A*: work"]
+# -DMQ_STAGE_MAP_SPLIT builds instead: 12 = keys arrived + compared, payloads requested; 13 = lookups walking on; 14 = payloads arrived;
+# "probe resolve + runs" = the runs alone.
 # A*: builds with -DMQ_STAGE_A_SPLIT only; then "stage A" = wait for the bases of a sequence's first super-row, "general seeder" = what
 # precedes the loop in a sequence's first tile (every stamp costs the wave an s_memtime round trip: ~400 cycles)
 
