@@ -104,7 +104,16 @@ __device__ __forceinline__ uint32_t seed_read_general(const SplitArgs &A, WaveLd
 #define MQ_ML_NB 7
 #endif
 constexpr int ML_NB = MQ_ML_NB;                              // lane-batches of 64 k-min-mers hashed and probed together
-constexpr uint32_t ML_LIST_CAP = 64 * ML_NB + 64;      // minimizers staged in LDS at a time (64 * ML_NB + k - 1 used)
+constexpr uint32_t ML_LIST_CAP = 64 * ML_NB + MAX_L;   // minimizers staged in LDS at a time (64 * ML_NB + k - 1 used, k <= 32)
+static_assert(MAX_L >= 32, "k - 1 <= 31 entries of overlap between chunks");
+// MQ_LDS_LIST = n > 0: map_kernel keeps the first n minimizers of the read it is working on in LDS (mq_seed.hpp LdsThenGlobalList): the
+// list of an ordinary read is never written to device memory nor read back.  Needs the LDS of one 16-wave workgroup per CU with
+// two-super-row tiles (MQ_MAP_WAVES=16, MQ_SD_MAX_SR=2).
+#ifndef MQ_LDS_LIST
+#define MQ_LDS_LIST 0
+#endif
+constexpr uint32_t LDS_LIST_CAP = MQ_LDS_LIST;
+typedef LdsList<(LDS_LIST_CAP ? LDS_LIST_CAP : 1)> ReadListLds;
 struct MapListLds {
     unsigned long long h[ML_LIST_CAP];
     uint32_t p[ML_LIST_CAP];
@@ -120,9 +129,11 @@ __device__ __forceinline__ void store_hit(const SplitArgs &A, uint32_t r, const 
     }
 }
 
+// lds_h / lds_p: the whole list (cnt entries) already in LDS -- then nothing is staged; nullptr: the list is at `base` in device memory
 template <int CH, bool TIMING>
 __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, MatchRec *scratch, uint32_t r, uint64_t len, uint32_t cnt,
-                                         uint64_t base, unsigned long long &t_steps, unsigned long long &t_lookups, mq_hit &h) {
+                                         uint64_t base, unsigned long long &t_steps, unsigned long long &t_lookups, mq_hit &h,
+                                         const unsigned long long *lds_h = nullptr, const uint32_t *lds_p = nullptr) {
     const uint32_t lane = lane_id();
     const DevParams &P = A.P;
     h.status = MQ_HIT_UNMAPPED;
@@ -143,7 +154,7 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
         const uint32_t chunk = 64u * (uint32_t)ML_NB + P.k - 1u;
         for (uint32_t g = 0; g + P.k <= cnt;) {
             const uint32_t have = cnt - g < chunk ? cnt - g : chunk;
-            {  // L2-served loads (the list may have been written by this very wave), ALL in flight before the first is stored: one L2
+            if (!lds_h) {  // L2-served loads (the list may have been written by this very wave), ALL in flight before the first is stored: one L2
                // round trip per chunk (a loop that loads and stores 64 entries at a time exposes one per 64 entries)
                 unsigned long long hv[ML_NB + 1];
                 uint32_t pv[ML_NB + 1];
@@ -168,7 +179,7 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
             }
             wave_sync();
             mq_clk(5);
-            sink.template consume_list<ML_NB>(S.h, S.p, have);
+            sink.template consume_list<ML_NB>(lds_h ? lds_h + g : S.h, lds_p ? lds_p + g : S.p, have);
             wave_sync();
             g += have - (P.k - 1u);
         }
@@ -213,6 +224,9 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
     __shared__ struct {
         SeedTables T;
         MapWaveLds SS[MAP_WAVES];
+#if MQ_LDS_LIST
+        ReadListLds LL[MAP_WAVES];
+#endif
     } W;
     SeedTables &T = W.T;
     MapWaveLds(&SS)[MAP_WAVES] = W.SS;
@@ -249,6 +263,7 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         if (lane == 0) rn_v = atomicAdd(&A.counters[0], 1u);
         uint32_t cnt = 0;
         uint64_t base = 0;
+        bool in_lds = false;  // the read's whole minimizer list is in W.LL[wv] (MQ_LDS_LIST builds)
         mq_clk(11);
         // extract(): len < l + k - 1 => None (src/mers.rs:44)
         if (len >> 32) {
@@ -257,7 +272,32 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
             uint32_t cap;
             list_region(A, o0 - o_base, len, r, base, cap);
             APre pre;
+#if MQ_LDS_LIST
+            cnt = SD_NOT_FAST;
+            if (!A.force_general) {
+                ReadListLds &L = W.LL[wv];
+                const LdsThenGlobalList<LDS_LIST_CAP> out = {L, {A.mz_hash + base, A.mz_pos + base, cap}};
+                cnt = seed_sequence_fast_to<0, false, LdsThenGlobalList<LDS_LIST_CAP>>(A.bases + o0, (uint32_t)len, P, T, S.seed, out, pre, false);
+                if (cnt != SD_NOT_FAST) {
+                    if (cnt <= LDS_LIST_CAP) {
+                        in_lds = true;
+                    } else if (cnt <= cap) {  // a long read: the head of its list joins the rest in its region
+                        wave_sync();
+                        for (uint32_t i = lane; i < LDS_LIST_CAP; i += 64u) {
+                            A.mz_hash[base + i] = L.h[i];
+                            A.mz_pos[base + i] = L.p[i];
+                        }
+                    } else if (pool_take(A, cnt, base)) {  // denser than its region: once more, into an exact-size pool region
+                        seed_sequence_fast(A.bases + o0, (uint32_t)len, P, T, S.seed, A.mz_hash + base, A.mz_pos + base, cnt, pre, false);
+                        n_moved++;
+                    } else {
+                        cnt = LIST_OVERFLOW;
+                    }
+                }
+            }
+#else
             cnt = A.force_general ? SD_NOT_FAST : seed_read_fast(A, T, S.seed, A.bases + o0, (uint32_t)len, base, cap, n_moved, pre, false);
+#endif
             if (cnt == SD_NOT_FAST) {
                 n_general++;
                 wave_sync();
@@ -266,7 +306,7 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
             } else {
                 n_fast++;
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have reached L2
+            if (!in_lds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have reached L2
             wave_sync();
             mq_clk(4);
         }
@@ -279,7 +319,11 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
             else n_o1 = A.offsets[rn + 1];
         }
         mq_hit h;
+#if MQ_LDS_LIST
+        map_read<CH, TIMING>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h, in_lds ? W.LL[wv].h : nullptr, in_lds ? W.LL[wv].p : nullptr);
+#else
         map_read<CH, TIMING>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h);
+#endif
         wave_sync();
         const uint32_t r_done = r;
         r = rn;

@@ -670,17 +670,53 @@ __device__ __forceinline__ uint32_t seed_rawpos_batch(const SeedLds &S, uint32_t
     return j < carry_n ? cpos : pos;
 }
 
+// Where a sequence's minimizers go: entry `dest` of its list.
+struct GlobalList {  // a region of the minimizer buffers in device memory (entries beyond cap are dropped: the caller sees the count)
+    unsigned long long *__restrict__ hash;
+    uint32_t *__restrict__ pos;
+    uint32_t cap;
+    __device__ __forceinline__ void put(uint32_t dest, uint64_t hv, uint32_t p) const {
+        if (dest < cap) {
+            hash[dest] = hv;
+            pos[dest] = p;
+        }
+    }
+};
+// The fused kernel: the first LCAP entries stay in the wave's LDS (map_kernel's map phase reads them there: an ordinary read's list
+// never visits device memory), entries beyond go to the read's region as before (the caller then copies the LDS part behind them).
+template <uint32_t LCAP>
+struct LdsList {
+    unsigned long long h[LCAP];
+    uint32_t p[LCAP];
+};
+template <uint32_t LCAP>
+struct LdsThenGlobalList {
+    LdsList<LCAP> &L;
+    GlobalList G;
+    __device__ __forceinline__ void put(uint32_t dest, uint64_t hv, uint32_t p) const {
+        // typed LDS stores: left generic, the compiler folds the two branches into ONE flat store through a selected pointer -- which
+        // counts on both the LDS and the memory counter and costs every later LDS wait a memory round trip
+        typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+        typedef __attribute__((address_space(3))) uint32_t lds_u32;
+        if (dest < LCAP) {
+            *(lds_u64 *)(&L.h[dest]) = hv;
+            *(lds_u32 *)(&L.p[dest]) = p;
+        } else {
+            G.put(dest, hv, p);
+        }
+    }
+};
+
 // Lists the tile's candidates in position order (lane = candidate), resolves their raw positions and appends them to the
 // sequence's minimizer list.  Returns the number of minimizers appended; sets inexact when a candidate fails the exact
 // 64-bit test (the sequence then goes to the general path, whose test is exact by construction).
 // Every lane first writes the windows of its own candidates to their places in the list (its flags are in registers: lowest
 // set bit, clear, next), so that a candidate's lane afterwards reads ONE value and starts its look-ups -- no search for the owning
 // lane, no bit select in another lane's flags.
-template <bool VIEW = false>
+template <bool VIEW = false, class Out = GlobalList>
 __device__ __forceinline__ uint32_t seed_stage_r(const SeedTables &T, SeedLds &S, const DevParams &P, uint32_t w_eff,
                                                  uint32_t n_blocks, uint32_t n_codes, uint32_t raw_base, uint32_t carry_n,
-                                                 unsigned long long *__restrict__ mz_hash, uint32_t *__restrict__ mz_pos, uint32_t out_base,
-                                                 uint32_t out_cap, bool &inexact, const SeedView &V = SeedView()) {
+                                                 const Out &out, uint32_t out_base, bool &inexact, const SeedView &V = SeedView()) {
     const uint32_t lane = lane_id();
     const uint32_t lc = (w_eff + 63u) >> 6;
     uint32_t n_listed = 0;  // VIEW: candidates that start before V.elig_end (positions ascend: they come first)
@@ -731,10 +767,7 @@ __device__ __forceinline__ uint32_t seed_stage_r(const SeedTables &T, SeedLds &S
                 if (hv > P.bound) inexact = true;
                 const uint32_t dest = out_base + i;
                 const bool listed = !VIEW || pos < V.elig_end;
-                if (listed && dest < out_cap) {
-                    mz_hash[dest] = hv;
-                    mz_pos[dest] = VIEW ? pos + V.pos_add : pos;
-                }
+                if (listed) out.put(dest, hv, VIEW ? pos + V.pos_add : pos);
                 if (VIEW) n_listed += (uint32_t)__popcll(__ballot(listed));
             }
         }
@@ -754,11 +787,9 @@ __device__ __forceinline__ bool seed_fast_eligible(uint64_t len) { return len >=
 // pre / pre_valid: the sequence's first super-row already requested by the caller (stage_a_request); else it is requested here.
 // VIEW: seq[0, len) is a window of a longer sequence (SeedView): only the minimizers that start before V.elig_end are listed and
 // counted, positions are shifted by V.pos_add, the base in front of the view decides whether its first base is a run head.
-template <int STOP = 0, bool VIEW = false>
-__device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict__ seq, uint32_t len, const DevParams &P, const SeedTables &T,
-                                                       SeedLds &S, unsigned long long *__restrict__ mz_hash,
-                                                       uint32_t *__restrict__ mz_pos, uint32_t out_cap, APre &pre, bool pre_valid,
-                                                       const SeedView &V = SeedView()) {
+template <int STOP = 0, bool VIEW = false, class Out = GlobalList>
+__device__ __forceinline__ uint32_t seed_sequence_fast_to(const uint8_t *__restrict__ seq, uint32_t len, const DevParams &P, const SeedTables &T,
+                                                          SeedLds &S, const Out &out, APre &pre, bool pre_valid, const SeedView &V = SeedView()) {
     const uint32_t lane = lane_id();
     uint32_t raw0 = 0, carry_n = 0, carry_prev = VIEW ? (V.first_prev & 3u) : 0u, n_out = 0;
     uint32_t halo_heads = 0, seg_heads = 0;  // VIEW: run heads at or behind V.elig_end / in front of it
@@ -787,7 +818,7 @@ __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict
             mq_clk(1);
             if (STOP != 2) {
                 bool inexact = false;
-                n_out += seed_stage_r<VIEW>(T, S, P, w_eff, n_blocks, n_codes, raw0, carry_n, mz_hash, mz_pos, n_out, out_cap, inexact, V);
+                n_out += seed_stage_r<VIEW, Out>(T, S, P, w_eff, n_blocks, n_codes, raw0, carry_n, out, n_out, inexact, V);
                 mq_clk(2);
                 if (inexact) return SD_NOT_FAST;
             }
@@ -816,6 +847,15 @@ __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict
     // too few run heads behind elig_end (long homopolymer runs): the general seeder takes the segment -- unless no l-mer starts in it at all
     if (VIEW && V.more_after && halo_heads + 1u < P.l && seg_heads != 0u) return SD_NOT_FAST;
     return n_out;
+}
+// the list in device memory: mz_hash[0, out_cap), mz_pos[0, out_cap)
+template <int STOP = 0, bool VIEW = false>
+__device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict__ seq, uint32_t len, const DevParams &P, const SeedTables &T,
+                                                       SeedLds &S, unsigned long long *__restrict__ mz_hash,
+                                                       uint32_t *__restrict__ mz_pos, uint32_t out_cap, APre &pre, bool pre_valid,
+                                                       const SeedView &V = SeedView()) {
+    const GlobalList out = {mz_hash, mz_pos, out_cap};
+    return seed_sequence_fast_to<STOP, VIEW, GlobalList>(seq, len, P, T, S, out, pre, pre_valid, V);
 }
 
 }  // namespace mq
