@@ -610,12 +610,16 @@ __device__ __forceinline__ void chain_stage(MatchRec *__restrict__ scratch, uint
 }
 
 // ------------------------------------------------------------------ the map stage's consumer of an ordered minimizer list
+// Match records a wave keeps in LDS next to the staged list (the space the seed phase's larger LDS leaves unused during the map phase):
+// an ordinary read has a handful, and chaining them from LDS saves the wait for their stores and the loads' round trip through L2
+constexpr uint32_t MAP_LDS_RECS = 48;
 struct MapSink {
     const Bucket *__restrict__ table;
     uint64_t mask;
     const DevParams &P;
     MatchRec *__restrict__ scratch;
     uint32_t cap_matches;
+    MatchRec *lds_rec;  // the first MAP_LDS_RECS Match records also go to LDS: a read with no more than that is chained from there
     mq_kminmer *__restrict__ dump;  // optional k-min-mer dump window for this read
     uint32_t dump_cap;
     // wave-uniform state
@@ -626,8 +630,13 @@ struct MapSink {
     uint32_t c_hit = 0, c_id = 0, c_off = 0, c_sigma = 0;  // last element of the previous batch
     uint32_t probe_steps = 0;  // per lane: slots visited beyond the home slot (diagnostic: mean probes per lookup)
 
-    __device__ MapSink(const Bucket *t, uint64_t m, const DevParams &p, MatchRec *s, uint32_t cap, mq_kminmer *d, uint32_t dc)
-        : table(t), mask(m), P(p), scratch(s), cap_matches(cap), dump(d), dump_cap(dc) {}
+    __device__ MapSink(const Bucket *t, uint64_t m, const DevParams &p, MatchRec *s, uint32_t cap, MatchRec *lr, mq_kminmer *d, uint32_t dc)
+        : table(t), mask(m), P(p), scratch(s), cap_matches(cap), lds_rec(lr), dump(d), dump_cap(dc) {}
+    // record i of the read: to its place in the wave's scratch in device memory and, the first MAP_LDS_RECS, to LDS
+    __device__ __forceinline__ void put_rec(uint32_t i, const MatchRec &m) const {
+        if (i < cap_matches) scratch[i] = m;
+        if (i < MAP_LDS_RECS) lds_rec[i] = m;
+    }
 
     // k-min-mer `base + lane` of a minimizer list: canonical orientation, tuple hash, query coordinates
     __device__ __forceinline__ void batch_keys(const unsigned long long *mzh, const uint32_t *mzp, uint32_t base, bool act,
@@ -745,15 +754,10 @@ struct MapSink {
         //   forward run continues iff r.offset - p.offset == 1                                      (cf)
         const uint32_t r_id = e.id_rc >> 1;
         const uint32_t srel = (hit && (rev != ((e.id_rc & 1u) != 0))) ? 1u : 0u;  // q.rev != r.rc
-        // previous element's entry: DPP wave shift right by one lane (lane 0 takes the carried element)
-        uint32_t hit_p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(hit ? 1u : 0u), 0x138, 0xf, 0xf, false);
-        uint32_t id_p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r_id, 0x138, 0xf, 0xf, false);
-        uint32_t off_p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)e.offset, 0x138, 0xf, 0xf, false);
-        if (lane == 0) {
-            hit_p = c_hit;
-            id_p = c_id;
-            off_p = c_off;
-        }
+        // previous element's entry: DPP wave shift right by one lane; lane 0 has no source lane and keeps `old` = the carried element
+        const uint32_t hit_p = (uint32_t)__builtin_amdgcn_update_dpp((int)c_hit, (int)(hit ? 1u : 0u), 0x138, 0xf, 0xf, false);
+        const uint32_t id_p = (uint32_t)__builtin_amdgcn_update_dpp((int)c_id, (int)r_id, 0x138, 0xf, 0xf, false);
+        const uint32_t off_p = (uint32_t)__builtin_amdgcn_update_dpp((int)c_off, (int)e.offset, 0x138, 0xf, 0xf, false);
         const bool both = hit && hit_p;
         const bool cf = both && ((int32_t)(e.offset - off_p) == 1);
         const bool cr = both && r_id == id_p && srel == 1u && ((int32_t)(off_p - e.offset) == 1);
@@ -763,25 +767,24 @@ struct MapSink {
         // composition: the state after it is 1 iff the nearest preceding constant element (or the carry) left state 1.
         const uint32_t sv = srel ? 2u : 1u;
         const bool nonconst = cf && srel == 1u;
-        const uint64_t constmask = __ballot(!nonconst);
-        const uint64_t constF = __ballot(!nonconst && hit && sv == 1u);
-        const uint64_t lt_mask = lane ? (~0ull >> (64u - lane)) : 0ull;  // lanes below this one
-        uint32_t sigma;
-        {
+        uint32_t sigma = hit ? sv : 0u;
+        if (__ballot(nonconst)) {  // rare (a forward step between entries whose strands disagree with the read's): most batches skip this
+            const uint64_t constmask = __ballot(!nonconst);
+            const uint64_t constF = __ballot(!nonconst && hit && sv == 1u);
+            const uint64_t lt_mask = lane ? (~0ull >> (64u - lane)) : 0ull;  // lanes below this one
             const uint64_t below = constmask & lt_mask;
             const bool baseF = below ? ((constF >> (63 - __clzll((long long)below))) & 1ull) != 0 : (c_sigma == 1u);
-            sigma = nonconst ? (baseF ? 1u : 2u) : (hit ? sv : 0u);
+            if (nonconst) sigma = baseF ? 1u : 2u;
         }
-        const uint64_t stF = __ballot(sigma == 1u), stR = __ballot(sigma == 2u);
-        const bool prevF = lane ? ((stF >> (lane - 1u)) & 1ull) != 0 : (c_sigma == 1u);
-        const bool prevR = lane ? ((stR >> (lane - 1u)) & 1ull) != 0 : (c_sigma == 2u);
+        const uint32_t sigma_p = (uint32_t)__builtin_amdgcn_update_dpp((int)c_sigma, (int)sigma, 0x138, 0xf, 0xf, false);  // lane 0: the carried state
+        const bool prevF = sigma_p == 1u, prevR = sigma_p == 2u;
         const bool isnew = hit && !((prevF && cf) || (prevR && cr));
         const uint64_t hitmask = __ballot(hit);
         const uint64_t newmask = __ballot(isnew);
         // the run carried in from the previous batch ends unless element 0 continues it
         const bool cont0 = (hitmask & 1ull) && !(newmask & 1ull);
         if (c_open && n > 0 && !cont0) {
-            if (n_matches < cap_matches && lane == 0) scratch[n_matches] = M;
+            if (lane == 0) put_rec(n_matches, M);
             n_matches++;
             c_open = false;
         }
@@ -819,7 +822,7 @@ struct MapSink {
             m.done = 0;
             if (is_end) {
                 const uint32_t mi = n_matches + mbcnt64(endmask);
-                if (mi < cap_matches) scratch[mi] = m;
+                put_rec(mi, m);
             }
             n_matches += (uint32_t)__popcll(endmask);
             // carry out: state of the last element
@@ -905,7 +908,7 @@ struct MapSink {
     // the run still open after the last k-min-mer of the read ends there
     __device__ __forceinline__ void finish_runs() {
         if (c_open) {
-            if (n_matches < cap_matches && lane_id() == 0) scratch[n_matches] = M;
+            if (lane_id() == 0) put_rec(n_matches, M);
             n_matches++;
             c_open = false;
         }

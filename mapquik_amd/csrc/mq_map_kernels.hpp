@@ -117,6 +117,7 @@ typedef LdsList<(LDS_LIST_CAP ? LDS_LIST_CAP : 1)> ReadListLds;
 struct MapListLds {
     unsigned long long h[ML_LIST_CAP];
     uint32_t p[ML_LIST_CAP];
+    MatchRec rec[MAP_LDS_RECS];  // MapSink::lds_rec
 };
 
 // map phase of read r: its list (cnt entries at base) -> mq_hit
@@ -148,7 +149,7 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
             d = A.dump + A.dump_off[r];
             dcap = (uint32_t)(A.dump_off[r + 1] - A.dump_off[r]);
         }
-        MapSink sink(A.table, A.mask, P, scratch, A.cap_matches, d, dcap);
+        MapSink sink(A.table, A.mask, P, scratch, A.cap_matches, S.rec, d, dcap);
         const unsigned long long *lh = A.mz_hash + base;
         const uint32_t *lp = A.mz_pos + base;
         const uint32_t chunk = 64u * (uint32_t)ML_NB + P.k - 1u;
@@ -187,6 +188,10 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
         n_kmm = sink.kmm_count;
         if (sink.n_matches > A.cap_matches) {
             h.status = MQ_HIT_OVERFLOW;
+        } else if (sink.n_matches > 0 && sink.n_matches <= MAP_LDS_RECS && sink.n_matches <= (uint32_t)CH) {
+            wave_sync();  // all of the read's records are in LDS (one chunk of the chain stage: it writes none back)
+            mq_clk(8);
+            chain_stage<CH>(S.rec, sink.n_matches, P, len, A.ref_lens, h);
         } else if (sink.n_matches > 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Match records written by this wave are in L2
             wave_sync();
