@@ -485,9 +485,10 @@ __device__ __forceinline__ MatchRec rd_match(const MatchRec &m, int l) {
 
 // Per-reference Chain::get_match + best-of + find_coords.  CH = lanes used per chunk (64; smaller only in tests
 // so that ordinary inputs exercise the multi-chunk path).
+// first: lane i's record i already in a register (the caller read the first chunk itself); with nm <= CH nothing is read here then
 template <int CH>
 __device__ __forceinline__ void chain_stage(MatchRec *__restrict__ scratch, uint32_t nm, const DevParams &P, uint64_t q_len,
-                                            const uint64_t *__restrict__ ref_lens, mq_hit &out) {
+                                            const uint64_t *__restrict__ ref_lens, mq_hit &out, const MatchRec *first = nullptr) {
     const uint32_t lane = lane_id();
     // find_largest_two_chains state (src/mers.rs:110-129)
     uint32_t max_count = 0, second_count = 0, n_cand = 0;
@@ -496,7 +497,8 @@ __device__ __forceinline__ void chain_stage(MatchRec *__restrict__ scratch, uint
     for (uint32_t c0 = 0; c0 < nm; c0 += CH) {
         const bool v0 = lane < (uint32_t)CH && c0 + lane < nm;
         MatchRec m = {};
-        if (v0) m = scratch[c0 + lane];
+        if (first && c0 == 0) m = *first;
+        else if (v0) m = scratch[c0 + lane];
         uint64_t pending = __ballot(v0 && !m.done);
         while (pending) {
             const int lead = __ffsll((long long)pending) - 1;
@@ -613,6 +615,7 @@ __device__ __forceinline__ void chain_stage(MatchRec *__restrict__ scratch, uint
 // Match records a wave keeps in LDS next to the staged list (the space the seed phase's larger LDS leaves unused during the map phase):
 // an ordinary read has a handful, and chaining them from LDS saves the wait for their stores and the loads' round trip through L2
 constexpr uint32_t MAP_LDS_RECS = 48;
+static_assert(MAP_LDS_RECS <= 64, "records_to_scratch: one record per lane");
 struct MapSink {
     const Bucket *__restrict__ table;
     uint64_t mask;
@@ -632,10 +635,16 @@ struct MapSink {
 
     __device__ MapSink(const Bucket *t, uint64_t m, const DevParams &p, MatchRec *s, uint32_t cap, MatchRec *lr, mq_kminmer *d, uint32_t dc)
         : table(t), mask(m), P(p), scratch(s), cap_matches(cap), lds_rec(lr), dump(d), dump_cap(dc) {}
-    // record i of the read: to its place in the wave's scratch in device memory and, the first MAP_LDS_RECS, to LDS
+    // record i of the read: the first MAP_LDS_RECS stay in LDS, later ones go to their place in the wave's scratch in device memory
+    // (records_to_scratch() then moves the LDS ones there too).  An ordinary read's records never leave LDS: no store's
+    // acknowledgement is outstanding when the map phase ends.
     __device__ __forceinline__ void put_rec(uint32_t i, const MatchRec &m) const {
-        if (i < cap_matches) scratch[i] = m;
         if (i < MAP_LDS_RECS) lds_rec[i] = m;
+        else if (i < cap_matches) scratch[i] = m;
+    }
+    __device__ __forceinline__ void records_to_scratch() const {
+        const uint32_t n = n_matches < MAP_LDS_RECS ? n_matches : MAP_LDS_RECS, i = lane_id();
+        if (i < n && i < cap_matches) scratch[i] = lds_rec[i];
     }
 
     // k-min-mer `base + lane` of a minimizer list: canonical orientation, tuple hash, query coordinates
@@ -849,8 +858,9 @@ struct MapSink {
 
     // All k-min-mers of an ordered minimizer list (have <= 64*NB + k - 1 entries) in one go: every tuple hash first, every home
     // bucket's keys in flight together, the probes resolved together (probe_all), then the runs batch by batch.
-    template <int NB>
-    __device__ __forceinline__ void consume_list(const unsigned long long *mzh, const uint32_t *mzp, uint32_t have) {
+    // hashes_done(): called once the minimizers' hashes (mzh) have all been read -- the positions (mzp) are still needed
+    template <int NB, class F>
+    __device__ __forceinline__ void consume_list(const unsigned long long *mzh, const uint32_t *mzp, uint32_t have, const F &hashes_done) {
         if (have < P.k) return;
         const uint32_t lane = lane_id();
         const uint32_t K = have - P.k + 1u;
@@ -874,6 +884,7 @@ struct MapSink {
                 __builtin_amdgcn_sched_barrier(0);  // one tuple hash at a time: interleaving NB of them costs ~10 registers each
             }
         }
+        hashes_done();
         mq_clk(6);
         uint32_t st;
         probe_all<NB>(key, kk, actbits, st);

@@ -118,6 +118,7 @@ struct MapListLds {
     unsigned long long h[ML_LIST_CAP];
     uint32_t p[ML_LIST_CAP];
     MatchRec rec[MAP_LDS_RECS];  // MapSink::lds_rec
+    uint32_t next_off[8];        // map_kernel: offsets (and length) of the wave's next read, fetched straight into LDS during the map phase
 };
 
 // map phase of read r: its list (cnt entries at base) -> mq_hit
@@ -130,11 +131,15 @@ __device__ __forceinline__ void store_hit(const SplitArgs &A, uint32_t r, const 
     }
 }
 
-// lds_h / lds_p: the whole list (cnt entries) already in LDS -- then nothing is staged; nullptr: the list is at `base` in device memory
-template <int CH, bool TIMING>
+struct NoOp {
+    __device__ __forceinline__ void operator()() const {}
+};
+// lds_h / lds_p: the whole list (cnt entries) already in LDS -- then nothing is staged; nullptr: the list is at `base` in device memory.
+// list_done(): called exactly once, when the staged HASHES (S.h) are no longer needed: after the tuple hashes of the list's last chunk.
+template <int CH, bool TIMING, class F = NoOp>
 __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, MatchRec *scratch, uint32_t r, uint64_t len, uint32_t cnt,
                                          uint64_t base, unsigned long long &t_steps, unsigned long long &t_lookups, mq_hit &h,
-                                         const unsigned long long *lds_h = nullptr, const uint32_t *lds_p = nullptr) {
+                                         const unsigned long long *lds_h = nullptr, const uint32_t *lds_p = nullptr, const F &list_done = F()) {
     const uint32_t lane = lane_id();
     const DevParams &P = A.P;
     h.status = MQ_HIT_UNMAPPED;
@@ -153,8 +158,10 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
         const unsigned long long *lh = A.mz_hash + base;
         const uint32_t *lp = A.mz_pos + base;
         const uint32_t chunk = 64u * (uint32_t)ML_NB + P.k - 1u;
+        bool requested = false;
         for (uint32_t g = 0; g + P.k <= cnt;) {
             const uint32_t have = cnt - g < chunk ? cnt - g : chunk;
+            const bool last = g + have >= cnt;
             if (!lds_h) {  // L2-served loads (the list may have been written by this very wave), ALL in flight before the first is stored: one L2
                // round trip per chunk (a loop that loads and stores 64 entries at a time exposes one per 64 entries)
                 unsigned long long hv[ML_NB + 1];
@@ -180,28 +187,49 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
             }
             wave_sync();
             mq_clk(5);
-            sink.template consume_list<ML_NB>(lds_h ? lds_h + g : S.h, lds_p ? lds_p + g : S.p, have);
+            sink.template consume_list<ML_NB>(lds_h ? lds_h + g : S.h, lds_p ? lds_p + g : S.p, have, [&]() {
+                if (last && !requested) {
+                    requested = true;
+                    list_done();
+                }
+            });
             wave_sync();
             g += have - (P.k - 1u);
         }
         sink.finish_runs();
         n_kmm = sink.kmm_count;
-        if (sink.n_matches > A.cap_matches) {
-            h.status = MQ_HIT_OVERFLOW;
-        } else if (sink.n_matches > 0 && sink.n_matches <= MAP_LDS_RECS && sink.n_matches <= (uint32_t)CH) {
-            wave_sync();  // all of the read's records are in LDS (one chunk of the chain stage: it writes none back)
-            mq_clk(8);
-            chain_stage<CH>(S.rec, sink.n_matches, P, len, A.ref_lens, h);
-        } else if (sink.n_matches > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Match records written by this wave are in L2
+        if (!requested) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing was staged: whatever list_done() wants to find in LDS has landed
+            list_done();
+        }
+        if (sink.n_matches > 0 && sink.n_matches <= MAP_LDS_RECS && sink.n_matches <= (uint32_t)CH) {
+            // all of the read's records are in LDS: lane i takes record i, and the chain stage -- one chunk -- reads no Match record
             wave_sync();
+            MatchRec m0 = {};
+            if (lane_id() < sink.n_matches) m0 = S.rec[lane_id()];
             mq_clk(8);
-            chain_stage<CH>(scratch, sink.n_matches, P, len, A.ref_lens, h);
+            chain_stage<CH>(S.rec, sink.n_matches, P, len, A.ref_lens, h, &m0);
+        } else {
+            if (sink.n_matches > 0 && sink.n_matches <= A.cap_matches) {  // many records: those in LDS join the others in the scratch
+                wave_sync();
+                sink.records_to_scratch();
+            }
+            if (sink.n_matches > A.cap_matches) {
+                h.status = MQ_HIT_OVERFLOW;
+            } else if (sink.n_matches > 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Match records written by this wave are in L2
+                wave_sync();
+                mq_clk(8);
+                chain_stage<CH>(scratch, sink.n_matches, P, len, A.ref_lens, h);
+            }
         }
         if (TIMING) {
             t_steps += wave_sum_u32(sink.probe_steps);
             t_lookups += n_kmm;
         }
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        list_done();
     }
     h.n_kminmers = n_kmm;
     mq_clk(9);
@@ -214,6 +242,15 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
 #define MQ_MAP_MIN_WAVES 4
 #endif
 constexpr int MAP_WAVES = MQ_MAP_WAVES;
+// 1 (experiment, off: measured -1.2 %): the first super-row of a wave's NEXT read is requested as soon as the current read's tuple hashes
+// are done, straight into the LDS area of the staged hashes (global_load_lds_dwordx4: no registers ride through the rest of the map
+// phase), together with the work-item atomic after it, and picked up from there at the end of the map phase; the next read's offsets come
+// the same way.  The seed phase then opens without a memory round trip (-3.2 k cycles of a read's 172 k), but the requests, the pick-up
+// and the LDS-direct loads' waits cost the map phase 3.9 k (profiles/NOTES.md).
+#ifndef MQ_LDS_PREFETCH
+#define MQ_LDS_PREFETCH 0
+#endif
+static_assert(!(MQ_LDS_PREFETCH && MQ_LDS_LIST), "MQ_LDS_PREFETCH lands in the staged list's area");
 
 // per-wave LDS of the fused kernel: the phases of one read follow each other, so they share the memory
 union MapWaveLds {
@@ -258,14 +295,22 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
     uint32_t r = 0;
     if (lane == 0) r = atomicAdd(&A.counters[0], 1u);
     r = rdfirst(r);
+#if MQ_LDS_PREFETCH
+    uint32_t rn_v = 0;  // lane 0: the work item after r, taken one read ahead (the request goes out with the next read's first super-row)
+    if (lane == 0) rn_v = atomicAdd(&A.counters[0], 1u);
+#endif
     uint64_t o0 = 0, len = 0;
     if (r < A.n) {
         o0 = A.offsets[r];
         len = A.lens ? (uint64_t)A.lens[r] : A.offsets[r + 1] - o0;
     }
+    APre pre;                // the current read's first super-row when pre_valid (MQ_LDS_PREFETCH: picked up from LDS at the end of the
+    bool pre_valid = false;  // iteration before)
     while (r < A.n) {
+#if !MQ_LDS_PREFETCH
         uint32_t rn_v = 0;
         if (lane == 0) rn_v = atomicAdd(&A.counters[0], 1u);
+#endif
         uint32_t cnt = 0;
         uint64_t base = 0;
         bool in_lds = false;  // the read's whole minimizer list is in W.LL[wv] (MQ_LDS_LIST builds)
@@ -276,7 +321,6 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         } else if (len >= (uint64_t)P.l + P.k - 1u) {
             uint32_t cap;
             list_region(A, o0 - o_base, len, r, base, cap);
-            APre pre;
 #if MQ_LDS_LIST
             cnt = SD_NOT_FAST;
             if (!A.force_general) {
@@ -301,7 +345,7 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
                 }
             }
 #else
-            cnt = A.force_general ? SD_NOT_FAST : seed_read_fast(A, T, S.seed, A.bases + o0, (uint32_t)len, base, cap, n_moved, pre, false);
+            cnt = A.force_general ? SD_NOT_FAST : seed_read_fast(A, T, S.seed, A.bases + o0, (uint32_t)len, base, cap, n_moved, pre, pre_valid);
 #endif
             if (cnt == SD_NOT_FAST) {
                 n_general++;
@@ -316,6 +360,22 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
             mq_clk(4);
         }
         const uint32_t rn = rdfirst(rn_v);
+#if MQ_LDS_PREFETCH
+        // the next read's offsets: LDS-direct loads by lane 0 (no register waits through the map phase for them -- the map phase has none
+        // to spare: held in registers they were spilled, which takes the load's round trip first); they land while the list is staged
+        if (lane_id() == 0 && rn < A.n) {
+            typedef __attribute__((address_space(3))) void lds_void;
+            typedef const __attribute__((address_space(1))) void glb_void;
+            if (A.lens) {
+                const uint32_t *po = reinterpret_cast<const uint32_t *>(A.offsets + rn);
+                __builtin_amdgcn_global_load_lds((glb_void *)po, (lds_void *)&S.map.next_off[0], 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void *)(po + 1), (lds_void *)&S.map.next_off[1], 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void *)(A.lens + rn), (lds_void *)&S.map.next_off[4], 4, 0, 0);
+            } else {
+                __builtin_amdgcn_global_load_lds((glb_void *)(A.offsets + rn), (lds_void *)&S.map.next_off[0], 16, 0, 0);
+            }
+        }
+#else
         unsigned long long n_o0 = 0, n_o1 = 0;
         uint32_t n_len = 0;
         if (lane == 0 && rn < A.n) {  // vector loads by one lane: in flight through the map phase (scalar loads would be waited for at its first LDS wait)
@@ -323,20 +383,77 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
             if (A.lens) n_len = A.lens[rn];
             else n_o1 = A.offsets[rn + 1];
         }
+#endif
         mq_hit h;
 #if MQ_LDS_LIST
         map_read<CH, TIMING>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h, in_lds ? W.LL[wv].h : nullptr, in_lds ? W.LL[wv].p : nullptr);
+#elif MQ_LDS_PREFETCH
+        uint64_t o0_n = 0, len_n = 0;
+        uint32_t rnn_v = 0;
+        bool pre_in_lds = false;  // the next read's first super-row is on its way into S.map.h
+        auto request_next = [&]() {  // the staged list is done with: the next read's first super-row goes into its place
+            {  // (landed long ago: the list's staging waited for everything issued before it)
+                const uint4 v = *reinterpret_cast<const uint4 *>(&S.map.next_off[0]);
+                const uint32_t nl = S.map.next_off[4];
+                o0_n = ((uint64_t)rdfirst(v.y) << 32) | rdfirst(v.x);
+                len_n = A.lens ? (uint64_t)rdfirst(nl) : ((((uint64_t)rdfirst(v.w) << 32) | rdfirst(v.z)) - o0_n);
+            }
+            // the work item after the next: its atomic is as old as the requests below, so the pick-up's wait covers it and stage A
+            // never waits for anything but its own super-rows
+            if (lane == 0) rnn_v = atomicAdd(&A.counters[0], 1u);
+            // (32-bit tests: the compiler keeps 64-bit comparands in a spilled register pair, and a reload here waits for every probe)
+            const uint32_t ln_hi = (uint32_t)(len_n >> 32), ln_lo = (uint32_t)len_n;
+            pre_in_lds = rn < A.n && !A.force_general && ln_hi == 0u && ln_lo >= 16u && ln_lo >= P.l + P.k - 1u;  // seed_fast_eligible, extract()'s guard
+            if (pre_in_lds) {
+                const uint8_t *seq = A.bases + o0_n;
+                const uint32_t ln = (uint32_t)len_n;
+                typedef __attribute__((address_space(3))) void lds_void;
+                typedef const __attribute__((address_space(1))) void glb_void;
+                char *land = reinterpret_cast<char *>(S.map.h);
+                const uint32_t ln_id = lane_id();  // its own copy: a value the compiler carries around the read loop gets spilled
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {  // piece j of every lane: the address load_piece() would use
+                    const uint32_t pos = ln_id * 64u + 16u * j;
+                    const uint32_t pp = pos < ln - 16u ? pos : ln - 16u;
+                    __builtin_amdgcn_global_load_lds((glb_void *)(seq + pp), (lds_void *)(land + 1024u * j), 16, 0, 0);
+                }
+            }
+        };
+        map_read<CH, TIMING>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h, nullptr, nullptr, request_next);
 #else
         map_read<CH, TIMING>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h);
 #endif
         wave_sync();
         const uint32_t r_done = r;
         r = rn;
+#if MQ_LDS_PREFETCH
+        o0 = o0_n;
+        len = len_n;
+        rn_v = rnn_v;
+        // pick the next read's first super-row up BEFORE this read's result is stored: the wait then covers the four requests and the
+        // work-item atomic (all as old as the chain stage) and nothing younger
+        // (unconditionally: assigned only when the request went out, `pre` would keep its old contents alive across the whole map phase
+        // of the next read -- 16 registers the map phase does not have; what is read when nothing was requested is never used)
+        pre_valid = pre_in_lds;
+        {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const uint4 *land = reinterpret_cast<const uint4 *>(S.map.h) + lane_id();
+            pre.nx0 = land[0];
+            pre.nx1 = land[64];
+            pre.nx2 = land[128];
+            pre.nx3 = land[192];
+            wave_sync();  // in registers before stage A clears its code stream (the same LDS)
+        }
+        store_hit(A, r_done, h);
+    }
+#else
         o0 = rdlane64(n_o0, 0);
         len = A.lens ? (uint64_t)rdfirst(n_len) : rdlane64(n_o1, 0) - o0;
         asm volatile("" ::: "memory");  // the prefetched offsets are out of their registers before the result's store is issued
         store_hit(A, r_done, h);
     }
+#endif
     if (lane == 0) {
         if (n_fast) atomicAdd(&A.counters[4], n_fast);
         if (n_general) atomicAdd(&A.counters[5], n_general);

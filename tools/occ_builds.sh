@@ -13,5 +13,7 @@ $B -DMQ_MAP_WAVES=16 -DMQ_MAP_MIN_WAVES=8 -DMQ_SD_MAX_SR=1 -DMQ_ML_NB=3 -DMQ_SEE
 # the read's minimizer list kept in LDS: one 16-wave workgroup per CU, two-super-row tiles, 256 entries per wave --
 # the bench's reads list 351 minimizers on average (4.2 KB), so nearly every list overflows into device memory: 1175 against 1218
 $B -DMQ_MAP_WAVES=16 -DMQ_MAP_MIN_WAVES=4 -DMQ_SD_MAX_SR=2 -DMQ_LDS_LIST=256 -o $ROOT/mapquik_amd/lib/libmq_ldslist.so $ROOT/mapquik_amd/csrc/mq_capi.hip &
+# the next read's first super-row requested during the map phase, straight into LDS (mq_map_kernels.hpp MQ_LDS_PREFETCH): 1237 against 1252
+$B -DMQ_LDS_PREFETCH=1 -o $ROOT/mapquik_amd/lib/libmq_ldsprefetch.so $ROOT/mapquik_amd/csrc/mq_capi.hip &
 wait
-for f in w6 w8 ldslist; do ls -la $ROOT/mapquik_amd/lib/libmq_$f.so; done
+for f in w6 w8 ldslist ldsprefetch; do ls -la $ROOT/mapquik_amd/lib/libmq_$f.so; done
