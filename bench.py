@@ -297,8 +297,34 @@ def fake_ranks():
     return os.environ.get("MQ_BENCH_FAKE_RANKS", "") not in ("", "0")
 
 
+def launch_ranks(n_gpus):
+    """`python bench.py --gpus N` typed by itself (no WORLD_SIZE in the environment): start the N ranks as a FRESH child process --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <the same arguments>` -- relay its output and return
+    its exit code.  Nothing here has imported torch or touched the GPU, and the child is started with subprocess, never os.exec*
+    (a process that has initialised the GPU must not replace itself).  Rank 0's JSON line stays the only `{..."metric"...}` line."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL / cross-process device memory needs dmabuf IPC on this platform
+    env.setdefault("OMP_NUM_THREADS", str(max(1, effective_cpus() // n_gpus)))
+    sys.stderr.write("bench.py: --gpus %d without WORLD_SIZE: starting the ranks with %s\n" % (n_gpus, " ".join(cmd[1:10])))
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # the driver's command shape for N = 1, typed with N > 1
+        sys.exit(launch_ranks(args.gpus))
     import torch
     import torch.distributed as dist
 
@@ -306,12 +332,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
+    fake = fake_ranks()
+    n_dev = torch.cuda.device_count()  # does not initialise the GPU
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a GPU: the mapquik HIP path has no CPU fallback")
+    if world > n_dev and not fake:
+        raise SystemExit("--gpus %d but this node shows %d GPU(s): one rank per GPU (MQ_BENCH_FAKE_RANKS=1 runs every rank on device 0, "
+                         "a test hook, not a measurement)" % (world, n_dev))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the mapquik HIP path has no CPU fallback")
-    fake = fake_ranks()
     if fake:
         local_rank = 0
     torch.cuda.set_device(local_rank)

@@ -144,7 +144,7 @@ static int redo_overflow(mq_ctx *c, const uint8_t *bases, const uint64_t *offset
 static int ctx_submit(mq_ctx *c, const uint8_t *bases, uint64_t buf_bytes, const uint64_t *offsets, const uint32_t *lens, uint32_t n,
                       mq_hit *out) {
     mq_index *idx = c->idx;
-    if (c->pending) return set_err(MQ_ESTATE, "context has a submitted batch: call mq_ctx_wait first");
+    if (c->pending || c->fx_pending) return set_err(MQ_ESTATE, "context has a submitted batch: call mq_ctx_wait / mq_ctx_wait_fasta first");
     if (!idx->finalized) return set_err(MQ_ESTATE, "index not finalized");
     if (n == 0) return MQ_OK;
     int rc = use_device(idx);
@@ -210,7 +210,7 @@ static int ctx_map_device(mq_ctx *c, const uint8_t *d_bases, const uint64_t *d_o
     mq_index *idx = c->idx;
     if (n && (!d_offsets || !d_out)) return set_err(MQ_EINVAL, "bad arguments");
     if (!idx->finalized) return set_err(MQ_ESTATE, "index not finalized");
-    if (c->pending) return set_err(MQ_ESTATE, "context has a submitted batch: call mq_ctx_wait first");
+    if (c->pending || c->fx_pending) return set_err(MQ_ESTATE, "context has a submitted batch: call mq_ctx_wait / mq_ctx_wait_fasta first");
     int rc = use_device(idx);
     if (rc) return rc;
     if ((rc = ctx_ensure(c, n, total_bases, list_f16(idx)))) return rc;

@@ -75,9 +75,12 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint8_t *__restr
             if (lines < nl_cap) nl_pos[lines] = end;
             lines++;
         }
-        info[0] = lines;
-        info[1] = lines / 2u;
-        info[2] = (lines & 1u) || lines > nl_cap ? FX_IRREGULAR : 0u;
+        // more line ends than nl_pos holds (records shorter than ~32 bytes: primers, barcodes, junk): the piece is IRREGULAR and NO record
+        // is reported -- fasta_spans_kernel and the caller index nl_pos[0, lines) and must never see a count beyond its capacity
+        const bool over = lines > nl_cap;
+        info[0] = over ? 0u : lines;
+        info[1] = over ? 0u : lines / 2u;
+        info[2] = (lines & 1u) || over ? FX_IRREGULAR : 0u;
         info[3] = 0;
     }
 }
@@ -111,6 +114,7 @@ __global__ __launch_bounds__(256) void list_newlines_kernel(const uint8_t *__res
 __global__ __launch_bounds__(256) void fasta_spans_kernel(const uint8_t *__restrict__ buf, uint32_t begin, uint32_t end, const uint32_t *__restrict__ nl_pos,
                                                           uint32_t *__restrict__ info, unsigned long long *__restrict__ starts, uint32_t *__restrict__ lens,
                                                           uint32_t span_cap) {
+    if (info[2] & FX_IRREGULAR) return;  // decided by the scan already (odd line count / more lines than nl_pos holds): nothing to look at
     const uint32_t n_rec = info[1];
     bool bad = false;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rec; r += gridDim.x * blockDim.x) {

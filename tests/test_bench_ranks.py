@@ -65,6 +65,39 @@ def test_bench_line_two_ranks(mode, tmp_path):
         assert h[0].shape == h[1].shape and not np.array_equal(h[0], h[1])  # every rank its own batch (seed + rank)
 
 
+def test_bench_gpus_2_typed_as_the_driver_types_it():
+    """`python bench.py --gpus 2 ...` with NO launcher and no WORLD_SIZE: bench.py starts its own ranks (a fresh torch.distributed.run
+    child, before anything has touched the GPU) and rank 0's line is the only JSON line; the N = 1 line through the same entry is
+    unchanged in shape."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(MQ_BENCH_FAKE_RANKS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "2", "--warmup", "1", "--genome-scale", "0.02", "--reads", "6000", "--no-cpu-baseline", "--no-e2e", "--no-configs"]
+    out = {}
+    for n in (2, 1):
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n)] + common, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+        assert len(lines) == 1, r.stdout[-2000:]
+        out[n] = json.loads(lines[0])
+    assert out[2]["n_gpus"] == 2 and out[1]["n_gpus"] == 1
+    assert out[2]["scaling"] == "weak" and len(out[2]["per_rank_gbases_s"]) == 2
+    for key in ("metric", "unit", "dtype", "data", "higher_is_better"):
+        assert out[1][key] == out[2][key]
+    assert set(out[2]) - set(out[1]) <= {"per_rank_gbases_s"}, set(out[2]) ^ set(out[1])
+
+
+def test_bench_more_ranks_than_gpus_fails_fast():
+    """Without the fake-rank hook, --gpus 2 on a one-GPU box must say so at once (every rank, before any work), not hang in RCCL."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "MQ_BENCH_FAKE_RANKS")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--genome-scale", "0.02", "--reads", "1000", "--no-cpu-baseline", "--no-e2e",
+                        "--no-configs"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    assert "one rank per GPU" in (r.stdout + r.stderr)
+
+
 def test_clone_on_the_same_device_at_bench_size(simlib, oracle):
     """mq_index_clone(src, same device) of the CHM13-sized index (a 17 GB table copied inside one device), then the source and the
     replica map the same 32,768-read batch from two threads at once through their own stream slots: identical hits, the oracle's
