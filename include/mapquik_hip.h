@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MQ_ABI_VERSION 3
+#define MQ_ABI_VERSION 4
 
 #define MQ_OK 0
 #define MQ_EINVAL (-1)
@@ -54,6 +54,27 @@ typedef struct mq_params {
 /* The reference upper-cases every sequence before the seam (to_ascii_uppercase, src/closures.rs:63,106).  With this flag the
  * kernels treat a-z as A-Z themselves, so a feeder can hand over raw FASTX bytes without touching them. */
 #define MQ_FLAG_FOLD_CASE 1u
+/* Seeding variants (flags bits 8..13; default 0 = the frozen reading of DESIGN.md section 2).  The k-min-mer iterator is a third-party
+ * crate (rust-seq2kminmers, Cargo.toml:30, no pinned revision; call sites src/mers.rs:22-27,53) that this image cannot build, so
+ * six of its decisions are switchable: tools/check_against_upstream.sh finds, on a machine with cargo, which combination reproduces
+ * the crate, and the product is then run with that value (`mapquik --seeding-variant v`).  Bits, any combination:
+ *    1  D3      strict `<` on the density bound (frozen: `<=`)
+ *    2  D2      FH = f32: the bound is computed in single precision
+ *    4  D2/D12  H = u32: 32-bit ntHash (low halves of the seeds, rotations mod 32) and a 32-bit bound -- what a 16-lane AVX-512
+ *               HashMode::HpcSimd (the reference's default mode, src/mers.rs:22) may use; hashes are zero-extended into the tuple
+ *    8  D5      a minimizer's position = raw index of the LAST base of its first base's homopolymer run (frozen: the run head); needs l >= 2
+ *   16  D6      end = raw position of the last compressed base of the last minimizer's l-mer (frozen: pos[k-1] + l - 1)
+ *   32  D8      rev = reversed tuple <= forward tuple (frozen: strict <; differs on palindromic tuples only)
+ * mq_index_new rejects undefined bits and unsupported combinations with MQ_EINVAL. */
+#define MQ_FLAG_SEED_VARIANT_SHIFT 8
+#define MQ_FLAG_SEED_VARIANT_MASK (0x3Fu << MQ_FLAG_SEED_VARIANT_SHIFT)
+#define MQ_FLAG_SEED_VARIANT(v) (((uint32_t)(v) & 0x3Fu) << MQ_FLAG_SEED_VARIANT_SHIFT)
+#define MQ_SEEDVAR_STRICT_BOUND 1u
+#define MQ_SEEDVAR_F32_BOUND 2u
+#define MQ_SEEDVAR_HASH32 4u
+#define MQ_SEEDVAR_POS_RUN_END 8u
+#define MQ_SEEDVAR_END_COMPRESSED 16u
+#define MQ_SEEDVAR_REV_ON_EQUAL 32u
 
 /* One k-min-mer as the reference's KminmerHash exposes it (fields used at src/index.rs:57-58,101). 24 bytes. */
 typedef struct mq_kminmer {

@@ -13,6 +13,8 @@ from . import build as _build
 
 MQ_HIT_UNMAPPED, MQ_HIT_MAPPED, MQ_HIT_OVERFLOW = 0, 1, 2
 MQ_FLAG_FOLD_CASE = 1
+MQ_FLAG_SEED_VARIANT_SHIFT = 8
+MQ_ABI_VERSION = 4  # include/mapquik_hip.h
 
 hit_dtype = np.dtype([("status", "<u4"), ("ref_id", "<u4"), ("rc", "<u4"), ("mapq", "<u4"), ("q_start", "<u4"), ("q_end", "<u4"),
                       ("r_start", "<u4"), ("r_end", "<u4"), ("score", "<u4"), ("n_kminmers", "<u4"), ("q_start_hi", "<u4"), ("q_end_hi", "<u4")])
@@ -45,8 +47,16 @@ class Params(C.Structure):
     _fields_ = [("k", C.c_uint32), ("l", C.c_uint32), ("density", C.c_double), ("use_hpc", C.c_uint32), ("c", C.c_uint32),
                 ("s", C.c_uint32), ("g", C.c_uint32), ("flags", C.c_uint32)]
 
-    def __init__(self, k=5, l=31, density=0.01, use_hpc=True, c=4, s=11, g=2000, fold_case=False):
-        super().__init__(k, l, density, 1 if use_hpc else 0, c, s, g, MQ_FLAG_FOLD_CASE if fold_case else 0)
+    def __init__(self, k=5, l=31, density=0.01, use_hpc=True, c=4, s=11, g=2000, fold_case=False, seeding_variant=0):
+        """seeding_variant: MQ_SEEDVAR_* bits (include/mapquik_hip.h), 0 = the frozen reading of the third-party k-min-mer iterator."""
+        if not 0 <= int(seeding_variant) < 64:
+            raise ValueError("seeding_variant must be 0..63")
+        super().__init__(k, l, density, 1 if use_hpc else 0, c, s, g,
+                         (MQ_FLAG_FOLD_CASE if fold_case else 0) | (int(seeding_variant) << MQ_FLAG_SEED_VARIANT_SHIFT))
+
+    @property
+    def seeding_variant(self):
+        return (self.flags >> MQ_FLAG_SEED_VARIANT_SHIFT) & 0x3F
 
 
 class IndexStats(C.Structure):
@@ -99,7 +109,10 @@ def load_library(path=None):
     L.mq_ctx_submit.argtypes = [vp, vp, vp, u32, vp]
     L.mq_ctx_submit_spans.argtypes = [vp, vp, u64, vp, vp, u32, vp]
     L.mq_ctx_wait.argtypes = [vp]
-    if path is None or hasattr(L, "mq_ctx_submit_fasta"):  # (an older build given by path for an A/B run lacks them)
+    abi = L.mq_abi_version()
+    if path is None and abi != MQ_ABI_VERSION:
+        raise MapquikError("%s has ABI version %d, this binding is for %d: rebuild (python __graft_entry__.py)" % (p, abi, MQ_ABI_VERSION))
+    if abi >= 4 or hasattr(L, "mq_ctx_submit_fasta"):  # (an older build given by MQ_LIB / path for an A/B run may lack them)
         L.mq_index_reserve.argtypes = [vp, u64]
         L.mq_host_register.argtypes = [vp, C.c_size_t]
         L.mq_host_unregister.argtypes = [vp]

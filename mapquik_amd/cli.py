@@ -99,6 +99,9 @@ def build_parser():
     ap.add_argument("-q", type=int)
     ap.add_argument("--device", type=int, default=0, help="HIP device ordinal (extension)")
     ap.add_argument("--batch-bases", type=int, default=1 << 30, help="bases per GPU batch (extension)")
+    ap.add_argument("--seeding-variant", type=int, default=0, dest="seeding_variant",
+                    help="reading of the k-min-mer iterator's unpinned decisions, bits 1 2 4 8 16 32 (include/mapquik_hip.h); 0 = the frozen "
+                         "reading (extension; tools/check_against_upstream.sh finds the value that reproduces the crate)")
     ap.add_argument("--unmapped", action="store_true",
                     help="also write <prefix>.unmapped.out with the ids of reads that got no PAF line (extension; the reference "
                          "has this writer commented out, src/closures.rs:38-43; feeds a second pass with other parameters)")
@@ -155,7 +158,10 @@ def main(argv=None):
     lines, st = banner_lines(opt)
     for ln in lines:
         print(ln)
-    params = api.Params(k=st["k"], l=st["l"], density=st["density"], use_hpc=st["use_hpc"], c=st["c"], s=st["s"], g=st["g"])
+    if opt.seeding_variant:
+        print("Seeding variant %d (reading of rust-seq2kminmers other than the frozen one; include/mapquik_hip.h)." % opt.seeding_variant)
+    params = api.Params(k=st["k"], l=st["l"], density=st["density"], use_hpc=st["use_hpc"], c=st["c"], s=st["s"], g=st["g"],
+                        seeding_variant=opt.seeding_variant)
     index = api.Index(params, device=opt.device)
     paf = open(st["prefix"] + ".paf", "w")  # src/closures.rs:32
     unm = open(st["prefix"] + ".unmapped.out", "w") if opt.unmapped else None

@@ -91,6 +91,7 @@ struct Opt {
     double density = -1;
     int device = 0;
     int gpus = 1;
+    int seeding_variant = 0;  // MQ_SEEDVAR_* bits (include/mapquik_hip.h)
     std::string second;  // "k2,l2,d2"
     long k2 = 0, l2 = 0;
     double d2 = 0;
@@ -104,7 +105,7 @@ static void usage() {
          "        --parallelfastx\n        --unmapped      (extension) also write <prefix>.unmapped.out\n\nOPTIONS:\n"
          "    -b <b>\n    -c, --chain <chain>\n    -d, --density <density>\n    -g, --gap-diff <gap-diff>\n    -k <k>\n    -l <l>\n"
          "    -p, --prefix <prefix>\n    -q <q>\n        --reference <reference>\n    -s, --seed <seed>\n        --threads <threads>\n"
-         "        --device <n>    (extension) first HIP device ordinal\n        --gpus <n>      (extension) shard read batches over n GPUs, index replicated\n        --batch-bases <n> (extension) raw input bytes per chunk\n        --second-pass <k2,l2,d2> (extension) map the unmapped reads again with these parameters: <prefix>-k2-l2-d2.{fa,paf,unmapped.out}\n\nARGS:\n    <reads>");
+         "        --device <n>    (extension) first HIP device ordinal\n        --gpus <n>      (extension) shard read batches over n GPUs, index replicated\n        --batch-bases <n> (extension) raw input bytes per chunk\n        --seeding-variant <v> (extension) reading of the k-min-mer iterator's unpinned decisions, bits 1 2 4 8 16 32 (include/mapquik_hip.h); 0 = frozen\n        --second-pass <k2,l2,d2> (extension) map the unmapped reads again with these parameters: <prefix>-k2-l2-d2.{fa,paf,unmapped.out}\n\nARGS:\n    <reads>");
 }
 
 // One run of the reference's flow (src/closures.rs:22-212): index the reference, map the reads, write <prefix>.paf in input
@@ -513,6 +514,10 @@ int main(int argc, char **argv) {
         else if (a == "--device") o.device = atoi(val());
         else if (a == "--gpus") o.gpus = std::max(1, atoi(val()));
         else if (a == "--batch-bases") o.batch_bases = strtoull(val(), nullptr, 10);
+        else if (a == "--seeding-variant") {
+            o.seeding_variant = atoi(val());
+            if (o.seeding_variant < 0 || o.seeding_variant > 63) { fprintf(stderr, "error: --seeding-variant wants 0..63 (bits 1 2 4 8 16 32)\n"); return 2; }
+        }
         else if (a == "--second-pass") {
             o.second = val();
             char *e1 = nullptr, *e2 = nullptr;
@@ -548,6 +553,8 @@ int main(int argc, char **argv) {
     P.use_simd = !o.nosimd;
     P.use_pfx = o.parallelfastx;
     P.fold_case = true;  // raw FASTX bytes go to the GPU: the kernels do the reference's to_ascii_uppercase
+    P.seeding_variant = (unsigned)o.seeding_variant;
+    if (o.seeding_variant) printf("Seeding variant %d (reading of rust-seq2kminmers other than the frozen one; include/mapquik_hip.h).\n", o.seeding_variant);
     if (P.use_hpc) puts(P.use_simd ? "Using HPC ntHash, with SIMD" : "Using HPC ntHash, scalar");
     else puts(P.use_simd ? "Using regular ntHash (not HPC), with SIMD" : "Using regular ntHash (not HPC), scalar");
 

@@ -19,6 +19,7 @@ struct RefSeedArgs {
     DevParams P;
     unsigned long long *seg_hash;  // segment s: entries [s * cap, s * cap + counts[s])
     uint32_t *seg_pos;
+    uint32_t *seg_last;  // seeding variant 16 only (else nullptr): every minimizer's second position
     uint32_t cap;
     uint32_t *counts;    // minimizers of segment s (may exceed cap: the list is then incomplete and the host retries with room)
     uint32_t *queue;     // segments the fast seeder declined
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(64 * SEED_WAVES, MQ_SEED_MIN_WAVES) void seed_ref_k
         SeedTables T;
         SeedLds SS[SEED_WAVES];
     } W;
-    build_seed_tables(W.T, A.P.l);
+    build_seed_tables(W.T, A.P.l, var_h32<true>(A.P));
     __syncthreads();
     const uint32_t lane = lane_id();
     const uint32_t wv = rdfirst(threadIdx.x >> 6);
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(64 * SEED_WAVES, MQ_SEED_MIN_WAVES) void seed_ref_k
         APre pre;
         const size_t at = (size_t)s * A.cap;
         const uint32_t cnt = A.force_general ? SD_NOT_FAST
-                                             : seed_sequence_fast<0, true>(A.seq + a, vlen, A.P, W.T, S, A.seg_hash + at, A.seg_pos + at, A.cap, pre, false, V);
+                                             : seed_sequence_fast<0, true>(A.seq + a, vlen, A.P, W.T, S, A.seg_hash + at, A.seg_pos + at, A.cap, pre, false, V,
+                                                                           A.seg_last ? A.seg_last + at : nullptr);
         if (lane == 0) {
             A.counts[s] = cnt;
             if (cnt == SD_NOT_FAST) A.queue[atomicAdd(&A.counters[1], 1u)] = s;
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(64) void seed_ref_general_kernel(const RefSeedArgs 
         const uint64_t a = (uint64_t)s * REF_SEG;
         const uint64_t b = a + REF_SEG < A.len ? a + REF_SEG : A.len;
         const size_t at = (size_t)s * A.cap;
-        SoaListSink sink(A.seg_hash + at, A.seg_pos + at, A.cap);
+        SoaListSink sink(A.seg_hash + at, A.seg_pos + at, A.seg_last ? A.seg_last + at : nullptr, A.cap);
         uint32_t mz_count = 0;
         seed_segment(A.seq, A.len, a, b, A.P, S, sink, mz_count);
         if (lane == 0) A.counts[s] = sink.written;
@@ -126,13 +128,13 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t *__res
 // seeder, into its exact-size place in the dense list
 __global__ __launch_bounds__(64) void seed_ref_redo_kernel(const RefSeedArgs A, const uint32_t *__restrict__ over_queue, uint32_t n_over,
                                                            const unsigned long long *__restrict__ seg_off, unsigned long long *__restrict__ dense_hash,
-                                                           uint32_t *__restrict__ dense_pos) {
+                                                           uint32_t *__restrict__ dense_pos, uint32_t *__restrict__ dense_last) {
     __shared__ WaveLds S;
     for (uint32_t i = blockIdx.x; i < n_over; i += gridDim.x) {
         const uint32_t s = over_queue[i];
         const uint64_t a = (uint64_t)s * REF_SEG;
         const uint64_t b = a + REF_SEG < A.len ? a + REF_SEG : A.len;
-        SoaListSink sink(dense_hash + seg_off[s], dense_pos + seg_off[s], A.counts[s]);
+        SoaListSink sink(dense_hash + seg_off[s], dense_pos + seg_off[s], dense_last ? dense_last + seg_off[s] : nullptr, A.counts[s]);
         uint32_t mz_count = 0;
         seed_segment(A.seq, A.len, a, b, A.P, S, sink, mz_count);
         wave_sync();
@@ -142,7 +144,8 @@ __global__ __launch_bounds__(64) void seed_ref_redo_kernel(const RefSeedArgs A, 
 // Stage 3: segment lists -> one dense ordered list
 __global__ void compact_lists_kernel(const unsigned long long *__restrict__ seg_hash, const uint32_t *__restrict__ seg_pos, uint32_t cap,
                                      const uint32_t *__restrict__ counts, const unsigned long long *__restrict__ seg_off, uint32_t n_seg,
-                                     unsigned long long *__restrict__ dense_hash, uint32_t *__restrict__ dense_pos) {
+                                     unsigned long long *__restrict__ dense_hash, uint32_t *__restrict__ dense_pos,
+                                     const uint32_t *__restrict__ seg_last, uint32_t *__restrict__ dense_last) {
     for (uint32_t s = blockIdx.x; s < n_seg; s += gridDim.x) {
         const uint32_t c = counts[s];
         if (c > cap) continue;  // seeded again into its place (seed_ref_redo_kernel)
@@ -151,23 +154,25 @@ __global__ void compact_lists_kernel(const unsigned long long *__restrict__ seg_
         for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) {
             dense_hash[dst + i] = seg_hash[src + i];
             dense_pos[dst + i] = seg_pos[src + i];
+            if (dense_last) dense_last[dst + i] = seg_last[src + i];
         }
     }
 }
 
 // Stage 4: every k consecutive minimizers -> one reference k-min-mer (KminmersIterator; Entry::new_with_mer src/index.rs:57-58)
 __global__ void ref_kminmers_kernel(const unsigned long long *__restrict__ dense_hash, const uint32_t *__restrict__ dense_pos, uint64_t n_mz, DevParams P,
-                                    uint32_t ref_id, RefKmm *__restrict__ out) {
+                                    uint32_t ref_id, RefKmm *__restrict__ out, const uint32_t *__restrict__ dense_last) {
     const uint64_t n_kmm = n_mz - P.k + 1;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_kmm; i += (uint64_t)gridDim.x * blockDim.x) {
         bool rev;
         auto get = [&](uint32_t j) { return (uint64_t)dense_hash[i + j]; };
-        const uint64_t key = P.k == 5u ? kminmer_hash_fixed<5>(get, rev) : P.k == 7u ? kminmer_hash_fixed<7>(get, rev) : P.k == 8u ? kminmer_hash_fixed<8>(get, rev)
-                                                                                                                   : kminmer_hash(P.k, get, rev);
+        const bool re = var_rev_eq<true>(P);
+        const uint64_t key = P.k == 5u ? kminmer_hash_fixed<5>(get, rev, re) : P.k == 7u ? kminmer_hash_fixed<7>(get, rev, re) : P.k == 8u ? kminmer_hash_fixed<8>(get, rev, re)
+                                                                                                                       : kminmer_hash(P.k, get, rev, re);
         RefKmm r;
         r.hash = key;
         r.start = dense_pos[i];
-        r.end = dense_pos[i + P.k - 1] + P.l - 1u;
+        r.end = dense_last ? dense_last[i + P.k - 1] : dense_pos[i + P.k - 1] + P.l - 1u;  // (seeding variant 16: the second position)
         r.offset = (uint32_t)i;
         r.id_rc = (ref_id << 1) | (rev ? 1u : 0u);
         out[i] = r;

@@ -13,6 +13,21 @@ mq_index *mq_index_new(const mq_params *params, int device) try {
         set_err(MQ_EINVAL, "unsupported k/l: need 1 <= l <= 64 and 1 <= k <= 32");
         return nullptr;
     }
+    if (params->flags & ~(MQ_FLAG_FOLD_CASE | MQ_FLAG_SEED_VARIANT_MASK)) {
+        set_err(MQ_EINVAL, "undefined bits in mq_params.flags");
+        return nullptr;
+    }
+    const uint32_t variant = (params->flags & MQ_FLAG_SEED_VARIANT_MASK) >> MQ_FLAG_SEED_VARIANT_SHIFT;
+    if ((variant & MQ_SEEDVAR_POS_RUN_END) && params->l < 2) {
+        set_err(MQ_EINVAL, "seeding variant 8 (position = end of the homopolymer run) needs l >= 2: the run's end is read off the window's second base");
+        return nullptr;
+    }
+#if MQ_LDS_LIST || MQ_LDS_PREFETCH
+    if (variant & MQ_SEEDVAR_END_COMPRESSED) {
+        set_err(MQ_EINVAL, "seeding variant 16 is not available in this experimental build (MQ_LDS_LIST / MQ_LDS_PREFETCH)");
+        return nullptr;
+    }
+#endif
     int n = mq_device_count();
     if (n <= 0) {
         set_err(MQ_ENODEVICE, "no HIP device: the mapquik HIP path has no CPU fallback");
@@ -25,7 +40,7 @@ mq_index *mq_index_new(const mq_params *params, int device) try {
     mq_index *idx = new mq_index();
     idx->params = *params;
     idx->device = device;
-    idx->dp.bound = density_bound(params->density);
+    set_dev_bound(idx->dp, params->density, variant);
     idx->dp.k = params->k;
     idx->dp.l = params->l;
     idx->dp.use_hpc = params->use_hpc ? 1 : 0;
@@ -91,6 +106,8 @@ static int64_t add_ref_device_locked(mq_index *idx, uint32_t ref_id, const char 
     idx->refs[ref_id] = std::make_pair(std::string(name ? name : ""), len);
     const DevParams &P = idx->dp;
     if (len < (uint64_t)P.l + P.k - 1) return 0;  // src/mers.rs:18
+    if (P.keep_none) return 0;                    // (seeding variant 1 with a bound of 0: no l-mer passes `hash < 0`)
+    const bool with_last = (P.variant & MQ_SEEDVAR_END_COMPRESSED) != 0;
 
     const uint32_t n_seg = (uint32_t)((len + REF_SEG - 1) / REF_SEG);
     // expected minimizers per segment: 2 * density of the compressed l-mers; cap with slack, worst case on retry
@@ -111,6 +128,7 @@ static int64_t add_ref_device_locked(mq_index *idx, uint32_t ref_id, const char 
     unsigned long long info[2] = {0, 0};
     if ((rc = grow(idx->bld_seg_hash, idx->bld_seg_hash_cap, (uint64_t)n_seg * cap))) return rc;
     if ((rc = grow(idx->bld_seg_pos, idx->bld_seg_pos_cap, (uint64_t)n_seg * cap))) return rc;
+    if (with_last && (rc = grow(idx->bld_seg_last, idx->bld_seg_last_cap, (uint64_t)n_seg * cap))) return rc;
     HIPCHK(hipMemsetAsync(idx->bld_info, 0, 64, 0));
     RefSeedArgs A;
     A.seq = d_seq;
@@ -119,6 +137,7 @@ static int64_t add_ref_device_locked(mq_index *idx, uint32_t ref_id, const char 
     A.P = P;
     A.seg_hash = idx->bld_seg_hash;
     A.seg_pos = idx->bld_seg_pos;
+    A.seg_last = with_last ? idx->bld_seg_last : nullptr;
     A.cap = cap;
     A.counts = idx->bld_counts;
     A.queue = idx->bld_queue;
@@ -143,12 +162,14 @@ static int64_t add_ref_device_locked(mq_index *idx, uint32_t ref_id, const char 
         n_kmm = (int64_t)(n_mz - P.k + 1);
         if ((rc = grow(idx->bld_dense_hash, idx->bld_dense_hash_cap, n_mz))) return rc;
         if ((rc = grow(idx->bld_dense_pos, idx->bld_dense_pos_cap, n_mz))) return rc;
+        if (with_last && (rc = grow(idx->bld_dense_last, idx->bld_dense_last_cap, n_mz))) return rc;
+        uint32_t *const dense_last = with_last ? idx->bld_dense_last : nullptr;
         hipLaunchKernelGGL(compact_lists_kernel, dim3(std::min<uint32_t>(n_seg, 65535u)), dim3(64), 0, 0, idx->bld_seg_hash, idx->bld_seg_pos, cap,
-                           idx->bld_counts, idx->bld_seg_off, n_seg, idx->bld_dense_hash, idx->bld_dense_pos);
+                           idx->bld_counts, idx->bld_seg_off, n_seg, idx->bld_dense_hash, idx->bld_dense_pos, A.seg_last, dense_last);
         HIPCHK(hipGetLastError());
         if (n_over) {
             hipLaunchKernelGGL(seed_ref_redo_kernel, dim3(std::min<uint32_t>(n_over, (uint32_t)idx->n_cu * 32u)), dim3(64), 0, 0, A, idx->bld_queue, n_over,
-                               idx->bld_seg_off, idx->bld_dense_hash, idx->bld_dense_pos);
+                               idx->bld_seg_off, idx->bld_dense_hash, idx->bld_dense_pos, dense_last);
             HIPCHK(hipGetLastError());
         }
         // the reference's k-min-mers go behind those of the previous references in the current chunk while it has room
@@ -160,7 +181,7 @@ static int64_t add_ref_device_locked(mq_index *idx, uint32_t ref_id, const char 
         }
         KmmChunk &ch = idx->chunks.back();
         const uint32_t kb = (uint32_t)std::min<uint64_t>(((uint64_t)n_kmm + 255) / 256, 65535ull);
-        hipLaunchKernelGGL(ref_kminmers_kernel, dim3(kb), dim3(256), 0, 0, idx->bld_dense_hash, idx->bld_dense_pos, n_mz, P, ref_id, ch.d + ch.n);
+        hipLaunchKernelGGL(ref_kminmers_kernel, dim3(kb), dim3(256), 0, 0, idx->bld_dense_hash, idx->bld_dense_pos, n_mz, P, ref_id, ch.d + ch.n, dense_last);
         HIPCHK(hipGetLastError());
         ch.n += (uint64_t)n_kmm;
         idx->n_kmm_total += (uint64_t)n_kmm;

@@ -29,6 +29,7 @@ static int launch_map(mq_ctx *c, const uint8_t *d_bases, const uint64_t *d_offse
     A.P = idx->dp;
     A.mz_hash = c->mz_hash;
     A.mz_pos = c->mz_pos;
+    A.mz_last = c->mz_last;
     A.mz_count = c->mz_count;
     A.mz_base = c->mz_base;
     A.pool_base = c->pool_base;
@@ -52,7 +53,11 @@ static int launch_map(mq_ctx *c, const uint8_t *d_bases, const uint64_t *d_offse
         uint32_t grid = std::min<uint32_t>(idx->grid_fused, (n + MAP_WAVES - 1) / MAP_WAVES);
         if (o.grid_override) grid = std::min(grid, o.grid_override);
         const dim3 blk(64 * MAP_WAVES);
-        if (o.instrumented) hipLaunchKernelGGL((map_kernel<64, true>), dim3(grid), blk, 0, st, A);
+        if (idx->dp.variant) {  // a seeding variant other than the frozen reading: the instantiation built with the variants
+            if (o.instrumented) hipLaunchKernelGGL((map_kernel<64, true, true>), dim3(grid), blk, 0, st, A);
+            else if (idx->chain_chunk == 4) hipLaunchKernelGGL((map_kernel<4, false, true>), dim3(grid), blk, 0, st, A);
+            else hipLaunchKernelGGL((map_kernel<64, false, true>), dim3(grid), blk, 0, st, A);
+        } else if (o.instrumented) hipLaunchKernelGGL((map_kernel<64, true>), dim3(grid), blk, 0, st, A);
         else if (idx->chain_chunk == 4) hipLaunchKernelGGL((map_kernel<4, false>), dim3(grid), blk, 0, st, A);
         else hipLaunchKernelGGL((map_kernel<64, false>), dim3(grid), blk, 0, st, A);
         HIPCHK(hipGetLastError());

@@ -37,7 +37,28 @@ struct DevParams {
     uint64_t bound;  // density bound: keep l-mer iff min(fh,rh) <= bound
     uint32_t k, l, use_hpc, c, s, g;
     uint32_t fold;  // 1: a-z count as A-Z (to_ascii_uppercase of src/closures.rs:63,106 done here instead of by the caller)
+    // Seeding variant (MQ_SEEDVAR_* bits, include/mapquik_hip.h; 0 = the frozen reading).  What the kernels see of each bit:
+    //   1, 2   nothing: `bound` already is what `hash <= bound` must be compared with (bound - 1 for the strict test; keep_none when
+    //          even that cannot say it: strict test against a bound of 0)
+    //   4      the seeds are the low halves of the 64-bit seeds, DUPLICATED into both halves of a 64-bit word: rol64 of such a word
+    //          is rol32 of its half in both halves, XOR keeps the form, and dup(a) <= dup(b) <=> a <= b -- so every kernel runs
+    //          unchanged on dup(h32) against bound = dup(bound32), and only a hash on its way into a list is cut to its low word
+    //   8      a minimizer's listed position is (raw position of the NEXT run head) - 1
+    //   16     a minimizer carries a second position (raw position of its window's last compressed base) in a list of its own
+    //   32     kminmer_hash: an undecided (palindromic) tuple counts as reversed
+    uint32_t variant;
+    uint32_t keep_none;  // 1: no l-mer passes the density test at all
 };
+// VAR = false: code built for the frozen reading only -- the variant bits are not even looked at, so map_kernel's instantiation for
+// variant 0 (every timed launch) carries none of the variants' code or registers; every other kernel is built with VAR = true and
+// decides at run time (wave-uniform branches), with identical results for variant 0
+template <bool VAR> __device__ __forceinline__ bool var_h32(const DevParams &P) { return VAR && (P.variant & MQ_SEEDVAR_HASH32) != 0; }
+template <bool VAR> __device__ __forceinline__ bool var_pos_end(const DevParams &P) { return VAR && (P.variant & MQ_SEEDVAR_POS_RUN_END) != 0; }
+template <bool VAR> __device__ __forceinline__ bool var_end_compressed(const DevParams &P) { return VAR && (P.variant & MQ_SEEDVAR_END_COMPRESSED) != 0; }
+template <bool VAR> __device__ __forceinline__ bool var_rev_eq(const DevParams &P) { return VAR && (P.variant & MQ_SEEDVAR_REV_ON_EQUAL) != 0; }
+template <bool VAR> __device__ __forceinline__ bool var_keep_none(const DevParams &P) { return VAR && P.keep_none != 0; }
+// a hash as it goes into a minimizer list: the 32-bit variant's value zero-extended
+template <bool VAR> __device__ __forceinline__ uint64_t list_hash(const DevParams &P, uint64_t h) { return var_h32<VAR>(P) ? (h & 0xFFFFFFFFull) : h; }
 
 // Index table: 64-byte buckets of two 32-byte slots, both keys first so that ONE 16-byte load decides most lookups.
 //   slot s = bucket s >> 1, way s & 1;  key == 0 <=> empty (a real key 0 lives in way 0 of one extra bucket behind the table).
@@ -78,6 +99,7 @@ struct alignas(16) MatchRec {
 struct WaveLds {
     unsigned long long mz_hash[MZ_CAP];
     uint32_t mz_pos[MZ_CAP];
+    uint32_t mz_last[MZ_CAP];  // variant 16 only: raw position of the window's last compressed base
     uint32_t ring_pos[RING];
     uint8_t ring_code[RING];
 };
@@ -176,12 +198,15 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
 __device__ __forceinline__ uint32_t base_code(uint32_t b) {
     return b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 4u;
 }
-__device__ __forceinline__ uint64_t nt_seed(uint32_t code) {
-    return code == 0 ? 0x3c8bfbb395c60474ULL
-         : code == 1 ? 0x3193c18562a02b4cULL
-         : code == 2 ? 0x20323ed082572324ULL
-         : code == 3 ? 0x295549f54be24456ULL
-                     : 0ULL;
+// h32 (variant 4): the low half of the seed in both halves of the word
+__device__ __forceinline__ uint64_t dup_low(uint64_t s) { return (s & 0xFFFFFFFFull) | (s << 32); }
+__device__ __forceinline__ uint64_t nt_seed(uint32_t code, bool h32 = false) {
+    const uint64_t s = code == 0 ? 0x3c8bfbb395c60474ULL
+                     : code == 1 ? 0x3193c18562a02b4cULL
+                     : code == 2 ? 0x20323ed082572324ULL
+                     : code == 3 ? 0x295549f54be24456ULL
+                                 : 0ULL;
+    return h32 ? dup_low(s) : s;
 }
 __device__ __forceinline__ uint32_t comp_code(uint32_t code) { return code < 4 ? 3u - code : 4u; }
 
@@ -271,13 +296,14 @@ struct Sip13 {
 };
 
 // canonical orientation + tuple hash of k minimizer hashes read through `get(i)`, i = 0..k-1 (forward order)
+// rev_eq (variant 32): a tuple equal to its reverse counts as reversed (`<=` instead of `<`)
 template <class Get>
-__device__ __forceinline__ uint64_t kminmer_hash(uint32_t k, Get get, bool &rev) {
-    rev = false;
+__device__ __forceinline__ uint64_t kminmer_hash(uint32_t k, Get get, bool &rev, bool rev_eq = false) {
+    rev = rev_eq;
     for (uint32_t i = 0; i < k; ++i) {
         uint64_t a = get(i), b = get(k - 1 - i);
         if (b < a) { rev = true; break; }
-        if (b > a) break;
+        if (b > a) { rev = false; break; }
     }
     Sip13 h;
     h.init();
@@ -291,7 +317,7 @@ __device__ __forceinline__ uint64_t kminmer_hash(uint32_t k, Get get, bool &rev)
 // a reverse tuple is the forward one with its pairs (i, k-1-i) exchanged under a lane mask -- three bit operations a half-word.
 // (`r ? w[k-1-i] : w[i]` compiled to a select of the INDEX and a chain of k-1 compare/select pairs per word.)
 template <uint32_t K, class Get>
-__device__ __forceinline__ uint64_t kminmer_hash_fixed(Get get, bool &rev) {
+__device__ __forceinline__ uint64_t kminmer_hash_fixed(Get get, bool &rev, bool rev_eq = false) {
     uint64_t w[K];
 #pragma unroll
     for (uint32_t i = 0; i < K; ++i) w[i] = get(i);
@@ -301,6 +327,7 @@ __device__ __forceinline__ uint64_t kminmer_hash_fixed(Get get, bool &rev) {
         r = decided ? r : (w[K - 1u - i] < w[i]);
         decided = decided || (w[K - 1u - i] != w[i]);
     }
+    r = decided ? r : rev_eq;  // a palindromic tuple: forward under `<`, reversed under `<=` (the exchange below leaves it as it is)
     rev = r;
     U2 m[K];
 #pragma unroll
@@ -355,7 +382,7 @@ __device__ __forceinline__ bool probe_table(const Bucket *__restrict__ table, ui
 // ------------------------------------------------------------------ streaming seeder
 // Emits, in order, every minimizer whose l-mer starts at a homopolymer-run head with raw index in [a, b).
 // Sink interface: void on_minimizers(WaveLds&, uint32_t &mz_count)  (called after each block, wave-uniform)
-template <class Sink>
+template <bool VAR = true, class Sink>
 __device__ __forceinline__ void seed_segment(const uint8_t *__restrict__ seq, uint64_t len, uint64_t a, uint64_t b,
                                              const DevParams &P, WaveLds &S, Sink &sink, uint32_t &mz_count) {
     const uint32_t lane = lane_id();
@@ -371,13 +398,14 @@ __device__ __forceinline__ void seed_segment(const uint8_t *__restrict__ seq, ui
     const uint32_t from = (lane - l) & 63u;
     const bool src_cur = lane + l <= 63u;
     const uint32_t rot_r = (lane - l + 1u) & 63u;
+    const bool h32 = var_h32<VAR>(P), pos_end = var_pos_end<VAR>(P), with_last = var_end_compressed<VAR>(P);  // seeding variants (wave-uniform)
 
     auto process_block = [&](uint32_t nvalid) {
         const uint32_t idx = hproc + lane;
         const bool valid = lane < nvalid;
         const uint32_t code = valid ? (uint32_t)S.ring_code[idx & (RING - 1)] : 4u;
-        uint64_t tf = rotr64(nt_seed(code), lane);
-        uint64_t tr = rotl64(nt_seed(comp_code(code)), lane);
+        uint64_t tf = rotr64(nt_seed(code, h32), lane);
+        uint64_t tr = rotl64(nt_seed(comp_code(code), h32), lane);
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             uint64_t of = shfl_up64(tf, d), orr = shfl_up64(tr, d);
@@ -394,12 +422,14 @@ __device__ __forceinline__ void seed_segment(const uint8_t *__restrict__ seq, ui
         const uint64_t rh = rotr64(tr ^ orr, rot_r);
         const uint64_t h = fh < rh ? fh : rh;
         const uint32_t j = idx - (l - 1u);  // HPC index of the window's first base
-        const bool sel = valid && idx >= l - 1u && j < s_elig && h <= P.bound;
+        const bool sel = valid && idx >= l - 1u && j < s_elig && h <= P.bound && !var_keep_none<VAR>(P);
         const uint64_t sm = __ballot(sel);
         if (sel) {
             const uint32_t o = mz_count + mbcnt64(sm);
-            S.mz_hash[o] = h;
-            S.mz_pos[o] = S.ring_pos[j & (RING - 1)];
+            S.mz_hash[o] = list_hash<VAR>(P, h);
+            // variant 8: the last base of the first base's run = the base in front of the next run head (l >= 2: inside the window)
+            S.mz_pos[o] = pos_end ? S.ring_pos[(j + 1u) & (RING - 1)] - 1u : S.ring_pos[j & (RING - 1)];
+            if (with_last) S.mz_last[o] = S.ring_pos[idx & (RING - 1)];  // variant 16: the window's last compressed base
         }
         mz_count += (uint32_t)__popcll(sm);
         prevF = tf;
@@ -625,6 +655,7 @@ struct MapSink {
     MatchRec *lds_rec;  // the first MAP_LDS_RECS Match records also go to LDS: a read with no more than that is chained from there
     mq_kminmer *__restrict__ dump;  // optional k-min-mer dump window for this read
     uint32_t dump_cap;
+    bool rev_eq;  // seeding variant 32: a palindromic tuple counts as reversed (a constant false in code built without the variants)
     // wave-uniform state
     uint32_t kmm_count = 0;
     uint32_t n_matches = 0;
@@ -633,8 +664,8 @@ struct MapSink {
     uint32_t c_hit = 0, c_id = 0, c_off = 0, c_sigma = 0;  // last element of the previous batch
     uint32_t probe_steps = 0;  // per lane: slots visited beyond the home slot (diagnostic: mean probes per lookup)
 
-    __device__ MapSink(const Bucket *t, uint64_t m, const DevParams &p, MatchRec *s, uint32_t cap, MatchRec *lr, mq_kminmer *d, uint32_t dc)
-        : table(t), mask(m), P(p), scratch(s), cap_matches(cap), lds_rec(lr), dump(d), dump_cap(dc) {}
+    __device__ MapSink(const Bucket *t, uint64_t m, const DevParams &p, MatchRec *s, uint32_t cap, MatchRec *lr, mq_kminmer *d, uint32_t dc, bool re)
+        : table(t), mask(m), P(p), scratch(s), cap_matches(cap), lds_rec(lr), dump(d), dump_cap(dc), rev_eq(re) {}
     // record i of the read: the first MAP_LDS_RECS stay in LDS, later ones go to their place in the wave's scratch in device memory
     // (records_to_scratch() then moves the LDS ones there too).  An ordinary read's records never leave LDS: no store's
     // acknowledgement is outstanding when the map phase ends.
@@ -657,8 +688,9 @@ struct MapSink {
         if (act) {
             auto get = [&](uint32_t i) { return (uint64_t)mzh[i0 + i]; };
             // 5: the reference's default k (src/main.rs: -k 5); 7: experiments/table1.sh:50; 8: example/run_ecoli.sh:26
-            key = P.k == 5u ? kminmer_hash_fixed<5>(get, rev) : P.k == 7u ? kminmer_hash_fixed<7>(get, rev) : P.k == 8u ? kminmer_hash_fixed<8>(get, rev)
-                                                                                                              : kminmer_hash(P.k, get, rev);
+            const bool re = rev_eq;
+            key = P.k == 5u ? kminmer_hash_fixed<5>(get, rev, re) : P.k == 7u ? kminmer_hash_fixed<7>(get, rev, re) : P.k == 8u ? kminmer_hash_fixed<8>(get, rev, re)
+                                                                                                                  : kminmer_hash(P.k, get, rev, re);
             q_start = mzp[i0];
             q_end = mzp[i0 + P.k - 1] + P.l - 1u;
         }
@@ -859,8 +891,11 @@ struct MapSink {
     // All k-min-mers of an ordered minimizer list (have <= 64*NB + k - 1 entries) in one go: every tuple hash first, every home
     // bucket's keys in flight together, the probes resolved together (probe_all), then the runs batch by batch.
     // hashes_done(): called once the minimizers' hashes (mzh) have all been read -- the positions (mzp) are still needed
+    // mzq (variant 16 only, else nullptr): the minimizers' second positions (the window's last compressed base), valid once
+    // hashes_done() has returned (the caller stages them where the hashes were)
     template <int NB, class F>
-    __device__ __forceinline__ void consume_list(const unsigned long long *mzh, const uint32_t *mzp, uint32_t have, const F &hashes_done) {
+    __device__ __forceinline__ void consume_list(const unsigned long long *mzh, const uint32_t *mzp, uint32_t have, const F &hashes_done,
+                                                 const uint32_t *mzq = nullptr) {
         if (have < P.k) return;
         const uint32_t lane = lane_id();
         const uint32_t K = have - P.k + 1u;
@@ -902,7 +937,7 @@ struct MapSink {
                 uint32_t qs = 0, qe = 0;
                 if (act) {
                     qs = mzp[i0];
-                    qe = mzp[i0 + P.k - 1] + P.l - 1u;
+                    qe = mzq ? mzq[i0 + P.k - 1] : mzp[i0 + P.k - 1] + P.l - 1u;
                 }
                 Entry e;
                 e.start = kk[c].x;
@@ -932,9 +967,10 @@ struct MapSink {
 struct SoaListSink {
     unsigned long long *__restrict__ out_hash;
     uint32_t *__restrict__ out_pos;
+    uint32_t *__restrict__ out_last;  // variant 16 only (else nullptr): the second position of every minimizer
     uint32_t cap;
     uint32_t written = 0;  // may exceed cap (the map stage then reports the read as overflowed)
-    __device__ SoaListSink(unsigned long long *h, uint32_t *p, uint32_t c) : out_hash(h), out_pos(p), cap(c) {}
+    __device__ SoaListSink(unsigned long long *h, uint32_t *p, uint32_t *q, uint32_t c) : out_hash(h), out_pos(p), out_last(q), cap(c) {}
     __device__ __forceinline__ void on_minimizers(WaveLds &S, uint32_t &mz_count) {
         const uint32_t lane = lane_id();
         for (uint32_t base = 0; base < mz_count; base += 64u) {
@@ -942,6 +978,7 @@ struct SoaListSink {
             if (i < mz_count && written + i < cap) {
                 out_hash[written + i] = S.mz_hash[i];
                 out_pos[written + i] = S.mz_pos[i];
+                if (out_last) out_last[written + i] = S.mz_last[i];
             }
         }
         written += mz_count;

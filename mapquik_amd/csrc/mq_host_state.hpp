@@ -33,6 +33,7 @@ struct mq_ctx {
     size_t scratch_waves = 0;       // waves it has windows for
     unsigned long long *mz_hash = nullptr;
     uint32_t *mz_pos = nullptr;
+    uint32_t *mz_last = nullptr;    // seeding variant 16 only: every minimizer's second position (allocated with mz_pos, else nullptr)
     uint64_t mz_cap = 0;            // list entries allocated
     uint32_t *mz_count = nullptr;
     uint64_t *mz_base = nullptr;
@@ -99,7 +100,8 @@ struct mq_index {
     uint64_t bld_seq_cap = 0;
     unsigned long long *bld_seg_hash = nullptr, *bld_dense_hash = nullptr;  // per-segment minimizer lists, the reference's dense list
     uint32_t *bld_seg_pos = nullptr, *bld_dense_pos = nullptr;
-    uint64_t bld_seg_hash_cap = 0, bld_seg_pos_cap = 0, bld_dense_hash_cap = 0, bld_dense_pos_cap = 0;
+    uint32_t *bld_seg_last = nullptr, *bld_dense_last = nullptr;  // seeding variant 16 only
+    uint64_t bld_seg_hash_cap = 0, bld_seg_pos_cap = 0, bld_dense_hash_cap = 0, bld_dense_pos_cap = 0, bld_seg_last_cap = 0, bld_dense_last_cap = 0;
     uint32_t *bld_counts = nullptr, *bld_queue = nullptr;
     uint64_t bld_counts_cap = 0, bld_queue_cap = 0;
     unsigned long long *bld_seg_off = nullptr;
@@ -161,12 +163,43 @@ void mq_params_default(mq_params *p) {
 
 }  // extern "C"
 
-// (density as FH * u64::MAX as FH) as u64 with Rust's saturating float->int cast
-static uint64_t density_bound(double density) {
-    double d = density * 18446744073709551615.0;
+// (density as FH * H::MAX as FH) as H with Rust's saturating float->int cast, for the seeding variant's FH (f64; f32 with bit 2) and H
+// (u64; u32 with bit 4)
+static uint64_t density_bound(double density, uint32_t variant) {
+    if (variant & MQ_SEEDVAR_HASH32) {
+        if (variant & MQ_SEEDVAR_F32_BOUND) {
+            const float f = (float)density * 4294967295.0f;
+            if (!(f > 0.0f)) return 0;
+            if (f >= 4294967296.0f) return 0xFFFFFFFFull;
+            return (uint64_t)(uint32_t)f;
+        }
+        const double d = density * 4294967295.0;
+        if (!(d > 0.0)) return 0;
+        if (d >= 4294967296.0) return 0xFFFFFFFFull;
+        return (uint64_t)(uint32_t)d;
+    }
+    if (variant & MQ_SEEDVAR_F32_BOUND) {
+        const float f = (float)density * 18446744073709551615.0f;
+        if (!(f > 0.0f)) return 0;
+        if (f >= 18446744073709551616.0f) return UINT64_MAX;
+        return (uint64_t)f;
+    }
+    const double d = density * 18446744073709551615.0;
     if (!(d > 0.0)) return 0;
     if (d >= 18446744073709551616.0) return UINT64_MAX;
     return (uint64_t)d;
+}
+// DevParams of an index: the bound in the form the kernels compare with (`hash <= bound` on 64-bit words; DevParams::variant)
+static void set_dev_bound(DevParams &dp, double density, uint32_t variant) {
+    uint64_t b = density_bound(density, variant);
+    dp.keep_none = 0;
+    if (variant & MQ_SEEDVAR_STRICT_BOUND) {  // hash < b  <=>  hash <= b - 1; nothing is below 0
+        if (b == 0) dp.keep_none = 1;
+        else b -= 1;
+    }
+    if (variant & MQ_SEEDVAR_HASH32) b = (b & 0xFFFFFFFFull) | (b << 32);  // dup(bound32): compared with dup(hash32)
+    dp.bound = b;
+    dp.variant = variant;
 }
 
 static int use_device(const mq_index *idx) {
@@ -300,12 +333,15 @@ static int ctx_ensure(mq_ctx *c, uint32_t n, uint64_t total_bases, uint32_t f16)
     if (need > c->mz_cap) {
         if (c->mz_hash) HIPCHK(hipFree(c->mz_hash));
         if (c->mz_pos) HIPCHK(hipFree(c->mz_pos));
+        if (c->mz_last) HIPCHK(hipFree(c->mz_last));
         c->mz_hash = nullptr;
         c->mz_pos = nullptr;
+        c->mz_last = nullptr;
         c->mz_cap = 0;
         const uint64_t nc = need + need / 8;
         HIPCHK(hipMalloc((void **)&c->mz_hash, nc * 8));
         HIPCHK(hipMalloc((void **)&c->mz_pos, nc * 4));
+        if (idx->dp.variant & MQ_SEEDVAR_END_COMPRESSED) HIPCHK(hipMalloc((void **)&c->mz_last, nc * 4));
         c->mz_cap = nc;
     }
     return MQ_OK;
@@ -318,6 +354,7 @@ static void ctx_release(mq_ctx *c) {
     hipFree(c->scratch);
     hipFree(c->mz_hash);
     hipFree(c->mz_pos);
+    hipFree(c->mz_last);
     hipFree(c->mz_count);
     hipFree(c->mz_base);
     hipFree(c->queue);
@@ -362,6 +399,8 @@ static void free_build_scratch(mq_index *idx) {
     hipFree(idx->bld_seg_pos);
     hipFree(idx->bld_dense_hash);
     hipFree(idx->bld_dense_pos);
+    hipFree(idx->bld_seg_last);
+    hipFree(idx->bld_dense_last);
     hipFree(idx->bld_counts);
     hipFree(idx->bld_queue);
     hipFree(idx->bld_seg_off);
@@ -369,6 +408,8 @@ static void free_build_scratch(mq_index *idx) {
     idx->bld_seq = nullptr;
     idx->bld_seg_hash = idx->bld_dense_hash = nullptr;
     idx->bld_seg_pos = idx->bld_dense_pos = nullptr;
+    idx->bld_seg_last = idx->bld_dense_last = nullptr;
+    idx->bld_seg_last_cap = idx->bld_dense_last_cap = 0;
     idx->bld_counts = idx->bld_queue = nullptr;
     idx->bld_seg_off = nullptr;
     idx->bld_info = nullptr;

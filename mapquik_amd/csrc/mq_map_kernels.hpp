@@ -26,6 +26,7 @@ struct SplitArgs {
     DevParams P;
     unsigned long long *mz_hash;
     uint32_t *mz_pos;
+    uint32_t *mz_last;     // seeding variant 16 only (else nullptr): every minimizer's second position, same regions as mz_pos
     uint32_t *mz_count;    // split pipeline only: list length of read r (or NOT_FAST / LIST_OVERFLOW)
     uint64_t *mz_base;     // split pipeline only: where read r's list starts (its regular region or a pool region)
     uint64_t pool_base, pool_cap;  // the pool: entries [pool_base, pool_base + pool_cap)
@@ -62,13 +63,14 @@ __device__ __forceinline__ bool pool_take(const SplitArgs &A, uint32_t cnt, uint
 }
 
 // seed phase, fast seeder: list length, SD_NOT_FAST (declined: non-ACGT byte, ...) or LIST_OVERFLOW; base moves with the list
-template <int STOP = 0>
+template <int STOP = 0, bool VAR = true>
 __device__ __forceinline__ uint32_t seed_read_fast(const SplitArgs &A, const SeedTables &T, SeedLds &S, const uint8_t *seq,
                                                    uint32_t len, uint64_t &base, uint32_t cap, uint32_t &n_moved, APre &pre, bool pre_valid) {
-    uint32_t cnt = seed_sequence_fast<STOP>(seq, len, A.P, T, S, A.mz_hash + base, A.mz_pos + base, cap, pre, pre_valid);
+    uint32_t cnt = seed_sequence_fast<STOP, false, VAR>(seq, len, A.P, T, S, A.mz_hash + base, A.mz_pos + base, cap, pre, pre_valid, SeedView(),
+                                                        A.mz_last ? A.mz_last + base : nullptr);
     if (cnt != SD_NOT_FAST && cnt > cap) {  // denser than its region: once more, into an exact-size pool region
         if (pool_take(A, cnt, base)) {
-            seed_sequence_fast(seq, len, A.P, T, S, A.mz_hash + base, A.mz_pos + base, cnt, pre, false);
+            seed_sequence_fast<0, false, VAR>(seq, len, A.P, T, S, A.mz_hash + base, A.mz_pos + base, cnt, pre, false, SeedView(), A.mz_last ? A.mz_last + base : nullptr);
             n_moved++;
         } else {
             cnt = LIST_OVERFLOW;
@@ -78,20 +80,21 @@ __device__ __forceinline__ uint32_t seed_read_fast(const SplitArgs &A, const See
 }
 
 // seed phase, general streaming seeder (any bytes, any length)
+template <bool VAR = true>
 __device__ __forceinline__ uint32_t seed_read_general(const SplitArgs &A, WaveLds &S, const uint8_t *seq, uint64_t len, uint64_t &base,
                                                       uint32_t cap, uint32_t &n_moved) {
     uint32_t cnt;
     {
-        SoaListSink sink(A.mz_hash + base, A.mz_pos + base, cap);
+        SoaListSink sink(A.mz_hash + base, A.mz_pos + base, (VAR && A.mz_last) ? A.mz_last + base : nullptr, cap);
         uint32_t mz_count = 0;
-        seed_segment(seq, len, 0, len, A.P, S, sink, mz_count);
+        seed_segment<VAR>(seq, len, 0, len, A.P, S, sink, mz_count);
         cnt = sink.written;
     }
     if (cnt > cap) {
         if (pool_take(A, cnt, base)) {
-            SoaListSink sink(A.mz_hash + base, A.mz_pos + base, cnt);
+            SoaListSink sink(A.mz_hash + base, A.mz_pos + base, (VAR && A.mz_last) ? A.mz_last + base : nullptr, cnt);
             uint32_t mz_count = 0;
-            seed_segment(seq, len, 0, len, A.P, S, sink, mz_count);
+            seed_segment<VAR>(seq, len, 0, len, A.P, S, sink, mz_count);
             n_moved++;
         } else {
             cnt = LIST_OVERFLOW;
@@ -136,7 +139,7 @@ struct NoOp {
 };
 // lds_h / lds_p: the whole list (cnt entries) already in LDS -- then nothing is staged; nullptr: the list is at `base` in device memory.
 // list_done(): called exactly once, when the staged HASHES (S.h) are no longer needed: after the tuple hashes of the list's last chunk.
-template <int CH, bool TIMING, class F = NoOp>
+template <int CH, bool TIMING, class F = NoOp, bool VAR = true>
 __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, MatchRec *scratch, uint32_t r, uint64_t len, uint32_t cnt,
                                          uint64_t base, unsigned long long &t_steps, unsigned long long &t_lookups, mq_hit &h,
                                          const unsigned long long *lds_h = nullptr, const uint32_t *lds_p = nullptr, const F &list_done = F()) {
@@ -154,7 +157,7 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
             d = A.dump + A.dump_off[r];
             dcap = (uint32_t)(A.dump_off[r + 1] - A.dump_off[r]);
         }
-        MapSink sink(A.table, A.mask, P, scratch, A.cap_matches, S.rec, d, dcap);
+        MapSink sink(A.table, A.mask, P, scratch, A.cap_matches, S.rec, d, dcap, var_rev_eq<VAR>(P));
         const unsigned long long *lh = A.mz_hash + base;
         const uint32_t *lp = A.mz_pos + base;
         const uint32_t chunk = 64u * (uint32_t)ML_NB + P.k - 1u;
@@ -187,12 +190,20 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
             }
             wave_sync();
             mq_clk(5);
+            // seeding variant 16: the chunk's second positions take the place of its hashes once those are used up (S.h as dwords)
+            uint32_t *mzq = (VAR && A.mz_last && !lds_h) ? reinterpret_cast<uint32_t *>(S.h) : nullptr;
             sink.template consume_list<ML_NB>(lds_h ? lds_h + g : S.h, lds_p ? lds_p + g : S.p, have, [&]() {
+                if (mzq) {
+                    const uint32_t *lq = A.mz_last + base + g;
+                    wave_sync();  // every lane's reads of the staged hashes are done
+                    for (uint32_t i = lane; i < have; i += 64u) mzq[i] = ld_sc1_u32(lq + i);
+                    wave_sync();
+                }
                 if (last && !requested) {
                     requested = true;
                     list_done();
                 }
-            });
+            }, mzq);
             wave_sync();
             g += have - (P.k - 1u);
         }
@@ -260,7 +271,9 @@ union MapWaveLds {
 };
 
 // CH: lanes per chunk in the chain stage (64 in production; 4 only in tests so that ordinary reads take the multi-chunk path)
-template <int CH, bool TIMING = false>
+// VAR: built with the seeding variants (mq_params.flags bits 8..13); the launch for variant 0 -- the frozen reading, every timed launch --
+// uses the instantiation without them
+template <int CH, bool TIMING = false, bool VAR = false>
 __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(const SplitArgs A) {
     // one block of LDS with the tables FIRST: T.rot's entries are addressed through the 16-bit immediate offset of ds_read_b128
     __shared__ struct {
@@ -272,7 +285,7 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
     } W;
     SeedTables &T = W.T;
     MapWaveLds(&SS)[MAP_WAVES] = W.SS;
-    build_seed_tables(T, A.P.l);
+    build_seed_tables(T, A.P.l, var_h32<VAR>(A.P));
     __syncthreads();  // the only workgroup-wide rendezvous; waves are independent from here on
     const uint32_t lane = lane_id();
     const uint32_t wv = rdfirst(threadIdx.x >> 6);  // wave-uniform: per-wave bases stay in SGPRs
@@ -318,14 +331,14 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         // extract(): len < l + k - 1 => None (src/mers.rs:44)
         if (len >> 32) {
             cnt = LIST_OVERFLOW;  // beyond the documented limit (checked on the host where the host sees the lengths): loud, not wrong
-        } else if (len >= (uint64_t)P.l + P.k - 1u) {
+        } else if (len >= (uint64_t)P.l + P.k - 1u && !var_keep_none<VAR>(P)) {
             uint32_t cap;
             list_region(A, o0 - o_base, len, r, base, cap);
 #if MQ_LDS_LIST
             cnt = SD_NOT_FAST;
             if (!A.force_general) {
                 ReadListLds &L = W.LL[wv];
-                const LdsThenGlobalList<LDS_LIST_CAP> out = {L, {A.mz_hash + base, A.mz_pos + base, cap}};
+                const LdsThenGlobalList<LDS_LIST_CAP> out = {L, {A.mz_hash + base, A.mz_pos + base, cap, nullptr}};
                 cnt = seed_sequence_fast_to<0, false, LdsThenGlobalList<LDS_LIST_CAP>>(A.bases + o0, (uint32_t)len, P, T, S.seed, out, pre, false);
                 if (cnt != SD_NOT_FAST) {
                     if (cnt <= LDS_LIST_CAP) {
@@ -345,12 +358,12 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
                 }
             }
 #else
-            cnt = A.force_general ? SD_NOT_FAST : seed_read_fast(A, T, S.seed, A.bases + o0, (uint32_t)len, base, cap, n_moved, pre, pre_valid);
+            cnt = A.force_general ? SD_NOT_FAST : seed_read_fast<0, VAR>(A, T, S.seed, A.bases + o0, (uint32_t)len, base, cap, n_moved, pre, pre_valid);
 #endif
             if (cnt == SD_NOT_FAST) {
                 n_general++;
                 wave_sync();
-                cnt = seed_read_general(A, S.general, A.bases + o0, len, base, cap, n_moved);
+                cnt = seed_read_general<VAR>(A, S.general, A.bases + o0, len, base, cap, n_moved);
                 mq_clk(10);
             } else {
                 n_fast++;
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         };
         map_read<CH, TIMING>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h, nullptr, nullptr, request_next);
 #else
-        map_read<CH, TIMING>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h);
+        map_read<CH, TIMING, NoOp, VAR>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h);
 #endif
         wave_sync();
         const uint32_t r_done = r;
@@ -485,7 +498,7 @@ __global__ __launch_bounds__(64 * SEED_WAVES, MQ_SEED_MIN_WAVES) void seed_reads
     } W;
     SeedTables &T = W.T;
     SeedLds(&SS)[SEED_WAVES] = W.SS;
-    build_seed_tables(T, A.P.l);
+    build_seed_tables(T, A.P.l, var_h32<true>(A.P));
     __syncthreads();
     const uint32_t lane = lane_id();
     const uint32_t wv = rdfirst(threadIdx.x >> 6);  // wave-uniform: per-wave bases stay in SGPRs
@@ -505,7 +518,7 @@ __global__ __launch_bounds__(64 * SEED_WAVES, MQ_SEED_MIN_WAVES) void seed_reads
         uint64_t base = 0;
         if (len >> 32) {
             cnt = LIST_OVERFLOW;
-        } else if (len >= (uint64_t)P.l + P.k - 1u) {
+        } else if (len >= (uint64_t)P.l + P.k - 1u && !var_keep_none<true>(P)) {
             uint32_t cap;
             list_region(A, o0 - o_base, len, r, base, cap);
             APre pre;

@@ -78,11 +78,15 @@ struct SeedLds {
 };
 
 // 2-bit code = (ASCII >> 1) & 3 : A=0 C=1 T=2 G=3 ; complement = code ^ 2
-__device__ __forceinline__ uint64_t seed_of(uint32_t code) {
-    return code == 0 ? 0x3c8bfbb395c60474ULL : code == 1 ? 0x3193c18562a02b4cULL : code == 2 ? 0x295549f54be24456ULL : 0x20323ed082572324ULL;
+// h32 (seeding variant 4): the low half of the seed in both halves of the word -- every table entry, every hash and the bound then
+// have that form, and the 64-bit code below computes the 32-bit ntHash (rotations mod 32) in each half (DevParams::variant)
+__device__ __forceinline__ uint64_t seed_of(uint32_t code, bool h32) {
+    const uint64_t s = code == 0 ? 0x3c8bfbb395c60474ULL : code == 1 ? 0x3193c18562a02b4cULL : code == 2 ? 0x295549f54be24456ULL : 0x20323ed082572324ULL;
+    return h32 ? dup_low(s) : s;
 }
 
-__device__ __forceinline__ void build_seed_tables(SeedTables &T, uint32_t l) {
+__device__ __forceinline__ void build_seed_tables(SeedTables &T, uint32_t l, bool h32) {
+    auto seed_of = [h32](uint32_t code) { return mq::seed_of(code, h32); };
     for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) {
         uint32_t prev = i & 3u, out = 0, n = 0, hb = 0;
         for (uint32_t m = 0; m < 4; ++m) {
@@ -675,10 +679,12 @@ struct GlobalList {  // a region of the minimizer buffers in device memory (entr
     unsigned long long *__restrict__ hash;
     uint32_t *__restrict__ pos;
     uint32_t cap;
-    __device__ __forceinline__ void put(uint32_t dest, uint64_t hv, uint32_t p) const {
+    uint32_t *__restrict__ last;  // seeding variant 16 only (else nullptr): every minimizer's second position
+    __device__ __forceinline__ void put(uint32_t dest, uint64_t hv, uint32_t p, uint32_t lp) const {
         if (dest < cap) {
             hash[dest] = hv;
             pos[dest] = p;
+            if (last) last[dest] = lp;
         }
     }
 };
@@ -693,7 +699,8 @@ template <uint32_t LCAP>
 struct LdsThenGlobalList {
     LdsList<LCAP> &L;
     GlobalList G;
-    __device__ __forceinline__ void put(uint32_t dest, uint64_t hv, uint32_t p) const {
+    __device__ __forceinline__ void put(uint32_t dest, uint64_t hv, uint32_t p, uint32_t lp) const {
+        // (this experimental build has no second position in LDS: mq_index_new refuses seeding variant 16 under MQ_LDS_LIST)
         // typed LDS stores: left generic, the compiler folds the two branches into ONE flat store through a selected pointer -- which
         // counts on both the LDS and the memory counter and costs every later LDS wait a memory round trip
         typedef __attribute__((address_space(3))) unsigned long long lds_u64;
@@ -702,7 +709,7 @@ struct LdsThenGlobalList {
             *(lds_u64 *)(&L.h[dest]) = hv;
             *(lds_u32 *)(&L.p[dest]) = p;
         } else {
-            G.put(dest, hv, p);
+            G.put(dest, hv, p, lp);
         }
     }
 };
@@ -713,7 +720,7 @@ struct LdsThenGlobalList {
 // Every lane first writes the windows of its own candidates to their places in the list (its flags are in registers: lowest
 // set bit, clear, next), so that a candidate's lane afterwards reads ONE value and starts its look-ups -- no search for the owning
 // lane, no bit select in another lane's flags.
-template <bool VIEW = false, class Out = GlobalList>
+template <bool VIEW = false, class Out = GlobalList, bool VAR = true>
 __device__ __forceinline__ uint32_t seed_stage_r(const SeedTables &T, SeedLds &S, const DevParams &P, uint32_t w_eff,
                                                  uint32_t n_blocks, uint32_t n_codes, uint32_t raw_base, uint32_t carry_n,
                                                  const Out &out, uint32_t out_base, bool &inexact, const SeedView &V = SeedView()) {
@@ -767,7 +774,12 @@ __device__ __forceinline__ uint32_t seed_stage_r(const SeedTables &T, SeedLds &S
                 if (hv > P.bound) inexact = true;
                 const uint32_t dest = out_base + i;
                 const bool listed = !VIEW || pos < V.elig_end;
-                if (listed) out.put(dest, hv, VIEW ? pos + V.pos_add : pos);
+                // seeding variants (wave-uniform, off in the frozen reading): 8 lists the last base of the first base's run = the base in
+                // front of the next run head (l >= 2: code j + 1 is inside the window); 16 adds the window's last compressed base
+                uint32_t rep = pos, lp = 0;
+                if (var_pos_end<VAR>(P)) rep = seed_rawpos_batch(S, raw_base, carry_n, j + 1u) - 1u;
+                if (var_end_compressed<VAR>(P)) lp = seed_rawpos_batch(S, raw_base, carry_n, j + P.l - 1u) + (VIEW ? V.pos_add : 0u);
+                if (listed) out.put(dest, list_hash<VAR>(P, hv), VIEW ? rep + V.pos_add : rep, lp);
                 if (VIEW) n_listed += (uint32_t)__popcll(__ballot(listed));
             }
         }
@@ -787,7 +799,7 @@ __device__ __forceinline__ bool seed_fast_eligible(uint64_t len) { return len >=
 // pre / pre_valid: the sequence's first super-row already requested by the caller (stage_a_request); else it is requested here.
 // VIEW: seq[0, len) is a window of a longer sequence (SeedView): only the minimizers that start before V.elig_end are listed and
 // counted, positions are shifted by V.pos_add, the base in front of the view decides whether its first base is a run head.
-template <int STOP = 0, bool VIEW = false, class Out = GlobalList>
+template <int STOP = 0, bool VIEW = false, class Out = GlobalList, bool VAR = true>
 __device__ __forceinline__ uint32_t seed_sequence_fast_to(const uint8_t *__restrict__ seq, uint32_t len, const DevParams &P, const SeedTables &T,
                                                           SeedLds &S, const Out &out, APre &pre, bool pre_valid, const SeedView &V = SeedView()) {
     const uint32_t lane = lane_id();
@@ -818,7 +830,7 @@ __device__ __forceinline__ uint32_t seed_sequence_fast_to(const uint8_t *__restr
             mq_clk(1);
             if (STOP != 2) {
                 bool inexact = false;
-                n_out += seed_stage_r<VIEW, Out>(T, S, P, w_eff, n_blocks, n_codes, raw0, carry_n, out, n_out, inexact, V);
+                n_out += seed_stage_r<VIEW, Out, VAR>(T, S, P, w_eff, n_blocks, n_codes, raw0, carry_n, out, n_out, inexact, V);
                 mq_clk(2);
                 if (inexact) return SD_NOT_FAST;
             }
@@ -849,13 +861,13 @@ __device__ __forceinline__ uint32_t seed_sequence_fast_to(const uint8_t *__restr
     return n_out;
 }
 // the list in device memory: mz_hash[0, out_cap), mz_pos[0, out_cap)
-template <int STOP = 0, bool VIEW = false>
+template <int STOP = 0, bool VIEW = false, bool VAR = true>
 __device__ __forceinline__ uint32_t seed_sequence_fast(const uint8_t *__restrict__ seq, uint32_t len, const DevParams &P, const SeedTables &T,
                                                        SeedLds &S, unsigned long long *__restrict__ mz_hash,
                                                        uint32_t *__restrict__ mz_pos, uint32_t out_cap, APre &pre, bool pre_valid,
-                                                       const SeedView &V = SeedView()) {
-    const GlobalList out = {mz_hash, mz_pos, out_cap};
-    return seed_sequence_fast_to<STOP, VIEW, GlobalList>(seq, len, P, T, S, out, pre, pre_valid, V);
+                                                       const SeedView &V = SeedView(), uint32_t *__restrict__ mz_last = nullptr) {
+    const GlobalList out = {mz_hash, mz_pos, out_cap, VAR ? mz_last : nullptr};
+    return seed_sequence_fast_to<STOP, VIEW, GlobalList, VAR>(seq, len, P, T, S, out, pre, pre_valid, V);
 }
 
 }  // namespace mq

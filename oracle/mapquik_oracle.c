@@ -74,8 +74,8 @@ uint64_t mqo_ntc64(const uint8_t *s, size_t i, size_t l) {
 }
 
 /* Hedge for the unpinned seeding decisions: the frozen reading is variant 0.  The other variants exist
- * only so that tools/check_against_upstream.sh can tell, on a machine that can build the real crate, WHICH decision is wrong
- * if the k-min-mer dumps differ.  Bits (any combination):
+ * so that tools/check_against_upstream.sh can tell, on a machine that can build the real crate, WHICH decision is wrong
+ * if the k-min-mer dumps differ -- and the product can then be run with that reading.  Bits (any combination):
  *    1  D3   strict `<` on the density bound instead of `<=`
  *    2  D2   FH is f32: the bound is computed in single precision
  *    4  D2/D12  H is u32: ntHash in 32-bit words (seeds = low halves of the 64-bit seeds, rotations mod 32) and a 32-bit bound
@@ -83,7 +83,8 @@ uint64_t mqo_ntc64(const uint8_t *s, size_t i, size_t l) {
  *    8  D5   a minimizer's position = raw index of the LAST base of its first base's homopolymer run (frozen: the run head)
  *   16  D6   end = raw position of the last compressed base of the last minimizer's l-mer (frozen: pos[k-1] + l - 1, raw l)
  *   32  D8   rev = reversed tuple <= forward tuple (frozen: strict <; differs on palindromic tuples only)
- * Never set by tests of the product or by the product. */
+ * The product has the same six switches (mq_params.flags bits 8..13, include/mapquik_hip.h): tests/ set a variant here and the same
+ * value there and compare the two, variant by variant; everything else in the repository runs the frozen reading. */
 static int g_variant = 0;
 void mqo_set_variant(int v) { g_variant = v; }
 int mqo_get_variant(void) { return g_variant; }

@@ -52,7 +52,9 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_abi_version_and_defaults(lib):
     import mapquik_amd
-    assert lib.mq_abi_version() == 3  # 3: mq_hit carries columns 3 and 4 as 64 bits (48-byte records)
+    # 3: mq_hit carries columns 3 and 4 as 64 bits (48-byte records); 4: FASTA pieces on the device, mq_index_reserve, page-lock helpers,
+    # the diagnostics' own header (mq_last_stage_clocks fills 16 values), seeding variants in mq_params.flags
+    assert lib.mq_abi_version() == 4
     p = mapquik_amd.Params()
     q = mapquik_amd.Params(0, 0, 0.0, False, 0, 0, 0)
     lib.mq_params_default(C.byref(q))

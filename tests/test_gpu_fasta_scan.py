@@ -101,6 +101,46 @@ def test_irregular_pieces_are_handed_back(mq, world):
     ctx.close()
 
 
+def test_more_line_ends_than_the_scan_holds(mq, world, tmp_path):
+    """A well-formed FASTA of very short records (primers, barcodes, k-mers: under ~32 bytes each) has more line ends than the scan's
+    list holds (bytes / 16 + 4096): the piece must come back IRREGULAR with NO record reported -- never a record count that indexes
+    past the list -- and the driver then parses it on the host: the same PAF (no line: nothing that short maps) and exit code 0.
+    Junk input full of newlines likewise."""
+    ix = world["ix"]
+    ctx = ix.context()
+    for piece in (b">a\nAC\n" * 40000, b">a\nAC\n" * 1500000, b"\n" * 300000, b">x\n" + b"\n" * 200001):
+        ctx.submit_fasta(np.frombuffer(piece, dtype=np.uint8))
+        hits, lines, flags = ctx.wait_fasta()
+        assert flags & 1 and hits.size == 0 and lines.size == 0
+    # just under the capacity: regular, every record reported, nothing maps
+    n = 2400
+    piece = b">a\nAC\n" * n  # 2 n = 4,800 line ends <= 6 n / 16 + 4096 = 4,996
+    ctx.submit_fasta(np.frombuffer(piece, dtype=np.uint8))
+    hits, lines, flags = ctx.wait_fasta()
+    assert flags == 0 and hits.size == n and lines.size == 2 * n and not (hits["status"] != 0).any()
+    ctx.close()
+    # through the driver: short records in front of real reads, one chunk and many
+    from mapquik_amd import build
+    exe = build.build_cli()
+    from tools import sim
+    g, off, names = sim.make_genome([700000, 400000], seed=91, repeat_frac=0.1, tandem_frac=0.02)
+    ref = tmp_path / "ref.fa"
+    with open(ref, "wb") as w:
+        for r in range(2):
+            w.write(b">" + names[r].encode() + b"\n" + g[int(off[r]):int(off[r + 1])].tobytes() + b"\n")
+    txt, _ = _fasta(world)
+    rd = tmp_path / "short_then_reads.fa"
+    rd.write_bytes(b">p\nACGTACGT\n" * 60000 + txt)
+    outs = []
+    for chunk, env in (("33554432", {}), ("200000", {}), ("33554432", {"MQ_DRIVER_HOST_PARSE": "1"})):
+        prefix = str(tmp_path / ("s%d" % len(outs)))
+        r = subprocess.run([exe, str(rd), "--reference", str(ref), "-p", prefix, "--batch-bases", chunk, "--threads", "3"], capture_output=True, text=True,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(open(prefix + ".paf").read())
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 10000
+
+
 def test_native_driver_fasta_device_and_host_parse(mq, oracle, world, tmp_path):
     """FASTA file -> PAF through the native driver: records found on the device (default), parsed by the reader threads
     (MQ_DRIVER_HOST_PARSE=1), and a multi-line FASTA whose chunks all come back irregular -- the oracle's PAF every time, at chunk

@@ -45,7 +45,7 @@ while [ $i -lt ${#args[@]} ]; do
   esac
 done
 best=""
-for v in 0 1 2 3 4 5 6 7 8 16 24 32; do
+for v in 32 24 16 8 7 6 5 4 3 2 1 0; do   # (variant 0 last: when several readings match this input, the frozen one is the one kept)
   python3 "$HERE/tools/dump_kminmers.py" "$REF" --variant $v "${OFLAGS[@]}" > "$WORK/oracle.v$v.kmm"
   if cmp -s "$WORK/upstream.kmm" "$WORK/oracle.v$v.kmm"; then
     echo "k-min-mer tuples: oracle variant $v IDENTICAL to the reference ($(wc -l < "$WORK/upstream.kmm") tuples)"; best=$v
@@ -54,11 +54,12 @@ for v in 0 1 2 3 4 5 6 7 8 16 24 32; do
     diff "$WORK/upstream.kmm" "$WORK/oracle.v$v.kmm" | head -4 || true
   fi
 done
-[ "$best" = "0" ] && echo "seeding stage PINNED: the frozen reading (variant 0) reproduces the crate" || echo "seeding stage NOT pinned by variant 0 (matching variant: '${best:-none}'): DESIGN.md section 2 names the kernel constant behind each bit"
+[ "$best" = "0" ] && echo "seeding stage PINNED: the frozen reading (variant 0) reproduces the crate" || echo "seeding stage NOT pinned by variant 0 (matching variant: '${best:-none}'): run the product with --seeding-variant ${best:-?} (mq_params.flags bits 8..13; DESIGN.md section 2)"
 
 # ---- step 2: PAF identity
 "$WORK/mapquik/target/release/mapquik" "$READS" --reference "$REF" -p "$WORK/upstream" "$@"
-"$HERE/mapquik_amd/lib/mapquik" "$READS" --reference "$REF" -p "$WORK/hip" "$@"
+# the HIP product runs the reading that step 1 matched (variant 0 when none did: the diff below then shows what the mismatch costs)
+"$HERE/mapquik_amd/lib/mapquik" "$READS" --reference "$REF" -p "$WORK/hip" --seeding-variant "${best:-0}" "$@"
 if cmp -s "$WORK/upstream.paf" "$WORK/hip.paf"; then
   echo "IDENTICAL: $(wc -l < "$WORK/hip.paf") PAF lines"
 else
