@@ -34,6 +34,14 @@ using Clock = std::chrono::steady_clock;
 
 static double secs(Clock::time_point a) { return std::chrono::duration<double>(Clock::now() - a).count(); }
 
+// MQ_DRIVER_TIMING=1 (diagnostic, stderr): where the wall time of a whole job goes -- seconds since main() started at every step of the
+// reference phase, the map phase and the teardown (on a 0.1-s map phase the fixed costs around it are most of the job)
+static const Clock::time_point g_t_main = Clock::now();
+static const bool g_timeline = getenv("MQ_DRIVER_TIMING") != nullptr;
+static void tl(const char *what) {
+    if (g_timeline) fprintf(stderr, "[+%.3f s] %s\n", secs(g_t_main), what);
+}
+
 // `{:?}` of a std::time::Duration
 static std::string rust_duration(double seconds) {
     unsigned long long ns = (unsigned long long)(seconds * 1e9 + 0.5);
@@ -157,6 +165,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         // copied device to device to the other GPUs (mq_index_clone).  The kernels fold soft-masked lower case.
         std::vector<std::unique_ptr<Index>> building(1);
         building[0].reset(new Index(P, dev_of(0)));
+        tl("Index::new returned (HIP runtime up, device chosen)");
         const bool ref_plain = ref_fasta && !ends_with(o.reference, ".gz") && !ends_with(o.reference, ".lz4");
         if (ref_plain && getenv("MQ_DRIVER_NO_RESERVE") == nullptr) {
             // Index::new sizes its map before the first insert (src/index.rs:83: with_capacity(39,821,990), CHM13 at the defaults); here the
@@ -171,8 +180,10 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         if (ref_plain) {
             // an uncompressed FASTA: the whole file read once by all threads, records handed over whole and in order (ref_loader.hpp)
             feeder::RefLoader rl(o.reference, n_parse);
+            tl("reference loader constructed");
             size_t ref_idx = 0;
             rl.for_each([&](const feeder::RefLoader::Record &r, const uint8_t *seq) {
+                if (ref_idx == 0) tl("reference file read, first record ready");
                 if (prefetch) start_feed();  // the whole file has been read by now: the host threads are free
                 const size_t cnt = mers::ref_extract(ref_idx, r.id, seq, r.len, P, *building[0]);
                 printf("Indexed reference %s: %zu k-min-mers.\n", r.id.c_str(), cnt);  // src/closures.rs:58
@@ -209,8 +220,10 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             flush();
         }
         std::vector<std::unique_ptr<ReadOnlyIndex>> ro((size_t)o.gpus);
+        tl("every reference record handed to ref_extract");
         {
             ro[0].reset(new ReadOnlyIndex(std::move(*building[0]).into_read_only()));
+            tl("into_read_only returned (table allocated, k-min-mers inserted)");
             building.clear();
             std::vector<std::string> errs((size_t)o.gpus);
             std::vector<std::thread> th;
@@ -250,6 +263,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                     throw Error(e);
                 }
         }
+        tl("replicas cloned, stream slots and first chunk buffers set up");
         printf("Indexed %llu unique k-min-mers in %s.\n", (unsigned long long)ro[0]->unique_count(), rust_duration(secs(t0)).c_str());
 
         t0 = Clock::now();
@@ -480,7 +494,9 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                             "format %.3f s (%d formatters), write + recycle %.3f s\n", secs(t0), t_submit_us / 1e6, t_finish_us / 1e6, t_fetch_us / 1e6, o.gpus * n_sub,
                     t_format_us / 1e6, n_format, t_write_us / 1e6);
         printf("Mapped query sequences in %s.\n", rust_duration(secs(t0)).c_str());  // src/closures.rs:211
+        tl("PAF written");
         for (auto &v : slots) for (auto c : v) mq_ctx_free(c);
+        tl("stream slots freed");
     return 0;
 }
 
@@ -560,7 +576,9 @@ int main(int argc, char **argv) {
 
     const std::string second_prefix = prefix + "-" + std::to_string(o.k2) + "-" + std::to_string(o.l2) + "-" + rust_float(o.d2);
     try {
+        tl("arguments parsed");
         int rc = run_pass(o, P, o.reads, reads_fasta, ref_fasta, prefix, threads, o.second.empty() ? std::string() : second_prefix + ".fa");
+        tl("run_pass returned (index, feeder and its page-locked pool released)");
         if (rc) return rc;
         if (!o.second.empty()) {
             // the second pass of experiments/chm13/run_chm13_mapquik_unmapped.sh:8-24: the reads the first pass left unmapped,

@@ -42,6 +42,22 @@ with tempfile.TemporaryDirectory(dir=base) as wd:
                 print("      " + ln, flush=True)
 
     NP = {"MQ_DRIVER_NO_PREFETCH": "1"}
+    if os.environ.get("E2E_R5T"):  # round 5: the whole job's timeline (MQ_DRIVER_TIMING), by table factor and thread count
+        def tline(extra, tag, env):
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, rd, "--reference", ref, "-p", os.path.join(wd, "o")] + extra, capture_output=True, text=True, timeout=900,
+                               env=dict(os.environ, MQ_DRIVER_TIMING="1", **env))
+            print("== %s: wall %.3f s rc %d" % (tag, time.perf_counter() - t0, r.returncode), flush=True)
+            for ln in r.stderr.splitlines():
+                print("      " + ln, flush=True)
+            for ln in r.stdout.splitlines():
+                if "unique k-min-mers" in ln or "Mapped query" in ln or "Total execution" in ln:
+                    print("      " + ln, flush=True)
+        tline(["--threads", "4"], "warm-up", {})
+        for extra_env in ({}, {"MQ_TABLE_FACTOR": "4"}, {"MQ_TABLE_FACTOR": "2"}, {"MQ_DRIVER_NO_RESERVE": "1"}):
+            for th in (4, 8):
+                tline(["--threads", str(th)], "FASTA %d threads %s" % (th, extra_env), extra_env)
+        sys.exit(0)
     if os.environ.get("E2E_BGZF"):  # a bgzip'ed FASTA of a quarter of the reads: blocks inflated in parallel by the reader threads
         import struct, zlib
         from concurrent.futures import ThreadPoolExecutor
