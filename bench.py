@@ -47,6 +47,13 @@ def parse():
                     help="weak (default, the BASELINE metric): every rank maps its own HBM-resident batch of --reads reads; strong: ONE fixed "
                          "read set of --reads reads in host memory is dealt to the ranks (mapquik_amd.shard) and mapped through the "
                          "host-buffer stream slots, PCIe included")
+    ap.add_argument("--reference-fasta", default=os.environ.get("MQ_BENCH_REFERENCE") or None,
+                    help="a real reference FASTA (plain or .gz; also MQ_BENCH_REFERENCE), e.g. chm13v2.0.fa (BASELINE config 3, "
+                         "experiments/simulate_chm13.sh:12): indexed instead of the synthetic genome; the JSON says data: real")
+    ap.add_argument("--reads-fastx", default=os.environ.get("MQ_BENCH_READS") or None,
+                    help="real reads, FASTA or FASTQ by the reference's naming rule (src/main.rs:196-205), plain or .gz (also MQ_BENCH_READS), "
+                         "e.g. pbsim2fq output or the DeepConsensus HG002 FASTQ (BASELINE config 4, experiments/table1.sh:50): rank r maps reads "
+                         "r*--reads .. (r+1)*--reads-1 of the file from HBM; without it reads are simulated from the given reference")
     ap.add_argument("--k", type=int, default=5, help="k-min-mer order (BASELINE config 4, experiments/table1.sh:50, runs -k 7)")
     ap.add_argument("--l", type=int, default=31)
     ap.add_argument("--density", type=float, default=0.01)
@@ -323,6 +330,11 @@ def main():
     args = parse()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.reads_fastx and not args.reference_fasta:
+        raise SystemExit("--reads-fastx needs --reference-fasta (reads of another genome would not map)")
+    for pth in (args.reference_fasta, args.reads_fastx):
+        if pth and not os.path.exists(pth):
+            raise SystemExit("no such file: %s" % pth)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # the driver's command shape for N = 1, typed with N > 1
         sys.exit(launch_ranks(args.gpus))
     import torch
@@ -361,14 +373,25 @@ def main():
     threads = max(1, ncpu // world)
     P = mq.Params(k=args.k, l=args.l, density=args.density)  # defaults k=5 l=31 d=0.01, HPC on, c=4 s=11 g=2000 (src/main.rs:174-188)
 
+    # ---- a real reference (and real reads) when given: BASELINE configs 3 / 4 the day the files are on the box
+    real_ref = args.reference_fasta is not None
+    real = None
+    if real_ref:
+        from tools import realdata
+        t0 = time.time()
+        real = realdata.load_reference(args.reference_fasta)
+
+    t0 = time.time() if not real_ref else t0
     # ---- Index::new with its capacity (src/index.rs:78-83): the table is allocated and cleared in the background from here on
-    lens = [max(40, int(x * args.genome_scale)) for x in sim.CHM13_LIKE]
+    lens = [int(x) for x in (real[1][1:] - real[1][:-1])] if real_ref else [max(40, int(x * args.genome_scale)) for x in sim.CHM13_LIKE]
     ix0 = mq.Index(P, device=local_rank)
     ix0.reserve_table(expected_kminmers(sum(lens), P))
 
     # ---- genome (same on every rank: the index is replicated)
-    t0 = time.time()
-    if args.genome_preset == "human-like":
+    if real_ref:
+        genome, ctg_off, ctg_names = real
+        del real
+    elif args.genome_preset == "human-like":
         genome, ctg_off, ctg_names = sim.make_genome(lens, seed=args.seed, threads=threads, **sim.HUMAN_LIKE)
     else:
         genome, ctg_off, ctg_names = sim.make_genome(lens, seed=args.seed, threads=threads, repeat_frac=args.repeat_frac,
@@ -391,7 +414,7 @@ def main():
     # ---- this rank's batch of reads, resident in HBM
     t0 = time.time()
     strong = args.scaling == "strong"
-    if strong:  # the same read set on every rank; this rank's contiguous shard of it
+    if strong and not args.reads_fastx:  # the same read set on every rank; this rank's contiguous shard of it
         from mapquik_amd.shard import shard_bounds
         full = sim.make_reads(genome, ctg_off, args.reads, seed=args.seed + 1000, threads=threads)
         lo, hi = shard_bounds(args.reads, world, rank)
@@ -400,8 +423,26 @@ def main():
         reads["bases"] = full["bases"][int(fo[lo]):int(fo[hi])]
         reads["offsets"] = (fo[lo:hi + 1] - fo[lo]).astype(np.uint64)
         del full
+    elif args.reads_fastx:
+        reads = None
     else:
         reads = sim.make_reads(genome, ctg_off, args.reads, seed=args.seed + 1000 + rank, threads=threads)
+    read_names = None
+    have_truth = True
+    if args.reads_fastx:  # real reads: weak scaling = every rank its own slice of the file; strong = one slice dealt to the ranks
+        from mapquik_amd.shard import shard_bounds
+        skip = 0 if strong else rank * args.reads
+        rr = realdata.load_reads(args.reads_fastx, args.reads, skip=skip)
+        if rr["offsets"].size - 1 == 0:
+            raise SystemExit("%s holds no read for rank %d (reads %d..)" % (args.reads_fastx, rank, skip))
+        if strong:
+            lo, hi = shard_bounds(rr["offsets"].size - 1, world, rank)
+            fo = rr["offsets"]
+            rr = dict(bases=rr["bases"][int(fo[lo]):int(fo[hi])], offsets=(fo[lo:hi + 1] - fo[lo]).astype(np.uint64), names=rr["names"][lo:hi])
+        read_names = rr.pop("names")
+        truth_ = realdata.truth_from_names(read_names, ctg_names)  # pbsim2fq names carry it; real reads do not
+        have_truth = truth_ is not None
+        reads = dict(rr, **(truth_ or {}))
     offs = reads["offsets"]
     n = offs.size - 1
     total_bases = int(offs[-1])
@@ -490,7 +531,7 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("reads") == n and abs(tj.get("genome_scale", -1) - args.genome_scale) < 1e-9:
+            if tj.get("reads") == n and abs(tj.get("genome_scale", -1) - args.genome_scale) < 1e-9 and not real_ref:
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_commit = tj.get("commit")
         except Exception:
@@ -507,7 +548,7 @@ def main():
     if os.path.exists(ipath):
         try:
             ij = json.load(open(ipath))
-            if ij.get("reads") == n and abs(ij.get("genome_scale", -1) - args.genome_scale) < 1e-9 and ij.get("k") == args.k and not strong:
+            if ij.get("reads") == n and abs(ij.get("genome_scale", -1) - args.genome_scale) < 1e-9 and ij.get("k") == args.k and not strong and not real_ref:
                 n_simd = int(ij["n_simd"])
                 # cycles: the launch's busy cycles as the counters gave them (GRBM_GUI_ACTIVE / 8 XCDs) -- a property of the kernel on this
                 # workload; this run's launch time only says what shader clock that implies here (the clock moves with the power state:
@@ -530,11 +571,14 @@ def main():
             roofline["secondary"] = {"error": repr(ex)[:200]}
 
     # ---- accuracy on the whole batch (BASELINE metric: "Q60 mapeval parity"): paftools-mapeval-style counts
-    truth = {k: v for k, v in reads.items() if k not in ("bases", "offsets")}
-    pafs = {"mapped": (hits["status"] == 1).astype(np.uint32)}
-    for a_ in ("ref_id", "rc", "mapq", "r_start", "r_end"):
-        pafs[a_] = hits[a_]
-    n_m, n_q60, n_q60_wrong = sim.mapeval(truth, pafs)
+    if have_truth:
+        truth = {k: v for k, v in reads.items() if k not in ("bases", "offsets")}
+        pafs = {"mapped": (hits["status"] == 1).astype(np.uint32)}
+        for a_ in ("ref_id", "rc", "mapq", "r_start", "r_end"):
+            pafs[a_] = hits[a_]
+        n_m, n_q60, n_q60_wrong = sim.mapeval(truth, pafs)
+    else:  # real reads: no truth in the names -- truth-free counts only (the reference's Table 1 reports the same two for HG002)
+        n_m, n_q60, n_q60_wrong = n_mapped, int(((hits["status"] == 1) & (hits["mapq"] == 60)).sum()), None
 
     # ---- CPU baseline: the C oracle ("port") on a bounded sample of the same reads, rank 0 at N=1 only
     cpu = None
@@ -585,7 +629,7 @@ def main():
     # ---- kernel-only legs of the other configurations (rank 0, N=1): a human-like repeat landscape, a maize-like repetitive genome
     # (BASELINE config 5, experiments/simulate_maize.sh:9) and -k 7 (BASELINE config 4, experiments/table1.sh:50)
     configs = None
-    if rank == 0 and world == 1 and not args.no_configs and not strong:
+    if rank == 0 and world == 1 and not args.no_configs and not strong and not real_ref:  # (synthetic stand-ins of the other configurations)
         from oracle import oracle as O
         configs = {}
         nr = args.config_reads or args.reads
@@ -677,7 +721,8 @@ def main():
     if rank == 0:
         value = all_bases * args.steps / elapsed / 1e9
         line = {
-            "metric": "Gbases/s mapped (sim CHM13v2-like HiFi, k=%d l=%d d=%g)" % (args.k, args.l, args.density),
+            "metric": ("Gbases/s mapped (%s, k=%d l=%d d=%g)" % ("real reference" + (" + real reads" if args.reads_fastx else ", simulated HiFi reads"), args.k, args.l, args.density))
+                      if real_ref else "Gbases/s mapped (sim CHM13v2-like HiFi, k=%d l=%d d=%g)" % (args.k, args.l, args.density),
             "value": round(value, 3),
             "unit": "Gbases/s",
             "n_gpus": world,
@@ -688,10 +733,16 @@ def main():
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u64",
-            "data": "synthetic",
+            "data": ("real" if args.reads_fastx else "real reference, simulated reads") if real_ref else "synthetic",
             "config": {
-                "genome_preset": args.genome_preset,
-                "workload": "CHM13v2.0-like synthetic genome (25 contigs, %.3f Gbp, scale %.3g, %s) "
+                "genome_preset": "real" if real_ref else args.genome_preset,
+                "workload": ("reference %s (%d contigs, %.3f Gbp) x %s; k=%d l=%d d=%g HPC"
+                             % (realdata.describe(args.reference_fasta), len(lens), sum(lens) / 1e9,
+                                ("reads %s, %d per rank from read %d on%s" % (realdata.describe(args.reads_fastx), n, 0 if strong else rank * args.reads,
+                                                                             "" if have_truth else " (no truth in the read names: q60_wrong is null)"))
+                                if args.reads_fastx else "pbsim-like HiFi reads simulated from it (mean 24 kb, 1% error)", args.k, args.l, args.density))
+                            if real_ref else
+                            "CHM13v2.0-like synthetic genome (25 contigs, %.3f Gbp, scale %.3g, %s) "
                             "x pbsim-like HiFi reads (mean 24 kb, 1%% error); k=%d l=%d d=%g HPC"
                             % (sum(lens) / 1e9, args.genome_scale,
                                "human-like repeats: 6% satellite arrays, 5% segmental duplications, young interspersed copies" if args.genome_preset == "human-like"

@@ -136,6 +136,21 @@ void mq_index_free(mq_index *idx);
 int64_t mq_index_add_ref(mq_index *idx, uint32_t ref_id, const char *name, const uint8_t *seq, uint64_t len);
 int64_t mq_index_add_ref_device(mq_index *idx, uint32_t ref_id, const char *name, const uint8_t *d_seq, uint64_t len);
 
+/* The reference file handed over in pieces (the batch form of the reader loop of src/closures.rs:46-94 for a caller that never holds a
+ * whole record in host memory): the file's bytes go to a device buffer of the index piece by piece, asynchronously, and a record is
+ * indexed from there while the pieces behind it are still on their way.
+ *   mq_index_stage_begin(idx, total_bytes)       the device buffer, total_bytes = the file's size; once per index, before the first piece
+ *   mq_index_stage_piece(idx, at, src, n, &t)    queues the copy of src[0, n) to buffer offset `at` and returns; src (page-locked memory,
+ *                                                mq_host_alloc, for the link's full rate) must stay untouched until
+ *   mq_index_stage_done(idx, t, wait)            returns 1 (copied; src may be reused), 0 (not yet; only with wait == 0) or <0
+ *   mq_index_add_ref_staged(idx, id, name, at, len)  = mq_index_add_ref_device on buffer[at, at + len), ordered behind every piece issued
+ *                                                so far (the caller issues a record's pieces before it asks for the record)
+ * Pieces may be issued from one thread while another asks for records.  The buffer is released by mq_index_finalize. */
+int mq_index_stage_begin(mq_index *idx, uint64_t total_bytes);
+int mq_index_stage_piece(mq_index *idx, uint64_t at, const uint8_t *src, uint64_t n, uint64_t *ticket);
+int mq_index_stage_done(mq_index *idx, uint64_t ticket, int wait);
+int64_t mq_index_add_ref_staged(mq_index *idx, uint32_t ref_id, const char *name, uint64_t at, uint64_t len);
+
 /* DashMap::with_capacity (src/index.rs:83 sizes its map for 39,821,990 k-min-mers at Index::new): a hint that about
  * expected_kminmers k-min-mers will be inserted.  The table is allocated and cleared in the background while the references are
  * added; mq_index_finalize adopts it when the size fits and allocates anew when it does not.  Fresh device memory costs ~30 ms per GB
@@ -153,6 +168,11 @@ mq_index *mq_index_load(const char *path, int device);
  * index once and clone it instead of indexing the reference on every GPU).  Free it with mq_index_free. */
 mq_index *mq_index_clone(const mq_index *src, int device);
 int mq_index_ref_info(const mq_index *idx, uint32_t ref_id, const char **name, uint64_t *len);
+/* The parameters an index was built with (a loaded file's k, l, density, use_hpc and seeding variant decide its keys), and the ones that
+ * act at mapping time only -- Params.c / .s (Chain::get_match, src/chain.rs:147-169), .g (the gap tests, src/chain.rs:132-142) and the
+ * case folding -- which a loaded index takes from its caller's command line. */
+int mq_index_get_params(const mq_index *idx, mq_params *out);
+int mq_index_set_map_params(mq_index *idx, uint32_t c, uint32_t s, uint32_t g, int fold_case);
 
 /* find_matches (src/mers.rs:77-102) for n reads.  bases: concatenated reads; offsets: n+1 prefix offsets.
  * Host-buffer form: copies in, runs, copies out, synchronises.  Reads that overflow the per-wave Match scratch or whose

@@ -30,7 +30,7 @@ def hit_column(hits, name):
     return v
 
 # every symbol include/mapquik_hip.h (the seam) and include/mapquik_hip_diag.h (measurement / diagnostics) declare
-EXPORTS = ["mq_ctx_submit_fasta", "mq_ctx_wait_fasta", "mq_index_reserve", "mq_host_register", "mq_host_unregister",
+EXPORTS = ["mq_index_get_params", "mq_index_set_map_params", "mq_index_stage_begin", "mq_index_stage_piece", "mq_index_stage_done", "mq_index_add_ref_staged", "mq_ctx_submit_fasta", "mq_ctx_wait_fasta", "mq_index_reserve", "mq_host_register", "mq_host_unregister",
            "mq_last_error", "mq_abi_version", "mq_device_count", "mq_params_default", "mq_index_new", "mq_index_free",
            "mq_index_add_ref", "mq_index_add_ref_device", "mq_index_finalize", "mq_index_get_stats", "mq_index_ref_info",
            "mq_map_batch", "mq_map_batch_device", "mq_map_reserve", "mq_kminmers_batch", "mq_index_lookup", "mq_format_paf",
@@ -114,6 +114,14 @@ def load_library(path=None):
         raise MapquikError("%s has ABI version %d, this binding is for %d: rebuild (python __graft_entry__.py)" % (p, abi, MQ_ABI_VERSION))
     if abi >= 4 or hasattr(L, "mq_ctx_submit_fasta"):  # (an older build given by MQ_LIB / path for an A/B run may lack them)
         L.mq_index_reserve.argtypes = [vp, u64]
+    if abi >= 4 and hasattr(L, "mq_index_stage_begin"):
+        L.mq_index_get_params.argtypes = [vp, C.POINTER(Params)]
+        L.mq_index_set_map_params.argtypes = [vp, u32, u32, u32, C.c_int]
+        L.mq_index_stage_begin.argtypes = [vp, u64]
+        L.mq_index_stage_piece.argtypes = [vp, u64, vp, u64, C.POINTER(u64)]
+        L.mq_index_stage_done.argtypes = [vp, u64, C.c_int]
+        L.mq_index_add_ref_staged.restype = C.c_int64
+        L.mq_index_add_ref_staged.argtypes = [vp, u32, C.c_char_p, u64, u64]
         L.mq_host_register.argtypes = [vp, C.c_size_t]
         L.mq_host_unregister.argtypes = [vp]
         L.mq_ctx_submit_fasta.argtypes = [vp, vp, u64, u64]
@@ -197,8 +205,8 @@ class Index:
 
     @classmethod
     def load(cls, path, device=0):
-        """A finalized index read back from Index.save; the parameters stored in the file are not exposed here,
-        pass the same Params you built it with if you need them on the Python side."""
+        """A finalized index read back from Index.save (its parameters: Index.params(); the mapping-time ones can be replaced with
+        Index.set_map_params)."""
         L = load_library()
         h = L.mq_index_load(os.fsencode(path), device)
         if not h:
@@ -235,6 +243,45 @@ class Index:
         n = self._L.mq_index_add_ref_device(self._h, ref_idx, name.encode(), C.c_void_p(d_ptr), length)
         if n < 0:
             raise _err(self._L, "mq_index_add_ref_device")
+        return n
+
+    def params(self):
+        """The parameters the index was built with (a loaded file's own)."""
+        p = Params()
+        if self._L.mq_index_get_params(self._h, C.byref(p)) != 0:
+            raise _err(self._L, "mq_index_get_params")
+        return p
+
+    def set_map_params(self, c, s, g, fold_case=False):
+        """Params.c / .s / .g (src/chain.rs:132-169) and the case folding act at mapping time only: a loaded index takes the caller's."""
+        if self._L.mq_index_set_map_params(self._h, int(c), int(s), int(g), 1 if fold_case else 0) != 0:
+            raise _err(self._L, "mq_index_set_map_params")
+
+    def stage_begin(self, total_bytes):
+        """The reference file in pieces (mq_index_stage_*): a device buffer of the file's size."""
+        if self._L.mq_index_stage_begin(self._h, int(total_bytes)) != 0:
+            raise _err(self._L, "mq_index_stage_begin")
+
+    def stage_piece(self, at, piece):
+        """Queues the copy of `piece` (uint8 array; page-locked for the full rate) to buffer offset `at`; returns the ticket."""
+        s = _seq(piece)
+        t = C.c_uint64()
+        if self._L.mq_index_stage_piece(self._h, int(at), _p(s), s.size, C.byref(t)) != 0:
+            raise _err(self._L, "mq_index_stage_piece")
+        self._staged = getattr(self, "_staged", [])
+        self._staged.append(s)  # the source stays alive until the index is finalized
+        return t.value
+
+    def stage_done(self, ticket, wait=True):
+        r = self._L.mq_index_stage_done(self._h, int(ticket), 1 if wait else 0)
+        if r < 0:
+            raise _err(self._L, "mq_index_stage_done")
+        return bool(r)
+
+    def add_ref_staged(self, ref_idx, name, at, length):
+        n = self._L.mq_index_add_ref_staged(self._h, ref_idx, name.encode(), int(at), int(length))
+        if n < 0:
+            raise _err(self._L, "mq_index_add_ref_staged")
         return n
 
     def reserve_table(self, expected_kminmers):

@@ -99,6 +99,10 @@ def build_parser():
     ap.add_argument("-q", type=int)
     ap.add_argument("--device", type=int, default=0, help="HIP device ordinal (extension)")
     ap.add_argument("--batch-bases", type=int, default=1 << 30, help="bases per GPU batch (extension)")
+    ap.add_argument("--save-index", dest="save_index", help="write the finalized index (occupied slots only) for later runs (extension: the "
+                    "reference re-indexes the FASTA on every run, src/closures.rs:24-94)")
+    ap.add_argument("--index", dest="load_index", help="map against a saved index instead of indexing --reference; same -k -l -d --nohpc as it was "
+                    "built with (extension)")
     ap.add_argument("--seeding-variant", type=int, default=0, dest="seeding_variant",
                     help="reading of the k-min-mer iterator's unpinned decisions, bits 1 2 4 8 16 32 (include/mapquik_hip.h); 0 = the frozen "
                          "reading (extension; tools/check_against_upstream.sh finds the value that reproduces the crate)")
@@ -113,10 +117,10 @@ def banner_lines(opt):
     out = []
     k, l, c, s, g, b, q, density, threads = 5, 31, 4, 11, 2000, 1, 200, 0.01, 8
     reads_fasta = is_fasta_name(opt.reads)
-    ref_fasta = is_fasta_name(opt.reference)
+    ref_fasta = is_fasta_name(opt.reference) if opt.reference else False
     if reads_fasta:
         out += ["Input file: %s" % opt.reads, "Format: FASTA"]
-    if ref_fasta:
+    if ref_fasta and not getattr(opt, "load_index", None):
         out += ["Reference file: %s" % opt.reference, "Format: FASTA"]
     if opt.k is not None: k = opt.k
     else: out.append("Warning: Using default k value (%d)." % k)
@@ -153,8 +157,10 @@ def main(argv=None):
     opt = build_parser().parse_args(argv)
     if not opt.reads:
         raise SystemExit("Please specify an input file.")
-    if not opt.reference:
+    if not opt.reference and not opt.load_index:
         raise SystemExit("Please specify a reference file.")
+    if opt.load_index and opt.save_index:
+        raise SystemExit("error: --index cannot be combined with --save-index")
     lines, st = banner_lines(opt)
     for ln in lines:
         print(ln)
@@ -162,15 +168,30 @@ def main(argv=None):
         print("Seeding variant %d (reading of rust-seq2kminmers other than the frozen one; include/mapquik_hip.h)." % opt.seeding_variant)
     params = api.Params(k=st["k"], l=st["l"], density=st["density"], use_hpc=st["use_hpc"], c=st["c"], s=st["s"], g=st["g"],
                         seeding_variant=opt.seeding_variant)
-    index = api.Index(params, device=opt.device)
     paf = open(st["prefix"] + ".paf", "w")  # src/closures.rs:32
     unm = open(st["prefix"] + ".unmapped.out", "w") if opt.unmapped else None
 
     t0 = time.time()
-    for ref_idx, (name, seq) in enumerate(read_fastx(opt.reference, st["ref_fasta"])):
-        n = index.add_ref(ref_idx, name, np.frombuffer(seq, dtype=np.uint8))
-        print("Indexed reference %s: %d k-min-mers." % (name, n))  # src/closures.rs:58
-    unique = index.finalize()
+    if opt.load_index:
+        index = api.Index.load(opt.load_index, device=opt.device)
+        fp = index.params()
+        if (fp.k, fp.l, fp.density, fp.use_hpc, fp.seeding_variant) != (params.k, params.l, params.density, params.use_hpc, params.seeding_variant):
+            raise SystemExit("%s was built with -k %d -l %d -d %s%s --seeding-variant %d: run with the same seeding parameters"
+                             % (opt.load_index, fp.k, fp.l, rust_float(fp.density), "" if fp.use_hpc else " --nohpc", fp.seeding_variant))
+        index.set_map_params(params.c, params.s, params.g, bool(params.flags & api.MQ_FLAG_FOLD_CASE))
+        ist = index.stats()
+        print("Loaded index %s: %d references, %d k-min-mers." % (opt.load_index, ist["n_refs"], ist["n_kminmers"]))
+        unique = ist["n_unique"]
+    else:
+        index = api.Index(params, device=opt.device)
+        for ref_idx, (name, seq) in enumerate(read_fastx(opt.reference, st["ref_fasta"])):
+            n = index.add_ref(ref_idx, name, np.frombuffer(seq, dtype=np.uint8))
+            print("Indexed reference %s: %d k-min-mers." % (name, n))  # src/closures.rs:58
+        unique = index.finalize()
+        if opt.save_index:
+            ts = time.time()
+            index.save(opt.save_index)
+            print("Saved index to %s in %s." % (opt.save_index, rust_duration(time.time() - ts)))
     print("Indexed %d unique k-min-mers in %s." % (unique, rust_duration(time.time() - t0)))  # src/closures.rs:92
 
     t0 = time.time()

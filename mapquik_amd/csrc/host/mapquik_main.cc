@@ -100,6 +100,7 @@ struct Opt {
     int device = 0;
     int gpus = 1;
     int seeding_variant = 0;  // MQ_SEEDVAR_* bits (include/mapquik_hip.h)
+    std::string save_index, load_index;  // --save-index / --index: the on-disk index (the reference has none and re-indexes on every run)
     std::string second;  // "k2,l2,d2"
     long k2 = 0, l2 = 0;
     double d2 = 0;
@@ -113,7 +114,7 @@ static void usage() {
          "        --parallelfastx\n        --unmapped      (extension) also write <prefix>.unmapped.out\n\nOPTIONS:\n"
          "    -b <b>\n    -c, --chain <chain>\n    -d, --density <density>\n    -g, --gap-diff <gap-diff>\n    -k <k>\n    -l <l>\n"
          "    -p, --prefix <prefix>\n    -q <q>\n        --reference <reference>\n    -s, --seed <seed>\n        --threads <threads>\n"
-         "        --device <n>    (extension) first HIP device ordinal\n        --gpus <n>      (extension) shard read batches over n GPUs, index replicated\n        --batch-bases <n> (extension) raw input bytes per chunk\n        --seeding-variant <v> (extension) reading of the k-min-mer iterator's unpinned decisions, bits 1 2 4 8 16 32 (include/mapquik_hip.h); 0 = frozen\n        --second-pass <k2,l2,d2> (extension) map the unmapped reads again with these parameters: <prefix>-k2-l2-d2.{fa,paf,unmapped.out}\n\nARGS:\n    <reads>");
+         "        --device <n>    (extension) first HIP device ordinal\n        --gpus <n>      (extension) shard read batches over n GPUs, index replicated\n        --batch-bases <n> (extension) raw input bytes per chunk\n        --save-index <file> (extension) write the finalized index (occupied slots only) for later runs\n        --index <file>  (extension) map against a saved index instead of indexing --reference (same -k -l -d --nohpc as it was built with)\n        --seeding-variant <v> (extension) reading of the k-min-mer iterator's unpinned decisions, bits 1 2 4 8 16 32 (include/mapquik_hip.h); 0 = frozen\n        --second-pass <k2,l2,d2> (extension) map the unmapped reads again with these parameters: <prefix>-k2-l2-d2.{fa,paf,unmapped.out}\n\nARGS:\n    <reads>");
 }
 
 // One run of the reference's flow (src/closures.rs:22-212): index the reference, map the reads, write <prefix>.paf in input
@@ -164,10 +165,52 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         // index_mers (src/closures.rs:46-51) per reference record, in file order, on the first GPU; the finalized table is then
         // copied device to device to the other GPUs (mq_index_clone).  The kernels fold soft-masked lower case.
         std::vector<std::unique_ptr<Index>> building(1);
-        building[0].reset(new Index(P, dev_of(0)));
-        tl("Index::new returned (HIP runtime up, device chosen)");
+        if (o.load_index.empty()) {
+            building[0].reset(new Index(P, dev_of(0)));
+            tl("Index::new returned (HIP runtime up, device chosen)");
+        }
         const bool ref_plain = ref_fasta && !ends_with(o.reference, ".gz") && !ends_with(o.reference, ".lz4");
-        if (ref_plain && getenv("MQ_DRIVER_NO_RESERVE") == nullptr) {
+        // The stream slots of the map phase (device staging, minimizer lists, Match scratch: a few hundred MB of device memory per
+        // submitting thread) and the feeder's first page-locked chunk buffers depend on neither the reference nor the reads: the first
+        // GPU's are set up by a thread of its own BESIDE the reference phase (0.03-0.04 s of a 0.1-s phase when they came after it).
+        const int n_sub = feed.mapped_views() ? 2 : 1;  // submitting threads per GPU (see below)
+        std::vector<std::vector<mq_ctx *>> slots((size_t)(o.gpus * n_sub), std::vector<mq_ctx *>((size_t)n_slots, nullptr));
+        auto make_slots = [&](size_t gw, mq_index *h) -> std::string {
+            for (int sl = 0; sl < n_slots; ++sl) {
+                if (slots[gw][sl]) continue;
+                slots[gw][sl] = mq_ctx_new(h);
+                if (!slots[gw][sl]) return std::string("mq_ctx_new: ") + last_error();
+                const uint64_t cb = std::min<uint64_t>(o.batch_bases + o.batch_bases / 8 + (1u << 20), feed.bytes_in() + 64);
+                if (mq_ctx_reserve(slots[gw][sl], (uint32_t)std::min<uint64_t>(cb / 16000 + 512, 1u << 24), cb) != MQ_OK)  // (sized for long reads; a chunk of short reads makes its slot grow once)
+                    return std::string("mq_ctx_reserve: ") + last_error();
+            }
+            return std::string();
+        };
+        std::thread early;
+        std::string early_err;
+        bool pool_ready = false;
+        auto early_join = [&]() {
+            if (early.joinable()) early.join();
+        };
+        auto early_start = [&]() {
+            if (getenv("MQ_DRIVER_LATE_SLOTS") != nullptr) return;  // (diagnostic: everything after the reference phase, as in earlier rounds)
+            mq_index *h = building[0]->handle();
+            early = std::thread([&, h]() {
+                for (int w = 0; w < n_sub && early_err.empty(); ++w) early_err = make_slots((size_t)w, h);
+                if (!prefetch && early_err.empty()) {
+                    try {
+                        feed.preallocate(n_parse + n_slots);
+                        pool_ready = true;
+                    } catch (const std::exception &e) { early_err = e.what(); }
+                }
+            });
+        };
+        struct EarlyGuard {  // an exception on the way: the thread is joined before its captures go away
+            std::thread &t;
+            ~EarlyGuard() { if (t.joinable()) t.join(); }
+        } early_guard{early};
+        auto reserve_table = [&]() {
+            if (!ref_plain || getenv("MQ_DRIVER_NO_RESERVE") != nullptr) return;
             // Index::new sizes its map before the first insert (src/index.rs:83: with_capacity(39,821,990), CHM13 at the defaults); here the
             // expected count follows from the reference's size: canonical selection keeps 1 - (1 - d)^2 of the l-mers, homopolymer
             // compression about three quarters of the bases.  The table is allocated in the background while the reference is read and seeded.
@@ -176,8 +219,81 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                 const double d = std::min(1.0, std::max(0.0, P.density));
                 building[0]->with_capacity((uint64_t)((double)rst.st_size * (1.0 - (1.0 - d) * (1.0 - d)) * (P.use_hpc ? 0.75 : 1.0)) + 1);
             }
+        };
+        bool ref_done = false;
+        std::unique_ptr<ReadOnlyIndex> loaded;
+        if (!o.load_index.empty()) {
+            // --index: the finalized table from a file written by --save-index (occupied slots only; validated against its header on load)
+            building.clear();
+            loaded.reset(new ReadOnlyIndex(ReadOnlyIndex::load(o.load_index, dev_of(0))));
+            mq_params fp;
+            if (mq_index_get_params(loaded->handle(), &fp) != MQ_OK) throw Error("mq_index_get_params: " + last_error());
+            const mq_params want = P.to_abi();
+            if (fp.k != want.k || fp.l != want.l || fp.density != want.density || fp.use_hpc != want.use_hpc ||
+                (fp.flags & MQ_FLAG_SEED_VARIANT_MASK) != (want.flags & MQ_FLAG_SEED_VARIANT_MASK)) {
+                char msg[512];
+                snprintf(msg, sizeof(msg), "%s was built with -k %u -l %u -d %s%s --seeding-variant %u: run with the same seeding parameters (this run: -k %u -l %u -d %s%s --seeding-variant %u)",
+                         o.load_index.c_str(), fp.k, fp.l, rust_float(fp.density).c_str(), fp.use_hpc ? "" : " --nohpc", (fp.flags & MQ_FLAG_SEED_VARIANT_MASK) >> MQ_FLAG_SEED_VARIANT_SHIFT,
+                         want.k, want.l, rust_float(want.density).c_str(), want.use_hpc ? "" : " --nohpc", (want.flags & MQ_FLAG_SEED_VARIANT_MASK) >> MQ_FLAG_SEED_VARIANT_SHIFT);
+                throw Error(msg);
+            }
+            // the chaining thresholds and the case folding are this run's (they act at mapping time only)
+            if (mq_index_set_map_params(loaded->handle(), want.c, want.s, want.g, (want.flags & MQ_FLAG_FOLD_CASE) ? 1 : 0) != MQ_OK) throw Error("mq_index_set_map_params: " + last_error());
+            mq_index_stats st;
+            mq_index_get_stats(loaded->handle(), &st);
+            printf("Loaded index %s: %llu references, %llu k-min-mers.\n", o.load_index.c_str(), (unsigned long long)st.n_refs, (unsigned long long)st.n_kminmers);
+            ref_done = true;
+            tl("index file loaded");
+        } else {
+            reserve_table();
+            early_start();
         }
-        if (ref_plain) {
+        if (!ref_done && ref_plain && getenv("MQ_DRIVER_REF_HOST") == nullptr) {
+            // an uncompressed FASTA of one sequence line per record (what assemblers and this repository's tools write): streamed to the
+            // device block by block as it is read, records indexed while the blocks behind them are still on the link (RefStreamer);
+            // the host reads the header lines only.  Any other shape: the loader below.
+            feeder::RefStreamer::Hooks hooks;
+            hooks.alloc = [](size_t n) { return mq_host_alloc(n); };
+            hooks.release = [](void *q) { mq_host_free(q); };
+            mq_index *h = building[0]->handle();
+            hooks.piece = [h](uint64_t at, const uint8_t *src, uint64_t n) {
+                uint64_t t = 0;
+                if (mq_index_stage_piece(h, at, src, n, &t) != MQ_OK) throw Error("mq_index_stage_piece: " + last_error());
+                return t;
+            };
+            hooks.done = [h](uint64_t t, bool wait) {
+                const int r = mq_index_stage_done(h, t, wait ? 1 : 0);
+                if (r < 0) throw Error("mq_index_stage_done: " + last_error());
+                return r == 1;
+            };
+            feeder::RefStreamer rs(o.reference, n_parse, hooks);
+            if (mq_index_stage_begin(h, rs.file_bytes()) != MQ_OK) throw Error("mq_index_stage_begin: " + last_error());
+            tl("reference streamer constructed, staging buffer allocated");
+            std::vector<std::string> lines;  // printed once the file's shape is known to be regular (else the loader below prints its own)
+            const feeder::RefStreamer::Result res = rs.run([&](size_t k, const std::string &id, uint64_t at, uint64_t len) {
+                const int64_t cnt = mq_index_add_ref_staged(h, (uint32_t)k, id.c_str(), at, len);  // index_mers, src/closures.rs:46-51
+                if (cnt < 0) throw Error("ref_extract: " + last_error());
+                lines.push_back("Indexed reference " + id + ": " + std::to_string(cnt) + " k-min-mers.");  // src/closures.rs:58
+            });
+            if (!res.irregular) {
+                for (const std::string &ln : lines) puts(ln.c_str());
+                ref_done = true;
+                tl("reference streamed: every record handed to ref_extract");
+            } else {
+                // not one sequence line per record (a line-wrapped FASTA shows in its first block, before anything was indexed): an index
+                // that took records already is dropped, and the file goes through the loader below
+                if (res.handed > 0) {  // (an index that has seen nothing stays: its table is being allocated in the background already)
+                    early_join();      // the slots set up so far belong to the index that goes away
+                    for (auto &v : slots) for (auto &c : v) { mq_ctx_free(c); c = nullptr; }
+                    building[0].reset();
+                    building[0].reset(new Index(P, dev_of(0)));
+                    reserve_table();
+                }
+                tl("reference is not one line per record: host loader");
+            }
+        }
+        if (ref_done) {
+        } else if (ref_plain) {
             // an uncompressed FASTA: the whole file read once by all threads, records handed over whole and in order (ref_loader.hpp)
             feeder::RefLoader rl(o.reference, n_parse);
             tl("reference loader constructed");
@@ -222,9 +338,18 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         std::vector<std::unique_ptr<ReadOnlyIndex>> ro((size_t)o.gpus);
         tl("every reference record handed to ref_extract");
         {
-            ro[0].reset(new ReadOnlyIndex(std::move(*building[0]).into_read_only()));
-            tl("into_read_only returned (table allocated, k-min-mers inserted)");
-            building.clear();
+            if (loaded) {
+                ro[0] = std::move(loaded);
+            } else {
+                ro[0].reset(new ReadOnlyIndex(std::move(*building[0]).into_read_only()));
+                tl("into_read_only returned (table allocated, k-min-mers inserted)");
+                building.clear();
+            }
+            if (!o.save_index.empty()) {
+                const auto ts = Clock::now();
+                ro[0]->save(o.save_index);
+                printf("Saved index to %s in %s.\n", o.save_index.c_str(), rust_duration(secs(ts)).c_str());
+            }
             std::vector<std::string> errs((size_t)o.gpus);
             std::vector<std::thread> th;
             for (int g = 1; g < o.gpus; ++g)
@@ -236,26 +361,19 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             for (auto &t : th) t.join();
             for (auto &e : errs) if (!e.empty()) throw Error(e);
         }
-        // The stream slots of the map phase (device staging, minimizer lists, Match scratch: a few hundred MB of device memory per
-        // submitting thread) are set up here, at the end of the reference phase: none of it depends on the reads.
-        const int n_sub = feed.mapped_views() ? 2 : 1;  // submitting threads per GPU (see below)
-        std::vector<std::vector<mq_ctx *>> slots((size_t)(o.gpus * n_sub), std::vector<mq_ctx *>((size_t)n_slots, nullptr));
+        // The stream slots of the other GPUs (the first GPU's were set up beside the reference phase) and whatever of the first GPU's
+        // is still missing.
+        early_join();
+        if (!early_err.empty()) {
+            for (auto &v : slots) for (auto c : v) mq_ctx_free(c);
+            throw Error(early_err);
+        }
         {
             std::vector<std::string> errs(slots.size());
             std::vector<std::thread> th;
             for (size_t gw = 0; gw < slots.size(); ++gw)
-                th.emplace_back([&, gw]() {
-                    for (int sl = 0; sl < n_slots; ++sl) {
-                        slots[gw][sl] = mq_ctx_new(ro[gw / (size_t)n_sub]->handle());
-                        if (!slots[gw][sl]) { errs[gw] = std::string("mq_ctx_new: ") + last_error(); return; }
-                        const uint64_t cb = std::min<uint64_t>(o.batch_bases + o.batch_bases / 8 + (1u << 20), feed.bytes_in() + 64);
-                        if (mq_ctx_reserve(slots[gw][sl], (uint32_t)std::min<uint64_t>(cb / 16000 + 512, 1u << 24), cb) != MQ_OK) {  // (sized for long reads; a chunk of short reads makes its slot grow once)
-                            errs[gw] = std::string("mq_ctx_reserve: ") + last_error();
-                            return;
-                        }
-                    }
-                });
-            if (!prefetch) th.emplace_back([&]() { feed.preallocate(n_parse + n_slots); });  // and the first page-locked chunk buffers
+                if (!slots[gw][(size_t)n_slots - 1]) th.emplace_back([&, gw]() { errs[gw] = make_slots(gw, ro[gw / (size_t)n_sub]->handle()); });
+            if (!prefetch && !pool_ready) th.emplace_back([&]() { feed.preallocate(n_parse + n_slots); });  // and the first page-locked chunk buffers
             for (auto &t : th) t.join();
             for (auto &e : errs)
                 if (!e.empty()) {
@@ -530,6 +648,8 @@ int main(int argc, char **argv) {
         else if (a == "--device") o.device = atoi(val());
         else if (a == "--gpus") o.gpus = std::max(1, atoi(val()));
         else if (a == "--batch-bases") o.batch_bases = strtoull(val(), nullptr, 10);
+        else if (a == "--save-index") o.save_index = val();
+        else if (a == "--index") o.load_index = val();
         else if (a == "--seeding-variant") {
             o.seeding_variant = atoi(val());
             if (o.seeding_variant < 0 || o.seeding_variant > 63) { fprintf(stderr, "error: --seeding-variant wants 0..63 (bits 1 2 4 8 16 32)\n"); return 2; }
@@ -546,13 +666,17 @@ int main(int argc, char **argv) {
         else o.reads = a;
     }
     if (o.reads.empty()) { fprintf(stderr, "Please specify an input file.\n"); return 101; }          // panic!, src/main.rs:191
-    if (o.reference.empty()) { fprintf(stderr, "Please specify a reference file.\n"); return 101; }   // src/main.rs:192
+    if (o.reference.empty() && o.load_index.empty()) { fprintf(stderr, "Please specify a reference file.\n"); return 101; }   // src/main.rs:192
+    if (!o.load_index.empty() && (!o.save_index.empty() || !o.second.empty())) {
+        fprintf(stderr, "error: --index cannot be combined with --save-index or --second-pass (a second pass builds its own index)\n");
+        return 2;
+    }
 
     Params P;
     size_t threads = 8;
     const bool reads_fasta = is_fasta_name(o.reads), ref_fasta = is_fasta_name(o.reference);
     if (reads_fasta) printf("Input file: %s\nFormat: FASTA\n", o.reads.c_str());
-    if (ref_fasta) printf("Reference file: %s\nFormat: FASTA\n", o.reference.c_str());
+    if (ref_fasta && o.load_index.empty()) printf("Reference file: %s\nFormat: FASTA\n", o.reference.c_str());
     if (o.k >= 0) P.k = (size_t)o.k; else printf("Warning: Using default k value (%zu).\n", P.k);
     if (o.l >= 0) P.l = (size_t)o.l; else printf("Warning: Using default l value (%zu).\n", P.l);
     if (o.b >= 0) P.b = (size_t)o.b; else printf("Warning: Using default buffer size (%zuX).\n", P.b);

@@ -287,6 +287,34 @@ mq_index *mq_index_clone(const mq_index *src, int device) try {
     return nullptr;
 }
 
+// The parameters an index was built with (what a loaded file says: k, l, density, use_hpc and the seeding variant decide its keys).
+int mq_index_get_params(const mq_index *idx, mq_params *out) try {
+    if (!idx || !out) return set_err(MQ_EINVAL, "bad arguments");
+    *out = idx->params;
+    return MQ_OK;
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+}
+
+// The parameters that act at mapping time only (Params.c / .s in Chain::get_match src/chain.rs:147-169, .g in the gap tests
+// src/chain.rs:132-142, and the feeder's case folding): a loaded index takes the command line's.  Launches queued before the call keep
+// the old values.
+int mq_index_set_map_params(mq_index *idx, uint32_t c, uint32_t s, uint32_t g, int fold_case) try {
+    if (!idx) return set_err(MQ_EINVAL, "idx is NULL");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    idx->params.c = c;
+    idx->params.s = s;
+    idx->params.g = g;
+    idx->params.flags = (idx->params.flags & ~MQ_FLAG_FOLD_CASE) | (fold_case ? MQ_FLAG_FOLD_CASE : 0u);
+    idx->dp.c = c;
+    idx->dp.s = s;
+    idx->dp.g = g;
+    idx->dp.fold = fold_case ? 1u : 0u;
+    return MQ_OK;
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+}
+
 int mq_index_ref_info(const mq_index *idx, uint32_t ref_id, const char **name, uint64_t *len) try {
     if (!idx) return set_err(MQ_EINVAL, "idx is NULL");
     auto it = idx->refs.find(ref_id);

@@ -116,6 +116,14 @@ struct mq_index {
     int chain_chunk = 64;           // test hook: MQ_CHAIN_CHUNK=4 exercises the multi-chunk chain path
     mq_ctx *def_ctx = nullptr;      // the context behind the index-level map entry points
     double t_add_ms = 0;            // MQ_BUILD_TIMING: wall time spent in mq_index_add_ref[_device] so far
+    // mq_index_stage_*: the reference file's bytes on their way to the device piece by piece (a buffer of the file's size, an upload
+    // stream, one event per piece); a state of its own behind its own lock, so that pieces keep flowing while a record is being indexed
+    std::mutex stg_mu;
+    uint8_t *stg_buf = nullptr;
+    uint64_t stg_bytes = 0;
+    hipStream_t stg_stream = nullptr;
+    std::vector<hipEvent_t> stg_events;  // ticket t = event t (tickets count from 0)
+    uint64_t stg_issued = 0;             // pieces issued so far
     // mq_index_reserve: the table allocated and cleared ahead of time by a thread of its own (finalize adopts it when the size fits)
     std::thread rsv_thread;
     Bucket *rsv_table = nullptr;
@@ -393,7 +401,21 @@ static mq_ctx *ctx_create(mq_index *idx) {
     return c;
 }
 
+static void free_stage(mq_index *idx) {
+    std::lock_guard<std::mutex> lk(idx->stg_mu);
+    if (idx->stg_stream) hipStreamSynchronize(idx->stg_stream);
+    for (hipEvent_t e : idx->stg_events) hipEventDestroy(e);
+    idx->stg_events.clear();
+    if (idx->stg_stream) hipStreamDestroy(idx->stg_stream);
+    idx->stg_stream = nullptr;
+    hipFree(idx->stg_buf);
+    idx->stg_buf = nullptr;
+    idx->stg_bytes = 0;
+    idx->stg_issued = 0;
+}
+
 static void free_build_scratch(mq_index *idx) {
+    free_stage(idx);
     hipFree(idx->bld_seq);
     hipFree(idx->bld_seg_hash);
     hipFree(idx->bld_seg_pos);

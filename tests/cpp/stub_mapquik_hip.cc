@@ -22,6 +22,11 @@ struct mq_index {
     std::map<uint32_t, std::pair<std::string, uint64_t>> refs;
     bool finalized = false;
     uint64_t n_kmm = 0;
+    // mq_index_stage_*: the reference file in pieces
+    std::vector<uint8_t> stage;
+    bool stage_begun = false;
+    uint64_t stage_tickets = 0;
+    std::mutex stage_mu;
 };
 struct mq_ctx {
     mq_index *idx;
@@ -81,9 +86,37 @@ int64_t mq_index_add_ref(mq_index *i, uint32_t id, const char *name, const uint8
     return (int64_t)(len / 100);
 }
 int mq_index_reserve(mq_index *, uint64_t) { return MQ_OK; }
+// the reference file in pieces: a host buffer stands in for the device's; a piece is copied at once (its ticket is done when it returns)
+int mq_index_stage_begin(mq_index *i, uint64_t total) {
+    if (!i->stage.empty()) { g_err = "one staging buffer per index"; return MQ_ESTATE; }
+    i->stage.assign((size_t)total + 1, 0);
+    i->stage_begun = true;
+    return MQ_OK;
+}
+int mq_index_stage_piece(mq_index *i, uint64_t at, const uint8_t *src, uint64_t n, uint64_t *ticket) {
+    std::lock_guard<std::mutex> lk(i->stage_mu);
+    if (!i->stage_begun || at + n + 1 > i->stage.size()) { g_err = "piece outside the staging buffer"; return MQ_EINVAL; }
+    memcpy(i->stage.data() + at, src, (size_t)n);
+    *ticket = i->stage_tickets++;
+    return MQ_OK;
+}
+int mq_index_stage_done(mq_index *i, uint64_t ticket, int) {
+    std::lock_guard<std::mutex> lk(i->stage_mu);
+    if (ticket >= i->stage_tickets) { g_err = "unknown ticket"; return MQ_EINVAL; }
+    return 1;
+}
+int64_t mq_index_add_ref_staged(mq_index *i, uint32_t id, const char *name, uint64_t at, uint64_t len) {
+    std::lock_guard<std::mutex> lk(i->stage_mu);
+    if (!i->stage_begun || at + len + 1 > i->stage.size()) { g_err = "record outside the staging buffer"; return MQ_EINVAL; }
+    return mq_index_add_ref(i, id, name, i->stage.data() + at, len);
+}
 int64_t mq_index_finalize(mq_index *i) { i->finalized = true; return (int64_t)i->n_kmm; }
 mq_index *mq_index_clone(const mq_index *s, int device) {
-    mq_index *i = new mq_index(*s);
+    mq_index *i = new mq_index();
+    i->p = s->p;
+    i->refs = s->refs;
+    i->finalized = s->finalized;
+    i->n_kmm = s->n_kmm;
     i->device = device;
     return i;
 }
@@ -98,6 +131,12 @@ int mq_index_ref_info(const mq_index *i, uint32_t ref_id, const char **name, uin
     if (it == i->refs.end()) { g_err = "unknown ref_id"; return MQ_EINVAL; }
     if (name) *name = it->second.first.c_str();
     if (len) *len = it->second.second;
+    return MQ_OK;
+}
+int mq_index_get_params(const mq_index *i, mq_params *o) { *o = i->p; return MQ_OK; }
+int mq_index_set_map_params(mq_index *i, uint32_t c, uint32_t s, uint32_t g, int fold) {
+    i->p.c = c; i->p.s = s; i->p.g = g;
+    i->p.flags = (i->p.flags & ~MQ_FLAG_FOLD_CASE) | (fold ? MQ_FLAG_FOLD_CASE : 0u);
     return MQ_OK;
 }
 int mq_index_save(const mq_index *, const char *) { g_err = "stub"; return MQ_EINVAL; }

@@ -184,6 +184,53 @@ def test_bench_line_small_run(mode):
     assert e["file_to_paf"].get("paf_lines", 0) > 1300, e
 
 
+def test_bench_line_with_a_real_reference_and_real_reads(simlib, tmp_path):
+    """bench.py's real-data door (BASELINE configs 3 / 4 the day chm13v2.0.fa and the HG002 FASTQ are on the box): a line-wrapped,
+    soft-masked reference FASTA and (a) pbsim2fq-named FASTQ reads: data "real", mapeval against the names' truth; (b) reads whose names
+    carry no truth: q60_wrong is null, the truth-free counts stay; (c) no reads file: reads simulated from the given reference; the
+    roofline, the oracle's column check (cpu_baseline) and the rest of the line unchanged."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g, off, names = simlib.make_genome([900000, 500000, 40], seed=5, repeat_frac=0.05)
+    ref = tmp_path / "ref.fa"
+    with open(ref, "wb") as f:
+        for r in range(3):
+            s = g[int(off[r]):int(off[r + 1])].tobytes()
+            s = s[:1000].lower() + s[1000:]
+            f.write(b">" + names[r].encode() + b" a description\n" + b"".join(s[i:i + 80] + b"\n" for i in range(0, len(s), 80)))
+    reads = simlib.make_reads(g, off, 4000, seed=9)
+    rn = simlib.read_names(reads, names)
+    o = reads["offsets"]
+    fq, fa = tmp_path / "reads.fastq", tmp_path / "anon.fa"
+    with open(fq, "wb") as f, open(fa, "wb") as h:
+        for i, n in enumerate(rn):
+            s = reads["bases"][int(o[i]):int(o[i + 1])].tobytes()
+            f.write(b"@" + n.encode() + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n")
+            h.write(b">m64011_190830_220126/%d/ccs\n" % i + s + b"\n")
+    base = [sys.executable, os.path.join(root, "bench.py"), "--reads", "3000", "--steps", "2", "--warmup", "1", "--no-e2e", "--cpu-sample-reads", "512",
+            "--reference-fasta", str(ref)]
+    out = {}
+    for tag, extra in (("fq", ["--reads-fastx", str(fq)]), ("anon", ["--reads-fastx", str(fa), "--no-cpu-baseline"]), ("sim", ["--no-cpu-baseline"])):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        j = out[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in j, k
+        assert j["value"] > 0 and j["overflow_reads"] == 0 and j["roofline"]["bound"] == "hbm" and j["configs"] is None
+        assert "ref.fa" in j["config"]["workload"] and j["config"]["reads_per_step_per_gpu"] == 3000 and j["roofline"]["traffic"] is None
+        assert j["config"]["index_unique_kminmers"] > 10000
+    assert out["fq"]["data"] == "real" and "reads.fastq" in out["fq"]["config"]["workload"]
+    assert out["fq"]["q60"] > 0.9 * 3000 and out["fq"]["q60_wrong"] is not None and out["fq"]["q60_wrong"] <= 2
+    cb = out["fq"]["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["paf_columns_identical_to_gpu"] and cb["unique_kminmers_equal"]
+    assert out["anon"]["data"] == "real" and out["anon"]["q60_wrong"] is None and out["anon"]["q60"] == out["fq"]["q60"]  # the same sequences
+    assert out["anon"]["mapped_reads"] == out["fq"]["mapped_reads"]
+    assert out["sim"]["data"] == "real reference, simulated reads" and out["sim"]["q60"] > 0.9 * 3000 and out["sim"]["q60_wrong"] <= 2
+
+
 def test_index_clone_is_a_deep_replica(mq, oracle, simlib, small):
     g, off, names = small
     ix, ox, po = _index_both(mq, oracle, small, dict())
