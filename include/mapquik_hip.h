@@ -156,6 +156,10 @@ int64_t mq_index_add_ref_staged(mq_index *idx, uint32_t ref_id, const char *name
  * added; mq_index_finalize adopts it when the size fits and allocates anew when it does not.  Fresh device memory costs ~30 ms per GB
  * here (0.5 s for a human genome's table): call this as early as the reference's size is known.  One reservation per index. */
 int mq_index_reserve(mq_index *idx, uint64_t expected_kminmers);
+/* Slots of the table per inserted k-min-mer (2..64, rounded up to a power of two of slots; default 8: load <= 1/8, the fastest lookups
+ * for a kernel fed from HBM).  A caller bound by its host side (files -> PAF runs at a thirtieth of the kernel's rate) takes 2: a
+ * quarter of the memory per replica and of its allocation, for 5 % of kernel speed it never sees.  Before mq_index_reserve / finalize. */
+int mq_index_set_table_factor(mq_index *idx, uint32_t slots_per_kminmer);
 /* get_count + into_read_only (src/closures.rs:92-94): dedup (a hash seen twice is a tombstone,
  * src/index.rs:94-104), build the HBM-resident table.  Returns the unique count or <0. */
 int64_t mq_index_finalize(mq_index *idx);
@@ -223,6 +227,16 @@ int mq_ctx_submit_spans(mq_ctx *ctx, const uint8_t *buf, uint64_t buf_bytes, con
  * valid until mq_ctx_wait_fasta has returned; page-locked memory (mq_host_alloc) gives the full PCIe rate. */
 #define MQ_FASTA_IRREGULAR 1u
 int mq_ctx_submit_fasta(mq_ctx *ctx, const uint8_t *buf, uint64_t begin, uint64_t bytes);
+/* The same for either format (the reference reads FASTQ unless the file's name says FASTA, src/main.rs:196-205; its real-data headline
+ * run is an uncompressed FASTQ, experiments/table1.sh:50).  MQ_FASTX_FASTQ: buf[begin, bytes) holds whole four-line records, begin at a
+ * record's '@'; read i is the second line of record i, and mq_ctx_wait_fasta reports n_lines = 4 * n_reads line ends (record i: header
+ * = buf[(i ? line_ends[4i-1]+1 : begin), line_ends[4i]), sequence = buf[line_ends[4i]+1, line_ends[4i+1])).  The device checks every
+ * record the way the reference's reader would have to: '@' opens it, '+' opens its third line, one quality per base; anything else
+ * (sequences or qualities over several lines, blank lines, a truncated record) comes back MQ_FASTA_IRREGULAR for the host's parser.
+ * The quality bytes cross the link but no host thread reads them. */
+#define MQ_FASTX_FASTA 0u
+#define MQ_FASTX_FASTQ 1u
+int mq_ctx_submit_fastx(mq_ctx *ctx, const uint8_t *buf, uint64_t begin, uint64_t bytes, uint32_t format);
 int mq_ctx_wait_fasta(mq_ctx *ctx, uint32_t *n_reads, const uint32_t **line_ends, uint32_t *n_lines, const mq_hit **hits, uint32_t *flags);
 /* Pre-size the context's device staging, minimizer lists and scratch for batches of up to n_reads reads / total_bytes buffer
  * bytes, so that the first submit does not pay for the allocations. */

@@ -30,7 +30,7 @@ def hit_column(hits, name):
     return v
 
 # every symbol include/mapquik_hip.h (the seam) and include/mapquik_hip_diag.h (measurement / diagnostics) declare
-EXPORTS = ["mq_index_get_params", "mq_index_set_map_params", "mq_index_stage_begin", "mq_index_stage_piece", "mq_index_stage_done", "mq_index_add_ref_staged", "mq_ctx_submit_fasta", "mq_ctx_wait_fasta", "mq_index_reserve", "mq_host_register", "mq_host_unregister",
+EXPORTS = ["mq_index_set_table_factor", "mq_ctx_submit_fastx", "mq_index_get_params", "mq_index_set_map_params", "mq_index_stage_begin", "mq_index_stage_piece", "mq_index_stage_done", "mq_index_add_ref_staged", "mq_ctx_submit_fasta", "mq_ctx_wait_fasta", "mq_index_reserve", "mq_host_register", "mq_host_unregister",
            "mq_last_error", "mq_abi_version", "mq_device_count", "mq_params_default", "mq_index_new", "mq_index_free",
            "mq_index_add_ref", "mq_index_add_ref_device", "mq_index_finalize", "mq_index_get_stats", "mq_index_ref_info",
            "mq_map_batch", "mq_map_batch_device", "mq_map_reserve", "mq_kminmers_batch", "mq_index_lookup", "mq_format_paf",
@@ -115,6 +115,7 @@ def load_library(path=None):
     if abi >= 4 or hasattr(L, "mq_ctx_submit_fasta"):  # (an older build given by MQ_LIB / path for an A/B run may lack them)
         L.mq_index_reserve.argtypes = [vp, u64]
     if abi >= 4 and hasattr(L, "mq_index_stage_begin"):
+        L.mq_index_set_table_factor.argtypes = [vp, u32]
         L.mq_index_get_params.argtypes = [vp, C.POINTER(Params)]
         L.mq_index_set_map_params.argtypes = [vp, u32, u32, u32, C.c_int]
         L.mq_index_stage_begin.argtypes = [vp, u64]
@@ -125,6 +126,8 @@ def load_library(path=None):
         L.mq_host_register.argtypes = [vp, C.c_size_t]
         L.mq_host_unregister.argtypes = [vp]
         L.mq_ctx_submit_fasta.argtypes = [vp, vp, u64, u64]
+        if hasattr(L, "mq_ctx_submit_fastx"):
+            L.mq_ctx_submit_fastx.argtypes = [vp, vp, u64, u64, u32]
         L.mq_ctx_wait_fasta.argtypes = [vp, C.POINTER(u32), C.POINTER(vp), C.POINTER(u32), C.POINTER(vp), C.POINTER(u32)]
     L.mq_ctx_reserve.argtypes = [vp, u32, u64]
     L.mq_ctx_map_batch_device.argtypes = [vp, vp, vp, u32, u64, vp, vp]
@@ -244,6 +247,11 @@ class Index:
         if n < 0:
             raise _err(self._L, "mq_index_add_ref_device")
         return n
+
+    def set_table_factor(self, slots_per_kminmer):
+        """Table slots per inserted k-min-mer (default 8; 2 for file-fed, host-bound runs).  Before reserve_table / finalize."""
+        if self._L.mq_index_set_table_factor(self._h, int(slots_per_kminmer)) != 0:
+            raise _err(self._L, "mq_index_set_table_factor")
 
     def params(self):
         """The parameters the index was built with (a loaded file's own)."""
@@ -473,10 +481,14 @@ class Context:
             raise _err(self._L, "mq_ctx_submit_spans")
         self._keep = (buf, starts, out, lens)
 
-    def submit_fasta(self, buf, begin=0):
-        """Queue a piece of an uncompressed FASTA file that holds whole records (buf[begin:]): the records are found on the device."""
+    def submit_fasta(self, buf, begin=0, fastq=False):
+        """Queue a piece of an uncompressed FASTA (or, fastq=True, four-line FASTQ) file that holds whole records (buf[begin:]): the
+        records are found on the device."""
         buf = _seq(buf)
-        if self._L.mq_ctx_submit_fasta(self._h, _p(buf), int(begin), buf.size) != 0:
+        if fastq:
+            if self._L.mq_ctx_submit_fastx(self._h, _p(buf), int(begin), buf.size, 1) != 0:
+                raise _err(self._L, "mq_ctx_submit_fastx")
+        elif self._L.mq_ctx_submit_fasta(self._h, _p(buf), int(begin), buf.size) != 0:
             raise _err(self._L, "mq_ctx_submit_fasta")
         self._keep = (buf,)
 

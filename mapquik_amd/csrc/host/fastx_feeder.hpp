@@ -137,7 +137,7 @@ class Feeder {
     void start() {
         if (mapped_fasta_) {
             for (int t = 0; t < n_threads_; ++t) threads_.emplace_back([this] { mapped_fasta_worker(); });
-        } else if (lean_fastq_) {
+        } else if (lean_fastq_ && !leave_unparsed_) {  // (records found by the consumer: the chunked reader below hands the file's bytes over as they are)
             for (int t = 0; t < n_threads_; ++t) threads_.emplace_back([this] { lean_fastq_worker(); });
         } else if (kind_ == 0 || kind_ == 3) {
             for (int t = 0; t < n_threads_; ++t) threads_.emplace_back([this] { raw_worker(); });
@@ -219,9 +219,9 @@ class Feeder {
         for (Chunk *c : got)
             if (c) recycle(c);
     }
-    // Before start(): chunks of an uncompressed FASTA file are handed over as they were read, Chunk::unparsed set, no host thread
-    // having looked at a base (the consumer submits them with mq_ctx_submit_fasta; a chunk that comes back MQ_FASTA_IRREGULAR is
-    // parsed with parse_chunk after all).  Compressed input and FASTQ are parsed here as always.
+    // Before start(): chunks of an uncompressed FASTA or FASTQ file are handed over as they were read, Chunk::unparsed set, no host thread
+    // having looked at a base (the consumer submits them with mq_ctx_submit_fastx; a chunk that comes back MQ_FASTA_IRREGULAR is
+    // parsed with parse_chunk after all).  Compressed input is parsed here as always.
     void leave_unparsed(bool on) { leave_unparsed_ = on; }
     bool fastq() const { return fastq_; }
     // chunks will be (after start(): are) views of the mapped file (see start())
@@ -370,7 +370,7 @@ class Feeder {
                     break;
                 }
                 c->seq_no = i;
-                if (leave_unparsed_ && kind_ == 0 && !fastq_ && c->bytes > c->begin) c->unparsed = true;  // the consumer finds the records (on the device)
+                if (leave_unparsed_ && kind_ == 0 && c->bytes > c->begin) c->unparsed = true;  // the consumer finds the records (on the device), FASTA or FASTQ
                 else parse_chunk(*c, fastq_);
                 publish(c);
             }

@@ -119,19 +119,20 @@ inline uint64_t next_record_start(const uint8_t *b, uint64_t from, uint64_t end,
 }
 
 // ---------------------------------------------------------------- spans of a chunk whose line ends were found elsewhere
-// line_ends: ascending positions of the '\n's of c.buf[c.begin, c.bytes) (a last line without one ends at c.bytes), two lines per
-// record (mq_ctx_wait_fasta): the same starts / lens / ids parse_chunk gives for such a chunk.
-inline void spans_from_line_ends(Chunk &c, const uint32_t *line_ends, uint32_t n_lines) {
+// line_ends: ascending positions of the '\n's of c.buf[c.begin, c.bytes) (a last line without one ends at c.bytes), lpr lines per
+// record (mq_ctx_wait_fasta: 2 for FASTA, 4 for FASTQ; header and sequence are a record's first two): the same starts / lens / ids
+// parse_chunk gives for such a chunk.
+inline void spans_from_line_ends(Chunk &c, const uint32_t *line_ends, uint32_t n_lines, uint32_t lpr = 2) {
     const uint8_t *b = c.buf;
-    const uint32_t n = n_lines / 2;
+    const uint32_t n = n_lines / lpr;
     c.starts.resize(n);
     c.lens.resize(n);
     c.ids.resize(n);
     for (uint32_t i = 0; i < n; ++i) {
-        const uint64_t hs = i ? (uint64_t)line_ends[2 * i - 1] + 1 : c.begin;
-        uint64_t he = line_ends[2 * i];
+        const uint64_t hs = i ? (uint64_t)line_ends[lpr * i - 1] + 1 : c.begin;
+        uint64_t he = line_ends[lpr * i];
         const uint64_t ss = he + 1;
-        uint64_t se = line_ends[2 * i + 1];
+        uint64_t se = line_ends[lpr * i + 1];
         if (se > ss && b[se - 1] == '\r') --se;
         if (he > hs + 1 && b[he - 1] == '\r') --he;
         uint64_t s = hs + 1, e = s;  // seq_io's id(): the header line up to its first SPACE

@@ -68,6 +68,10 @@ class Index {
     ~Index() { mq_index_free(h_); }
     mq_index *handle() const { return h_; }
     const Params &params() const { return params_; }
+    // table slots per inserted k-min-mer (mq_index_set_table_factor): 8 by default, 2 for host-bound file-fed runs
+    void table_factor(uint32_t slots_per_kminmer) {
+        if (mq_index_set_table_factor(h_, slots_per_kminmer) != MQ_OK) throw Error("Index::table_factor: " + last_error());
+    }
     // DashMap::with_capacity (src/index.rs:83): the table for about n k-min-mers is allocated and cleared while the references load
     void with_capacity(uint64_t n_kminmers) {
         if (mq_index_reserve(h_, n_kminmers) != MQ_OK) throw Error("Index::with_capacity: " + last_error());

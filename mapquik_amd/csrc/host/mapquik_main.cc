@@ -100,6 +100,7 @@ struct Opt {
     int device = 0;
     int gpus = 1;
     int seeding_variant = 0;  // MQ_SEEDVAR_* bits (include/mapquik_hip.h)
+    int table_factor = 2;  // table slots per inserted k-min-mer: this driver is bound by its host side (mq_index_set_table_factor)
     std::string save_index, load_index;  // --save-index / --index: the on-disk index (the reference has none and re-indexes on every run)
     std::string second;  // "k2,l2,d2"
     long k2 = 0, l2 = 0;
@@ -114,7 +115,7 @@ static void usage() {
          "        --parallelfastx\n        --unmapped      (extension) also write <prefix>.unmapped.out\n\nOPTIONS:\n"
          "    -b <b>\n    -c, --chain <chain>\n    -d, --density <density>\n    -g, --gap-diff <gap-diff>\n    -k <k>\n    -l <l>\n"
          "    -p, --prefix <prefix>\n    -q <q>\n        --reference <reference>\n    -s, --seed <seed>\n        --threads <threads>\n"
-         "        --device <n>    (extension) first HIP device ordinal\n        --gpus <n>      (extension) shard read batches over n GPUs, index replicated\n        --batch-bases <n> (extension) raw input bytes per chunk\n        --save-index <file> (extension) write the finalized index (occupied slots only) for later runs\n        --index <file>  (extension) map against a saved index instead of indexing --reference (same -k -l -d --nohpc as it was built with)\n        --seeding-variant <v> (extension) reading of the k-min-mer iterator's unpinned decisions, bits 1 2 4 8 16 32 (include/mapquik_hip.h); 0 = frozen\n        --second-pass <k2,l2,d2> (extension) map the unmapped reads again with these parameters: <prefix>-k2-l2-d2.{fa,paf,unmapped.out}\n\nARGS:\n    <reads>");
+         "        --device <n>    (extension) first HIP device ordinal\n        --gpus <n>      (extension) shard read batches over n GPUs, index replicated\n        --batch-bases <n> (extension) raw input bytes per chunk\n        --table-factor <n> (extension) index table slots per k-min-mer (default 2 here: a file-fed run is host-bound; the library's default for HBM-resident batches is 8)\n        --save-index <file> (extension) write the finalized index (occupied slots only) for later runs\n        --index <file>  (extension) map against a saved index instead of indexing --reference (same -k -l -d --nohpc as it was built with)\n        --seeding-variant <v> (extension) reading of the k-min-mer iterator's unpinned decisions, bits 1 2 4 8 16 32 (include/mapquik_hip.h); 0 = frozen\n        --second-pass <k2,l2,d2> (extension) map the unmapped reads again with these parameters: <prefix>-k2-l2-d2.{fa,paf,unmapped.out}\n\nARGS:\n    <reads>");
 }
 
 // One run of the reference's flow (src/closures.rs:22-212): index the reference, map the reads, write <prefix>.paf in input
@@ -145,7 +146,8 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         // An uncompressed FASTA file goes to the GPU as it lies in the file: the reader threads only copy file bytes into page-locked
         // chunks (pread, cut at record starts), the records are found on the device (mq_ctx_submit_fasta) and the host reads a header
         // only to print it.  MQ_DRIVER_HOST_PARSE=1: every chunk is parsed by the reader threads as in earlier rounds (same PAF; tests compare).
-        feed.leave_unparsed(reads_fasta && getenv("MQ_DRIVER_HOST_PARSE") == nullptr);
+        feed.leave_unparsed(getenv("MQ_DRIVER_HOST_PARSE") == nullptr);  // (acts on uncompressed input only, FASTA or FASTQ)
+        const uint32_t fx_format = reads_fasta ? MQ_FASTX_FASTA : MQ_FASTX_FASTQ, fx_lpr = reads_fasta ? 2u : 4u;
         feed.premap();  // MQ_FEEDER_MAPPED_FASTA=1 only (experiment): the file is mapped, not read, while the reference is indexed
         // The read feeder starts when the index is ready.  MQ_DRIVER_PREFETCH=1 starts it while the reference is still being indexed
         // (it then allocates its page-locked chunk buffers and parses the first chunks early): that was the default while pinning
@@ -167,9 +169,11 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         std::vector<std::unique_ptr<Index>> building(1);
         if (o.load_index.empty()) {
             building[0].reset(new Index(P, dev_of(0)));
+            building[0]->table_factor((uint32_t)o.table_factor);
             tl("Index::new returned (HIP runtime up, device chosen)");
         }
         const bool ref_plain = ref_fasta && !ends_with(o.reference, ".gz") && !ends_with(o.reference, ".lz4");
+        const bool stream_ref = ref_plain && o.load_index.empty() && getenv("MQ_DRIVER_REF_HOST") == nullptr;  // RefStreamer (below)
         // The stream slots of the map phase (device staging, minimizer lists, Match scratch: a few hundred MB of device memory per
         // submitting thread) and the feeder's first page-locked chunk buffers depend on neither the reference nor the reads: the first
         // GPU's are set up by a thread of its own BESIDE the reference phase (0.03-0.04 s of a 0.1-s phase when they came after it).
@@ -245,10 +249,18 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             ref_done = true;
             tl("index file loaded");
         } else {
+            if (stream_ref) {
+                // the staging buffer of the streamed reference FIRST: device allocations queue behind each other, and this one (the file's
+                // size) must not wait behind the table's, which is several times larger and not needed before the last record is indexed
+                struct stat rst;
+                if (stat(o.reference.c_str(), &rst) != 0) throw Error("Error opening compressed file: " + o.reference);  // get_reader's message (src/main.rs:62)
+                if (mq_index_stage_begin(building[0]->handle(), (uint64_t)rst.st_size) != MQ_OK) throw Error("mq_index_stage_begin: " + last_error());
+                tl("staging buffer for the reference allocated");
+            }
             reserve_table();
             early_start();
         }
-        if (!ref_done && ref_plain && getenv("MQ_DRIVER_REF_HOST") == nullptr) {
+        if (!ref_done && stream_ref) {
             // an uncompressed FASTA of one sequence line per record (what assemblers and this repository's tools write): streamed to the
             // device block by block as it is read, records indexed while the blocks behind them are still on the link (RefStreamer);
             // the host reads the header lines only.  Any other shape: the loader below.
@@ -267,8 +279,6 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                 return r == 1;
             };
             feeder::RefStreamer rs(o.reference, n_parse, hooks);
-            if (mq_index_stage_begin(h, rs.file_bytes()) != MQ_OK) throw Error("mq_index_stage_begin: " + last_error());
-            tl("reference streamer constructed, staging buffer allocated");
             std::vector<std::string> lines;  // printed once the file's shape is known to be regular (else the loader below prints its own)
             const feeder::RefStreamer::Result res = rs.run([&](size_t k, const std::string &id, uint64_t at, uint64_t len) {
                 const int64_t cnt = mq_index_add_ref_staged(h, (uint32_t)k, id.c_str(), at, len);  // index_mers, src/closures.rs:46-51
@@ -287,6 +297,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                     for (auto &v : slots) for (auto &c : v) { mq_ctx_free(c); c = nullptr; }
                     building[0].reset();
                     building[0].reset(new Index(P, dev_of(0)));
+                    building[0]->table_factor((uint32_t)o.table_factor);
                     reserve_table();
                 }
                 tl("reference is not one line per record: host loader");
@@ -433,7 +444,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                             // sequences over several lines, blank lines, ...: this chunk the old way (parsed here, spans to the device)
                             try {
                                 fc->materialize();  // a view of the mapped file: the parser compacts sequence lines in place
-                                feeder::parse_chunk(*fc, false);
+                                feeder::parse_chunk(*fc, !reads_fasta);
                                 fc->hits.resize(fc->starts.size());
                                 if (!fc->starts.empty() &&
                                     (mq_ctx_submit_spans(ctx[sl], fc->buf, fc->bytes, fc->starts.data(), fc->lens.data(), (uint32_t)fc->starts.size(), fc->hits.data()) != MQ_OK ||
@@ -441,7 +452,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                                     fail(std::string("mq_ctx_submit_spans: ") + last_error());
                             } catch (const std::exception &e) { fail(e.what()); }
                         } else {
-                            feeder::spans_from_line_ends(*fc, line_ends, n_lines);
+                            feeder::spans_from_line_ends(*fc, line_ends, n_lines, fx_lpr);
                             fc->hits.assign(hits, hits + n);
                         }
                         fc->unparsed = false;
@@ -491,7 +502,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                         }
                         if (c->unparsed) {
                             const auto ts0 = Clock::now();
-                            if (mq_ctx_submit_fasta(ctx[sl], c->buf, c->begin, c->bytes) != MQ_OK) throw Error(std::string("mq_ctx_submit_fasta: ") + last_error());
+                            if (mq_ctx_submit_fastx(ctx[sl], c->buf, c->begin, c->bytes, fx_format) != MQ_OK) throw Error(std::string("mq_ctx_submit_fastx: ") + last_error());
                             t_submit_us += us_since(ts0);
                             inflight[sl] = c;
                             age[sl] = submitted++;
@@ -648,6 +659,10 @@ int main(int argc, char **argv) {
         else if (a == "--device") o.device = atoi(val());
         else if (a == "--gpus") o.gpus = std::max(1, atoi(val()));
         else if (a == "--batch-bases") o.batch_bases = strtoull(val(), nullptr, 10);
+        else if (a == "--table-factor") {
+            o.table_factor = atoi(val());
+            if (o.table_factor < 2 || o.table_factor > 64) { fprintf(stderr, "error: --table-factor wants 2..64\n"); return 2; }
+        }
         else if (a == "--save-index") o.save_index = val();
         else if (a == "--index") o.load_index = val();
         else if (a == "--seeding-variant") {

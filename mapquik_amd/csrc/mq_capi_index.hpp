@@ -28,7 +28,13 @@ mq_index *mq_index_new(const mq_params *params, int device) try {
         return nullptr;
     }
 #endif
+    const bool init_timing = getenv("MQ_DRIVER_TIMING") != nullptr;  // diagnostic (stderr): where the first index's start-up time goes
+    const auto ti0 = std::chrono::steady_clock::now();
+    auto stamp = [&](const char *what) {
+        if (init_timing) fprintf(stderr, "    mq_index_new: +%.3f s %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - ti0).count(), what);
+    };
     int n = mq_device_count();
+    stamp("hipGetDeviceCount (runtime initialised)");
     if (n <= 0) {
         set_err(MQ_ENODEVICE, "no HIP device: the mapquik HIP path has no CPU fallback");
         return nullptr;
@@ -61,12 +67,15 @@ mq_index *mq_index_new(const mq_params *params, int device) try {
         return nullptr;
     }
     idx->n_cu = prop.multiProcessorCount;
+    stamp("hipSetDevice + hipGetDeviceProperties");
     // an empty one-bucket table so that seeding-only calls work before finalize
     if (alloc_table(idx, 2) != MQ_OK) {
         delete idx;
         return nullptr;
     }
+    stamp("first hipMalloc + hipMemset (code objects loaded)");
     idx->def_ctx = ctx_create(idx);
+    stamp("stream created");
     if (!idx->def_ctx) {
         hipFree(idx->table);
         delete idx;
@@ -311,6 +320,21 @@ int64_t mq_index_add_ref_staged(mq_index *idx, uint32_t ref_id, const char *name
     return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
+// Slots of the table per inserted k-min-mer (rounded up to a power of two of slots).  The default, 8 (load <= 1/8: 17 GB for a human
+// genome), is for a kernel fed from HBM: 1130 Gbases/s against 1114 / 1074 at 4 / 2.  A caller that feeds from files is bound by its
+// host side at a thirtieth of that and does better with 2: a quarter of the memory per replica, of the device-to-device copy per clone,
+// and of the allocation (fresh device memory can cost 30 ms per GB here) -- the native driver's default.
+int mq_index_set_table_factor(mq_index *idx, uint32_t slots_per_kminmer) try {
+    if (!idx) return set_err(MQ_EINVAL, "idx is NULL");
+    if (slots_per_kminmer < 2 || slots_per_kminmer > 64) return set_err(MQ_EINVAL, "slots per k-min-mer: 2..64");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (idx->finalized || idx->rsv_thread.joinable() || idx->rsv_table) return set_err(MQ_ESTATE, "mq_index_set_table_factor: before mq_index_reserve / mq_index_finalize");
+    idx->table_factor = slots_per_kminmer;
+    return MQ_OK;
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+}
+
 // DashMap::with_capacity at Index::new (src/index.rs:83 sizes the map for 39,821,990 k-min-mers before the first insert): the table
 // for `expected_kminmers` inserted k-min-mers is allocated and cleared by a thread of its own, while the caller reads, uploads and
 // seeds the reference -- fresh device memory costs ~30 ms per GB on this platform (tools/alloc_probe.hip: 485 ms for the 17 GB table
@@ -321,7 +345,7 @@ int mq_index_reserve(mq_index *idx, uint64_t expected_kminmers) try {
     std::lock_guard<std::mutex> lk(idx->mu);
     if (idx->finalized) return set_err(MQ_ESTATE, "index already finalized");
     if (idx->rsv_thread.joinable() || idx->rsv_table) return MQ_OK;  // one reservation per index
-    const uint64_t nslots = table_slots_for(expected_kminmers);
+    const uint64_t nslots = table_slots_for(idx, expected_kminmers);
     idx->rsv_nslots = nslots;
     const int device = idx->device;
     idx->rsv_thread = std::thread([idx, nslots, device]() {
@@ -363,7 +387,7 @@ int64_t mq_index_finalize(mq_index *idx) try {
     // the HBM).  ~85 % of a read's lookups miss, a miss walks to the first empty slot, and every extra step is one more dependent
     // random access of a memory system that sustains ~52 G of them per second (tools/probe_rate.py).  Measured on the CHM13-like
     // bench: factor 2: 926, 4: 1000, 8: 1034, 16: 1044, 32: 1051 Gbases/s.
-    const uint64_t nslots = table_slots_for(idx->n_kmm_total);
+    const uint64_t nslots = table_slots_for(idx, idx->n_kmm_total);
     rsv_join(idx);
     if (idx->rsv_table && idx->rsv_nslots == nslots && idx->rsv_err == 0) {  // the table mq_index_reserve allocated and cleared
         if (idx->table) HIPCHK(hipFree(idx->table));

@@ -230,11 +230,13 @@ static int ctx_map_device(mq_ctx *c, const uint8_t *d_bases, const uint64_t *d_o
 // back.  The copy of the NEXT chunk (another context, another stream) runs meanwhile: the link stays busy.
 static uint32_t fx_line_cap(uint64_t bytes) { return (uint32_t)std::min<uint64_t>(bytes / 16 + 4096, 1u << 28); }
 
-static int ctx_submit_fasta(mq_ctx *c, const uint8_t *buf, uint64_t begin, uint64_t bytes) {
+static int ctx_submit_fasta(mq_ctx *c, const uint8_t *buf, uint64_t begin, uint64_t bytes, uint32_t format) {
     mq_index *idx = c->idx;
     if (c->pending || c->fx_pending) return set_err(MQ_ESTATE, "context has a submitted batch: call mq_ctx_wait first");
     if (!idx->finalized) return set_err(MQ_ESTATE, "index not finalized");
     if (bytes >= (1ull << 32) || begin > bytes) return set_err(MQ_EINVAL, "a chunk must be smaller than 4 GB");
+    if (format != MQ_FASTX_FASTA && format != MQ_FASTX_FASTQ) return set_err(MQ_EINVAL, "format must be MQ_FASTX_FASTA or MQ_FASTX_FASTQ");
+    const uint32_t lpr = format == MQ_FASTX_FASTQ ? 4u : 2u;  // lines per record
     int rc = use_device(idx);
     if (rc) return rc;
     const uint32_t n_tiles = (uint32_t)((bytes + FX_TILE - 1) / FX_TILE);
@@ -266,13 +268,17 @@ static int ctx_submit_fasta(mq_ctx *c, const uint8_t *buf, uint64_t begin, uint6
     const uint32_t b = (uint32_t)begin, e = (uint32_t)bytes;
     const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>((n_tiles + 3) / 4, (uint32_t)idx->n_cu * 8u));
     hipLaunchKernelGGL(count_newlines_kernel, dim3(grid), dim3(256), 0, st, c->st_bases, b, e, n_tiles, c->fx_tile_counts);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, st, c->st_bases, b, e, c->fx_tile_counts, n_tiles, c->fx_tile_off, c->fx_nl, cap, c->fx_info);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, st, c->st_bases, b, e, c->fx_tile_counts, n_tiles, c->fx_tile_off, c->fx_nl, cap, c->fx_info, lpr);
     hipLaunchKernelGGL(list_newlines_kernel, dim3(grid), dim3(256), 0, st, c->st_bases, b, e, n_tiles, c->fx_tile_off, c->fx_nl, cap);
-    hipLaunchKernelGGL(fasta_spans_kernel, dim3(std::max<uint32_t>(1, std::min<uint32_t>(cap / 2 / 256 + 1, (uint32_t)idx->n_cu * 4u))), dim3(256), 0, st, c->st_bases, b, e,
-                       c->fx_nl, c->fx_info, reinterpret_cast<unsigned long long *>(c->st_off), c->st_lens, cap / 2);
+    const dim3 sgrid(std::max<uint32_t>(1, std::min<uint32_t>(cap / 2 / 256 + 1, (uint32_t)idx->n_cu * 4u)));
+    if (format == MQ_FASTX_FASTQ)
+        hipLaunchKernelGGL(fastq_spans_kernel, sgrid, dim3(256), 0, st, c->st_bases, b, e, c->fx_nl, c->fx_info, reinterpret_cast<unsigned long long *>(c->st_off), c->st_lens, cap / 2);
+    else
+        hipLaunchKernelGGL(fasta_spans_kernel, sgrid, dim3(256), 0, st, c->st_bases, b, e, c->fx_nl, c->fx_info, reinterpret_cast<unsigned long long *>(c->st_off), c->st_lens, cap / 2);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(c->h_fx_info, c->fx_info, 16, hipMemcpyDeviceToHost, st));
     c->fx_pending = true;
+    c->fx_lpr = lpr;
     c->fx_buf = buf;
     c->fx_begin = b;
     c->fx_bytes = e;
@@ -309,9 +315,10 @@ static int ctx_wait_fasta(mq_ctx *c, uint32_t *n_reads, const uint32_t **line_en
     if (over) {  // the rare reads with more Match runs / denser lists than the scratch holds: again with room, from the host's copy of the chunk
         std::vector<uint64_t> offs(n);
         std::vector<uint32_t> lens(n);
+        const uint32_t lpr = c->fx_lpr;
         for (uint32_t i = 0; i < n; ++i) {
-            const uint32_t ss = c->h_fx_nl[2 * i] + 1;
-            uint32_t e = c->h_fx_nl[2 * i + 1];
+            const uint32_t ss = c->h_fx_nl[lpr * i] + 1;
+            uint32_t e = c->h_fx_nl[lpr * i + 1];
             if (e > ss && c->fx_buf[e - 1] == '\r') --e;
             offs[i] = ss;
             lens[i] = e - ss;
@@ -329,7 +336,16 @@ extern "C" {
 
 int mq_ctx_submit_fasta(mq_ctx *ctx, const uint8_t *buf, uint64_t begin, uint64_t bytes) try {
     if (!ctx || (bytes && !buf)) return set_err(MQ_EINVAL, "bad arguments");
-    return ctx_submit_fasta(ctx, buf, begin, bytes);
+    return ctx_submit_fasta(ctx, buf, begin, bytes, MQ_FASTX_FASTA);
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+}
+
+int mq_ctx_submit_fastx(mq_ctx *ctx, const uint8_t *buf, uint64_t begin, uint64_t bytes, uint32_t format) try {
+    if (!ctx || (bytes && !buf)) return set_err(MQ_EINVAL, "bad arguments");
+    return ctx_submit_fasta(ctx, buf, begin, bytes, format);
 } catch (const std::bad_alloc &) {
     return set_err(MQ_ENOMEM, "out of host memory");
 } catch (const std::exception &e) {

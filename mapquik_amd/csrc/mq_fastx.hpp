@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void count_newlines_kernel(const uint8_t *__re
 // info: [0] lines (incl. the virtual end of a last line without '\n'), [1] records, [2] flags, [3] spare
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint8_t *__restrict__ buf, uint32_t begin, uint32_t end, const uint32_t *__restrict__ tile_counts,
                                                           uint32_t n_tiles, uint32_t *__restrict__ tile_off, uint32_t *__restrict__ nl_pos, uint32_t nl_cap,
-                                                          uint32_t *__restrict__ info) {
+                                                          uint32_t *__restrict__ info, uint32_t lines_per_record) {
     __shared__ uint32_t part[1024];
     const uint32_t t = threadIdx.x, per = (n_tiles + 1023u) / 1024u;
     const uint32_t lo = t * per < n_tiles ? t * per : n_tiles, hi = lo + per < n_tiles ? lo + per : n_tiles;
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint8_t *__restr
         // is reported -- fasta_spans_kernel and the caller index nl_pos[0, lines) and must never see a count beyond its capacity
         const bool over = lines > nl_cap;
         info[0] = over ? 0u : lines;
-        info[1] = over ? 0u : lines / 2u;
-        info[2] = (lines & 1u) || over ? FX_IRREGULAR : 0u;
+        info[1] = over ? 0u : lines / lines_per_record;  // FASTA: header + sequence line; FASTQ: header, sequence, '+', quality
+        info[2] = (lines % lines_per_record) || over ? FX_IRREGULAR : 0u;
         info[3] = 0;
     }
 }
@@ -124,6 +124,38 @@ __global__ __launch_bounds__(256) void fasta_spans_kernel(const uint8_t *__restr
         if (hs >= he || buf[hs] != '>') bad = true;            // a blank line, or a sequence that goes on over several lines
         if (ss < e && buf[ss] == '>') bad = true;              // a header without a sequence line
         if (e > ss && buf[e - 1u] == '\r') --e;                // CR-LF
+        if (r < span_cap) {
+            starts[r] = ss;
+            lens[r] = e - ss;
+        } else {
+            bad = true;
+        }
+    }
+    if (__ballot(bad) && lane_id() == 0) atomicOr(&info[2], FX_IRREGULAR);
+}
+
+// FASTQ (the reference's default format when the name is not .fa / .fasta / .fna, src/main.rs:196-205; its headline real-data run is an
+// uncompressed FASTQ, experiments/table1.sh:50): record r = lines 4r .. 4r + 3 = "@id ...", sequence, "+...", quality.  Checked per record,
+// as the host's validator does (fastx_records.hpp fastq_record_at): '@' opens the header line, '+' the third line, and the quality line
+// is as long as the sequence line ('\r' cut from both).  Anything else -- sequences or qualities over several lines, blank lines, a
+// record cut short -- sets FX_IRREGULAR and the host parses the piece.  The quality bytes cross the link (2 file bytes per base) but no
+// host thread touches them, and no kernel reads more of them than the byte in front of their line end.
+__global__ __launch_bounds__(256) void fastq_spans_kernel(const uint8_t *__restrict__ buf, uint32_t begin, uint32_t end, const uint32_t *__restrict__ nl_pos,
+                                                          uint32_t *__restrict__ info, unsigned long long *__restrict__ starts, uint32_t *__restrict__ lens,
+                                                          uint32_t span_cap) {
+    if (info[2] & FX_IRREGULAR) return;
+    const uint32_t n_rec = info[1];
+    bool bad = false;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rec; r += gridDim.x * blockDim.x) {
+        const uint32_t hs = r == 0 ? begin : nl_pos[4u * r - 1u] + 1u;
+        const uint32_t he = nl_pos[4u * r], se = nl_pos[4u * r + 1u], pe = nl_pos[4u * r + 2u], qe = nl_pos[4u * r + 3u];
+        const uint32_t ss = he + 1u, ps = se + 1u, qs = pe + 1u;
+        uint32_t e = se, q = qe;
+        if (hs >= he || buf[hs] != '@') bad = true;       // a blank line, or not a header where one must be
+        if (ps >= pe || buf[ps] != '+') bad = true;       // the third line is the separator
+        if (e > ss && buf[e - 1u] == '\r') --e;           // CR-LF
+        if (q > qs && q <= end && buf[q - 1u] == '\r') --q;
+        if (e - ss != q - qs) bad = true;                 // one quality per base
         if (r < span_cap) {
             starts[r] = ss;
             lens[r] = e - ss;

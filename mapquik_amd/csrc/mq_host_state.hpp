@@ -63,6 +63,7 @@ struct mq_ctx {
     uint32_t *fx_info = nullptr, *h_fx_info = nullptr;  // device / page-locked: lines, records, flags
     uint8_t *h_fx_tail = nullptr;                       // page-locked, one page: the piece's bytes behind its last page boundary
     bool fx_pending = false;
+    uint32_t fx_lpr = 2;                                // lines per record of the piece in flight (FASTA 2, FASTQ 4)
     const uint8_t *fx_buf = nullptr;
     uint32_t fx_begin = 0, fx_bytes = 0;
     // a submitted, not yet waited-for batch
@@ -91,6 +92,7 @@ struct mq_index {
     std::vector<KmmChunk> chunks;
     uint64_t n_kmm_total = 0;
     bool finalized = false;
+    uint32_t table_factor = 0;  // mq_index_set_table_factor: slots per inserted k-min-mer (0: the default, 8)
     Bucket *table = nullptr;  // nslots / 2 buckets + the extra bucket of the key 0
     uint64_t nslots = 0;
     uint64_t *d_ref_lens = nullptr;
@@ -132,9 +134,9 @@ struct mq_index {
 };
 
 // slots of the table for n inserted k-min-mers: MQ_TABLE_FACTOR (default 8: load <= 0.125) times n, rounded up to a power of two
-static uint64_t table_slots_for(uint64_t n_kmm) {
-    const char *lf = getenv("MQ_TABLE_FACTOR");
-    const uint64_t factor = lf && atoi(lf) >= 2 ? (uint64_t)atoi(lf) : 8ull;  // >= 2: a full table would make a miss walk forever
+static uint64_t table_slots_for(const mq_index *idx, uint64_t n_kmm) {
+    const char *lf = getenv("MQ_TABLE_FACTOR");  // (test / experiment hook: overrides the caller's choice)
+    const uint64_t factor = lf && atoi(lf) >= 2 ? (uint64_t)atoi(lf) : idx->table_factor ? (uint64_t)idx->table_factor : 8ull;  // >= 2: a full table would make a miss walk forever
     uint64_t nslots = 1024;
     while (nslots < factor * n_kmm) nslots <<= 1;
     return nslots;

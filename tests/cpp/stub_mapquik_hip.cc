@@ -86,6 +86,7 @@ int64_t mq_index_add_ref(mq_index *i, uint32_t id, const char *name, const uint8
     return (int64_t)(len / 100);
 }
 int mq_index_reserve(mq_index *, uint64_t) { return MQ_OK; }
+int mq_index_set_table_factor(mq_index *, uint32_t f) { return f >= 2 && f <= 64 ? MQ_OK : MQ_EINVAL; }
 // the reference file in pieces: a host buffer stands in for the device's; a piece is copied at once (its ticket is done when it returns)
 int mq_index_stage_begin(mq_index *i, uint64_t total) {
     if (!i->stage.empty()) { g_err = "one staging buffer per index"; return MQ_ESTATE; }
@@ -162,34 +163,43 @@ int mq_ctx_submit_spans(mq_ctx *c, const uint8_t *buf, uint64_t bytes, const uin
     });
     return MQ_OK;
 }
-// the device's record scan, on the host: line ends of buf[begin, bytes), two lines per record, '>' in front of every header
-int mq_ctx_submit_fasta(mq_ctx *c, const uint8_t *buf, uint64_t begin, uint64_t bytes) {
+// the device's record scan, on the host: line ends of buf[begin, bytes); FASTA: two lines per record, '>' in front of every header;
+// FASTQ: four lines, '@' / '+' / one quality per base
+int mq_ctx_submit_fastx(mq_ctx *c, const uint8_t *buf, uint64_t begin, uint64_t bytes, uint32_t format) {
     if (c->pending) { g_err = "context has a submitted batch"; return MQ_ESTATE; }
+    if (format > MQ_FASTX_FASTQ) { g_err = "format"; return MQ_EINVAL; }
     c->pending = true;
     c->worker = std::thread([=]() {
+        const size_t lpr = format == MQ_FASTX_FASTQ ? 4 : 2;
         c->fx_lines.clear();
         c->fx_hits.clear();
         c->fx_flags = 0;
         for (uint64_t p = begin; p < bytes; ++p)
             if (buf[p] == '\n') c->fx_lines.push_back((uint32_t)p);
         if (bytes > begin && buf[bytes - 1] != '\n') c->fx_lines.push_back((uint32_t)bytes);
-        if (c->fx_lines.size() & 1) c->fx_flags = MQ_FASTA_IRREGULAR;
-        const size_t n = c->fx_lines.size() / 2;
+        if (c->fx_lines.size() % lpr) c->fx_flags = MQ_FASTA_IRREGULAR;
+        const size_t n = c->fx_lines.size() / lpr;
+        auto cut = [&](uint64_t s, uint64_t e) { return (e > s && buf[e - 1] == '\r') ? e - 1 : e; };
         for (size_t i = 0; i < n && !c->fx_flags; ++i) {
-            const uint64_t hs = i ? (uint64_t)c->fx_lines[2 * i - 1] + 1 : begin, he = c->fx_lines[2 * i], ss = he + 1;
-            if (hs >= he || buf[hs] != '>' || (ss < c->fx_lines[2 * i + 1] && buf[ss] == '>')) c->fx_flags = MQ_FASTA_IRREGULAR;
+            const uint64_t hs = i ? (uint64_t)c->fx_lines[lpr * i - 1] + 1 : begin, he = c->fx_lines[lpr * i], ss = he + 1, se = c->fx_lines[lpr * i + 1];
+            if (format == MQ_FASTX_FASTQ) {
+                const uint64_t ps = se + 1, pe = c->fx_lines[4 * i + 2], qs = pe + 1, qe = c->fx_lines[4 * i + 3];
+                if (hs >= he || buf[hs] != '@' || ps >= pe || buf[ps] != '+' || cut(ss, se) - ss != cut(qs, qe) - qs) c->fx_flags = MQ_FASTA_IRREGULAR;
+            } else if (hs >= he || buf[hs] != '>' || (ss < se && buf[ss] == '>')) {
+                c->fx_flags = MQ_FASTA_IRREGULAR;
+            }
         }
         if (c->fx_flags) return;
         c->fx_hits.resize(n);
         for (size_t i = 0; i < n; ++i) {
-            const uint64_t ss = (uint64_t)c->fx_lines[2 * i] + 1;
-            uint64_t e = c->fx_lines[2 * i + 1];
-            if (e > ss && buf[e - 1] == '\r') --e;
+            const uint64_t ss = (uint64_t)c->fx_lines[lpr * i] + 1;
+            const uint64_t e = cut(ss, c->fx_lines[lpr * i + 1]);
             canned(c->idx, buf, ss, (uint32_t)(e - ss), &c->fx_hits[i]);
         }
     });
     return MQ_OK;
 }
+int mq_ctx_submit_fasta(mq_ctx *c, const uint8_t *buf, uint64_t begin, uint64_t bytes) { return mq_ctx_submit_fastx(c, buf, begin, bytes, MQ_FASTX_FASTA); }
 int mq_ctx_wait_fasta(mq_ctx *c, uint32_t *n_reads, const uint32_t **line_ends, uint32_t *n_lines, const mq_hit **hits, uint32_t *flags) {
     if (c->worker.joinable()) c->worker.join();
     c->pending = false;

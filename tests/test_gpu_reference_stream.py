@@ -141,8 +141,11 @@ def test_stage_api_pieces_in_any_order(mq, oracle, simlib):
         n = int(off[r + 1] - off[r])
         got.append(b.add_ref_staged(r, names[r], pos, n))
         pos += n + 1
-    assert got == want and b.finalize() == ua
-    assert all(b.stage_done(t, wait=False) for t in tickets)
+    assert got == want
+    assert all(b.stage_done(t, wait=True) for t in tickets)
+    assert b.finalize() == ua  # (releases the staging buffer and its tickets)
+    with pytest.raises(mq.MapquikError):
+        b.stage_done(tickets[0], wait=False)
     reads = simlib.make_reads(g, off, 200, seed=3)
     assert np.array_equal(a.map_batch(reads["bases"], reads["offsets"]).view(np.uint8), b.map_batch(reads["bases"], reads["offsets"]).view(np.uint8))
     c = mq.Index(P)
