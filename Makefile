@@ -7,16 +7,18 @@ CSRC   := mapquik_amd/csrc
 
 all: $(LIBDIR)/libmapquik_hip.so $(LIBDIR)/mapquik
 
-$(LIBDIR)/libmapquik_hip.so: $(CSRC)/mq_capi.hip $(CSRC)/mq_device.hpp $(CSRC)/mq_seed.hpp include/mapquik_hip.h
+# every part of the library's one translation unit (mq_capi.hip includes them all) and both headers: a stale .so would make parity
+# and perf numbers describe old kernels (mapquik_amd/build.py globs the same files)
+$(LIBDIR)/libmapquik_hip.so: $(CSRC)/mq_capi.hip $(wildcard $(CSRC)/*.hpp) $(wildcard include/*.h)
 	mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -Wno-align-mismatch -mllvm -amdgpu-atomic-optimizer-strategy=None -mllvm -pragma-unroll-threshold=65536 -o $@ $(CSRC)/mq_capi.hip
 
-$(LIBDIR)/mapquik: $(CSRC)/host/mapquik_main.cc $(CSRC)/host/mapquik_host.hpp $(CSRC)/host/fastx_feeder.hpp $(CSRC)/host/fastx_records.hpp $(CSRC)/host/par_gzip.hpp $(CSRC)/host/ref_loader.hpp include/mapquik_hip.h $(LIBDIR)/libmapquik_hip.so
+$(LIBDIR)/mapquik: $(CSRC)/host/mapquik_main.cc $(wildcard $(CSRC)/host/*.hpp) $(wildcard include/*.h) $(LIBDIR)/libmapquik_hip.so
 	$(CXX) -O2 -std=c++17 -Wall -o $@ $(CSRC)/host/mapquik_main.cc -L$(LIBDIR) -lmapquik_hip -lz -lpthread -ldl -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 # Sanitizer builds of the threaded host code (CPU only: no sanitizer runs on the GPU build).  The driver links a host-only stub of
 # the C ABI with canned results (tests/cpp/stub_mapquik_hip.cc); tests/test_sanitizers.py builds and runs these.
-HOSTSRC := $(CSRC)/host/mapquik_main.cc $(CSRC)/host/mapquik_host.hpp $(CSRC)/host/fastx_feeder.hpp $(CSRC)/host/fastx_records.hpp $(CSRC)/host/par_gzip.hpp $(CSRC)/host/ref_loader.hpp include/mapquik_hip.h
+HOSTSRC := $(CSRC)/host/mapquik_main.cc $(wildcard $(CSRC)/host/*.hpp) $(wildcard include/*.h)
 SAN_A := -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -O1
 SAN_T := -fsanitize=thread -fno-omit-frame-pointer -g -O1
 

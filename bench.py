@@ -136,7 +136,14 @@ def write_reference(genome, ctg_off, ctg_names, path):
             f.write(b"\n")
 
 
-def measure_file_to_paf(ref, reads, n_reads, threads, workdir, fastq=False, extra_args=(), compress=None, env=None):
+def files_on(path):
+    """Where the e2e legs' files live: /dev/shm is tmpfs (page cache, no device behind it) -- the rates say what the host side and the
+    link do, not what a disk does."""
+    p = os.path.realpath(path)
+    return "/dev/shm (tmpfs: memory, no block device)" if p.startswith("/dev/shm") else "%s (temporary directory, files read once before the timed run: page cache)" % os.path.dirname(p)
+
+
+def measure_file_to_paf(ref, reads, n_reads, threads, workdir, fastq=False, extra_args=(), compress=None, env=None, more_threads=()):
     """End to end through the native driver (mapquik_amd/lib/mapquik): reference FASTA + reads file on disk -> <prefix>.paf.
     fastq: the reads as a FASTQ file; compress="gz": as a plain gzip stream.  Three runs: one to bring the files into the page cache,
     the driver's default = the strict run (nothing of the reads is touched before the index is ready; also reported under the
@@ -156,12 +163,12 @@ def measure_file_to_paf(ref, reads, n_reads, threads, workdir, fastq=False, extr
         rd += ".gz"
     bases = int(offs[n_reads])
     out = {"reads": n_reads, "bases": bases, "file_bytes": file_bytes, "threads": threads, "format": ("FASTQ" if fastq else "FASTA") + (".gz" if compress else ""),
-           "args": " ".join(extra_args)}
+           "args": " ".join(extra_args), "files_on": files_on(workdir)}
     prefix = os.path.join(workdir, "e2e")
 
     base_env = dict(os.environ, **(env or {}))
 
-    def run(env):
+    def run(env, threads=threads):
         t0 = time.perf_counter()
         r = subprocess.run([exe, rd, "--reference", ref, "-p", prefix, "--threads", str(threads)] + list(extra_args),
                            capture_output=True, text=True, timeout=900, env=dict(base_env, **env))
@@ -187,6 +194,10 @@ def measure_file_to_paf(ref, reads, n_reads, threads, workdir, fastq=False, extr
                    prefetch_driver_wall_s=round(wall2, 2))
         with open(prefix + ".paf", "rb") as f:
             out["paf_lines"] = sum(1 for _ in f)
+        for t in more_threads:  # the same file at other thread counts (strict run)
+            tm, ti, w = run({}, threads=t)
+            out["at_%d_threads" % t] = dict(gbases_s=round(bases / tm / 1e9, 3), map_phase_s=round(tm, 4), index_phase_s=round(ti, 3), driver_wall_s=round(w, 2),
+                                            whole_job_gbases_s=round(bases / w / 1e9, 3))
     finally:
         for fn in (rd, prefix + ".paf"):
             try:
@@ -411,6 +422,24 @@ def main():
                             "DashMap::with_capacity, src/index.rs:83; fresh device memory costs ~30 ms per GB here); the contigs' upload (%.2f s) "
                             "is not in it" % (len(lens), st["table_bytes"] / 1e9, t_upload))
 
+    # what the table's allocation + clear costs by itself (the build above overlaps it with genome synthesis, which a real run does not
+    # have): the same number of bytes allocated and zeroed once more, timed alone
+    try:
+        torch.cuda.synchronize()
+        ta0 = time.perf_counter()
+        scratch_tbl = torch.zeros(int(st["table_bytes"]), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        t_tbl = time.perf_counter() - ta0
+        del scratch_tbl
+        torch.cuda.empty_cache()
+        index_build["table_alloc_and_clear_ms"] = round(t_tbl * 1e3, 2)
+        index_build["ms_with_table_allocation"] = round((t_index + t_tbl) * 1e3, 2)
+        index_build["table_note"] = ("%.1f GB allocated and zeroed by itself right after the build (torch.zeros + synchronize): what a run that cannot hide the "
+                                     "table's allocation behind other work adds to `ms`" % (st["table_bytes"] / 1e9))
+    except Exception as ex:  # noqa: BLE001
+        index_build["table_alloc_and_clear_ms"] = None
+        index_build["table_note"] = repr(ex)[:200]
+
     # ---- this rank's batch of reads, resident in HBM
     t0 = time.time()
     strong = args.scaling == "strong"
@@ -543,7 +572,7 @@ def main():
     # SURVEY.md 8(d)'s second bound: vector-instruction issue.  wave-instructions per launch and the shader clock come from the PMC
     # passes of the same workload (profiles/pmc_issue.json, tools/issue_json.py); the launch time is this run's; the ceiling is
     # what a SIMD issues at map_kernel's occupancy (four waves per SIMD as two 8-wave workgroups per CU) on the instruction mix
-    # of stage B in the microbenchmark (profiles/r04_valu_occ.txt / r04_valu_enc.txt).
+    # of stage B in the microbenchmark (profiles/r03_valu_occ.txt, profiles/r04_valu_enc.txt, profiles/r04_valu_enc_stepb.txt).
     ipath = os.path.join(ROOT, "profiles", "pmc_issue.json")
     if os.path.exists(ipath):
         try:
@@ -559,7 +588,13 @@ def main():
                                              valu=int(ij["valu"]), salu=int(ij["salu"]), lds=int(ij["lds"]), vmem=int(ij["vmem"]), n_simd=n_simd,
                                              busy_cycles_per_launch=int(cyc), cycles_per_instruction=round(cpi, 3),
                                              ceiling_cycles_per_instruction=ij["ceiling_cycles_per_instruction"],
-                                             frac=round(float(ij["ceiling_cycles_per_instruction"]) / cpi, 4), waves_per_simd=ij.get("waves_per_simd"),
+                                             ceiling_scope="stage B's step only (10 VALU + 1 LDS as built, tools/valu_enc.hip, at this kernel's occupancy): a measured "
+                                                           "floor of the kernel's densest loop, not of its whole instruction mix (80 % VALU / 14 % SALU / 6 % LDS over five stages)",
+                                             frac=round(float(ij["ceiling_cycles_per_instruction"]) / cpi, 4),
+                                             hardware_ceiling_cycles_per_instruction=2.0,
+                                             hardware_ceiling_source="/opt/skills/guides/MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32 "
+                                                                     "(one wave alone sustains one per 4)",
+                                             frac_of_hardware_ceiling=round(2.0 / cpi, 4), waves_per_simd=ij.get("waves_per_simd"),
                                              implied_shader_clock_mhz_this_run=round(cyc / avg_kern_s / 1e6, 1),
                                              shader_clock_mhz_in_counter_pass=ij["shader_clock_mhz"],
                                              counters_taken_at_commit=ij.get("commit"), ceiling_source=ij.get("ceiling_source"),
@@ -710,7 +745,8 @@ def main():
                 try:
                     big = reads if args.e2e_fastq_reads <= n else sim.make_reads(genome, ctg_off, args.e2e_fastq_reads, seed=args.seed + 5000, threads=threads)
                     k7 = ["-k", "7", "-l", "31", "-d", "0.01"]
-                    leg("fastq_k7_to_paf", reads=big, n_reads=args.e2e_fastq_reads, threads=ncpu, workdir=wd, fastq=True, extra_args=k7)
+                    # (records found on the device: the reader threads only pread the file -- 2 file bytes per base -- into page-locked chunks)
+                    leg("fastq_k7_to_paf", reads=big, n_reads=args.e2e_fastq_reads, threads=ncpu, workdir=wd, fastq=True, extra_args=k7, more_threads=(4, 8))
                     leg("fasta_k7_to_paf", reads=big, n_reads=args.e2e_fastq_reads, threads=ncpu, workdir=wd, fastq=False, extra_args=k7)
                     a_, b_ = e2e["fastq_k7_to_paf"].get("no_prefetch_gbases_s"), e2e["fasta_k7_to_paf"].get("no_prefetch_gbases_s")
                     e2e["fastq_over_fasta_rate"] = round(a_ / b_, 3) if a_ and b_ else None

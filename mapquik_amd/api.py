@@ -208,7 +208,7 @@ class Index:
 
     @classmethod
     def load(cls, path, device=0):
-        """A finalized index read back from Index.save (its parameters: Index.params(); the mapping-time ones can be replaced with
+        """A finalized index read back from Index.save (its parameters: Index.get_params(); the mapping-time ones can be replaced with
         Index.set_map_params)."""
         L = load_library()
         h = L.mq_index_load(os.fsencode(path), device)
@@ -253,7 +253,7 @@ class Index:
         if self._L.mq_index_set_table_factor(self._h, int(slots_per_kminmer)) != 0:
             raise _err(self._L, "mq_index_set_table_factor")
 
-    def params(self):
+    def get_params(self):
         """The parameters the index was built with (a loaded file's own)."""
         p = Params()
         if self._L.mq_index_get_params(self._h, C.byref(p)) != 0:

@@ -174,7 +174,7 @@ def main(argv=None):
     t0 = time.time()
     if opt.load_index:
         index = api.Index.load(opt.load_index, device=opt.device)
-        fp = index.params()
+        fp = index.get_params()
         if (fp.k, fp.l, fp.density, fp.use_hpc, fp.seeding_variant) != (params.k, params.l, params.density, params.use_hpc, params.seeding_variant):
             raise SystemExit("%s was built with -k %d -l %d -d %s%s --seeding-variant %d: run with the same seeding parameters"
                              % (opt.load_index, fp.k, fp.l, rust_float(fp.density), "" if fp.use_hpc else " --nohpc", fp.seeding_variant))

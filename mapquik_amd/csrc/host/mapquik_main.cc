@@ -100,6 +100,7 @@ struct Opt {
     int device = 0;
     int gpus = 1;
     int seeding_variant = 0;  // MQ_SEEDVAR_* bits (include/mapquik_hip.h)
+    bool last_pass = true;  // no second pass follows this one
     int table_factor = 2;  // table slots per inserted k-min-mer: this driver is bound by its host side (mq_index_set_table_factor)
     std::string save_index, load_index;  // --save-index / --index: the on-disk index (the reference has none and re-indexes on every run)
     std::string second;  // "k2,l2,d2"
@@ -116,6 +117,20 @@ static void usage() {
          "    -b <b>\n    -c, --chain <chain>\n    -d, --density <density>\n    -g, --gap-diff <gap-diff>\n    -k <k>\n    -l <l>\n"
          "    -p, --prefix <prefix>\n    -q <q>\n        --reference <reference>\n    -s, --seed <seed>\n        --threads <threads>\n"
          "        --device <n>    (extension) first HIP device ordinal\n        --gpus <n>      (extension) shard read batches over n GPUs, index replicated\n        --batch-bases <n> (extension) raw input bytes per chunk\n        --table-factor <n> (extension) index table slots per k-min-mer (default 2 here: a file-fed run is host-bound; the library's default for HBM-resident batches is 8)\n        --save-index <file> (extension) write the finalized index (occupied slots only) for later runs\n        --index <file>  (extension) map against a saved index instead of indexing --reference (same -k -l -d --nohpc as it was built with)\n        --seeding-variant <v> (extension) reading of the k-min-mer iterator's unpinned decisions, bits 1 2 4 8 16 32 (include/mapquik_hip.h); 0 = frozen\n        --second-pass <k2,l2,d2> (extension) map the unmapped reads again with these parameters: <prefix>-k2-l2-d2.{fa,paf,unmapped.out}\n\nARGS:\n    <reads>");
+}
+
+// the last two lines of a run (src/main.rs:270-271)
+static void print_totals(Clock::time_point start) {
+    printf("Total execution time: %s\n", rust_duration(secs(start)).c_str());  // src/main.rs:270
+    struct rusage ru;
+    getrusage(RUSAGE_SELF, &ru);
+    const float gb = (float)((double)ru.ru_maxrss * 1024.0) / 1024.0f / 1024.0f / 1024.0f;
+    char fb[64];
+    for (int prec = 1; prec < 12; ++prec) {
+        snprintf(fb, sizeof(fb), "%.*g", prec, (double)gb);
+        if ((float)strtod(fb, nullptr) == gb) break;
+    }
+    printf("Maximum RSS: %sGB\n", strchr(fb, '.') || strchr(fb, 'e') ? fb : (std::string(fb) + ".0").c_str());  // src/main.rs:271
 }
 
 // One run of the reference's flow (src/closures.rs:22-212): index the reference, map the reads, write <prefix>.paf in input
@@ -624,6 +639,14 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                     t_format_us / 1e6, n_format, t_write_us / 1e6);
         printf("Mapped query sequences in %s.\n", rust_duration(secs(t0)).c_str());  // src/closures.rs:211
         tl("PAF written");
+        if (o.last_pass && getenv("MQ_DRIVER_FAST_EXIT") != nullptr) {
+            // EXPERIMENT: the run's output is complete and closed -- leave without unwinding (stream slots, the table, the page-locked
+            // pool: the operating system takes a process's device and host memory back in one go when it ends)
+            print_totals(g_t_main);
+            fflush(stdout);
+            fflush(stderr);
+            _exit(0);
+        }
         for (auto &v : slots) for (auto c : v) mq_ctx_free(c);
         tl("stream slots freed");
     return 0;
@@ -716,6 +739,7 @@ int main(int argc, char **argv) {
     const std::string second_prefix = prefix + "-" + std::to_string(o.k2) + "-" + std::to_string(o.l2) + "-" + rust_float(o.d2);
     try {
         tl("arguments parsed");
+        o.last_pass = o.second.empty();
         int rc = run_pass(o, P, o.reads, reads_fasta, ref_fasta, prefix, threads, o.second.empty() ? std::string() : second_prefix + ".fa");
         tl("run_pass returned (index, feeder and its page-locked pool released)");
         if (rc) return rc;
@@ -726,6 +750,7 @@ int main(int argc, char **argv) {
             P.l = (size_t)o.l2;
             P.density = o.d2;
             printf("Second pass: %s with k=%zu l=%zu density=%s\n", (second_prefix + ".fa").c_str(), P.k, P.l, rust_float(P.density).c_str());
+            o.last_pass = true;
             rc = run_pass(o, P, second_prefix + ".fa", true, ref_fasta, second_prefix, threads, std::string());
             if (rc) return rc;
         }
@@ -734,15 +759,7 @@ int main(int argc, char **argv) {
         fprintf(stderr, "mapquik: %s\n", e.what());
         return 101;
     }
-    printf("Total execution time: %s\n", rust_duration(secs(start)).c_str());  // src/main.rs:270
-    struct rusage ru;
-    getrusage(RUSAGE_SELF, &ru);
-    const float gb = (float)((double)ru.ru_maxrss * 1024.0) / 1024.0f / 1024.0f / 1024.0f;
-    char fb[64];
-    for (int prec = 1; prec < 12; ++prec) {
-        snprintf(fb, sizeof(fb), "%.*g", prec, (double)gb);
-        if ((float)strtod(fb, nullptr) == gb) break;
-    }
-    printf("Maximum RSS: %sGB\n", strchr(fb, '.') || strchr(fb, 'e') ? fb : (std::string(fb) + ".0").c_str());  // src/main.rs:271
+    tl("all passes done");
+    print_totals(start);
     return 0;
 }

@@ -113,3 +113,18 @@ def test_shard_bounds_cover_in_order():
     offs = np.array([0, 10, 10, 35, 100], dtype=np.uint64)
     b, o, lo = shard_reads(bases, offs, 2, 1)
     assert lo == 2 and o.tolist() == [0, 25, 90] and b[0] == 10 and b.size == 90
+
+
+def test_makefile_rebuilds_the_library_for_every_part():
+    """`make` must rebuild libmapquik_hip.so when ANY part of its one translation unit (or either header) changes, and the driver when
+    any host header does: a stale .so would make parity and perf numbers describe old kernels."""
+    import glob
+    import subprocess
+    parts = sorted(glob.glob(os.path.join(ROOT, "mapquik_amd", "csrc", "*.hpp")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    assert len(parts) >= 12
+    for f in parts:
+        r = subprocess.run(["make", "-n", "-W", os.path.relpath(f, ROOT), "mapquik_amd/lib/libmapquik_hip.so"], capture_output=True, text=True, cwd=ROOT)
+        assert r.returncode == 0 and "hipcc" in r.stdout and "mq_capi.hip" in r.stdout, (f, r.stdout[-300:], r.stderr[-300:])
+    for f in sorted(glob.glob(os.path.join(ROOT, "mapquik_amd", "csrc", "host", "*.hpp"))):
+        r = subprocess.run(["make", "-n", "-W", os.path.relpath(f, ROOT), "mapquik_amd/lib/mapquik"], capture_output=True, text=True, cwd=ROOT)
+        assert r.returncode == 0 and "mapquik_main.cc" in r.stdout, (f, r.stdout[-300:])

@@ -42,6 +42,28 @@ with tempfile.TemporaryDirectory(dir=base) as wd:
                 print("      " + ln, flush=True)
 
     NP = {"MQ_DRIVER_NO_PREFETCH": "1"}
+    if os.environ.get("E2E_R5M"):  # round 5: medians of the job's phases over repeated runs, by driver option
+        import statistics
+        def once(extra, env):
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, rd, "--reference", ref, "-p", os.path.join(wd, "o")] + extra, capture_output=True, text=True, timeout=900,
+                               env=dict(os.environ, **env))
+            wall = time.perf_counter() - t0
+            unit = {"s": 1, "ms": 1e-3, "µs": 1e-6, "ns": 1e-9}
+            def grab(pat):
+                m = re.search(pat + r" ([0-9.]+)(s|ms|µs|ns)", r.stdout)
+                return float(m.group(1)) * unit[m.group(2)] if m else float("nan")
+            return wall, grab(r"unique k-min-mers in"), grab(r"Mapped query sequences in"), grab(r"Total execution time:"), r.returncode
+        once(["--threads", "4"], {})
+        reps = int(os.environ["E2E_R5M"])
+        for env in ({}, {"MQ_DRIVER_LATE_SLOTS": "1"}, {"MQ_DRIVER_NO_RESERVE": "1"}, {"MQ_DRIVER_LATE_SLOTS": "1", "MQ_DRIVER_NO_RESERVE": "1"},
+                    {"MQ_DRIVER_FAST_EXIT": "1"}, {"MQ_DRIVER_REF_HOST": "1"}, {"MQ_TABLE_FACTOR": "8"}):
+            for th in (4, 8):
+                rows = [once(["--threads", str(th)], env) for _ in range(reps)]
+                med = lambda i: statistics.median(r[i] for r in rows)
+                print("%-62s %d thr: wall %.3f  index %.3f  map %.3f  total-in-main %.3f  (outside main %.3f)  rc %s" %
+                      (env, th, med(0), med(1), med(2), med(3), med(0) - med(3), {r[4] for r in rows}), flush=True)
+        sys.exit(0)
     if os.environ.get("E2E_R5T"):  # round 5: the whole job's timeline (MQ_DRIVER_TIMING), by table factor and thread count
         def tline(extra, tag, env):
             t0 = time.perf_counter()
