@@ -746,6 +746,9 @@ __device__ __forceinline__ uint32_t seed_stage_r(const SeedTables &T, SeedLds &S
     const uint32_t total = rdlane(incl, 63);
     const uint32_t my_prefix = incl - my_count;
     const uint32_t nw_used = (lc + 31u) >> 5;  // words that can hold a flag at all (wave-uniform)
+#ifdef MQ_STAGE_R_SPLIT  // diagnostic: stage R's time by part -- 12 flags read, masked, counted, scanned; 13 listing; 14 window hashes; 15 raw positions + stores; 2 the rest
+    mq_clk(12);
+#endif
     for (uint32_t r0 = 0; r0 < total; r0 += SD_OWNER_CAP) {  // rounds of SD_OWNER_CAP candidates (one round unless the density is high)
         uint32_t at = my_prefix - r0;  // place of this lane's next candidate in the round's list (wraps below zero before the round)
 #pragma unroll
@@ -762,12 +765,20 @@ __device__ __forceinline__ uint32_t seed_stage_r(const SeedTables &T, SeedLds &S
             }
         }
         wave_sync();
+#ifdef MQ_STAGE_R_SPLIT
+        mq_clk(13);
+#endif
         const uint32_t r1 = total - r0 < SD_OWNER_CAP ? total : r0 + SD_OWNER_CAP;
         for (uint32_t i0 = r0; i0 < r1; i0 += 64u) {
             const uint32_t i = i0 + lane;
             if (i < r1) {
                 const uint32_t j = S.cand[i - r0];
                 const Hash2 wh = window_hash(T, S, P.l, j);
+#ifdef MQ_STAGE_R_SPLIT
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("" ::"v"(wh.flo), "v"(wh.fhi), "v"(wh.rlo), "v"(wh.rhi));
+                mq_clk(14);
+#endif
                 const uint32_t pos = seed_rawpos_batch(S, raw_base, carry_n, j);
                 const uint64_t F = ((uint64_t)wh.fhi << 32) | wh.flo, R = ((uint64_t)wh.rhi << 32) | wh.rlo;
                 const uint64_t hv = F < R ? F : R;
@@ -782,6 +793,9 @@ __device__ __forceinline__ uint32_t seed_stage_r(const SeedTables &T, SeedLds &S
                 if (listed) out.put(dest, list_hash<VAR>(P, hv), VIEW ? rep + V.pos_add : rep, lp);
                 if (VIEW) n_listed += (uint32_t)__popcll(__ballot(listed));
             }
+#ifdef MQ_STAGE_R_SPLIT
+            mq_clk(15);
+#endif
         }
         wave_sync();
     }

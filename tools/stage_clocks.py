@@ -18,6 +18,8 @@ NAMES = ["stage A decode+HPC", "stage B rolling hash", "stage R candidates", "ti
          "A*: wait for bases, super-rows 2, 3", "A*: before the loop, later tiles", "A*: wait for bases, later tiles", "A*: work"]
 # -DMQ_STAGE_MAP_SPLIT builds instead: 12 = keys arrived + compared, payloads requested; 13 = lookups walking on; 14 = payloads arrived;
 # "probe resolve + runs" = the runs alone.
+# -DMQ_STAGE_R_SPLIT builds instead: 12 = stage R's flags read, masked, counted and scanned; 13 = its listing passes; 14 = its window hashes;
+# 15 = its raw positions and list stores; "stage R candidates" = the rest of it.
 # A*: builds with -DMQ_STAGE_A_SPLIT only; then "stage A" = wait for the bases of a sequence's first super-row, "general seeder" = what
 # precedes the loop in a sequence's first tile (every stamp costs the wave an s_memtime round trip: ~400 cycles)
 
