@@ -143,13 +143,15 @@ int64_t mq_index_add_ref_device(mq_index *idx, uint32_t ref_id, const char *name
  *   mq_index_stage_piece(idx, at, src, n, &t)    queues the copy of src[0, n) to buffer offset `at` and returns; src (page-locked memory,
  *                                                mq_host_alloc, for the link's full rate) must stay untouched until
  *   mq_index_stage_done(idx, t, wait)            returns 1 (copied; src may be reused), 0 (not yet; only with wait == 0) or <0
- *   mq_index_add_ref_staged(idx, id, name, at, len)  = mq_index_add_ref_device on buffer[at, at + len), ordered behind every piece issued
- *                                                so far (the caller issues a record's pieces before it asks for the record)
+ *   mq_index_add_ref_staged(idx, id, name, at, len, t)  = mq_index_add_ref_device on buffer[at, at + len), ordered (on the device) behind
+ *                                                piece t and every piece issued before it -- the last piece that holds bytes of the
+ *                                                record -- or, t = MQ_STAGE_ALL_ISSUED, behind every piece issued so far
  * Pieces may be issued from one thread while another asks for records.  The buffer is released by mq_index_finalize. */
+#define MQ_STAGE_ALL_ISSUED (~(uint64_t)0)
 int mq_index_stage_begin(mq_index *idx, uint64_t total_bytes);
 int mq_index_stage_piece(mq_index *idx, uint64_t at, const uint8_t *src, uint64_t n, uint64_t *ticket);
 int mq_index_stage_done(mq_index *idx, uint64_t ticket, int wait);
-int64_t mq_index_add_ref_staged(mq_index *idx, uint32_t ref_id, const char *name, uint64_t at, uint64_t len);
+int64_t mq_index_add_ref_staged(mq_index *idx, uint32_t ref_id, const char *name, uint64_t at, uint64_t len, uint64_t after_ticket);
 
 /* DashMap::with_capacity (src/index.rs:83 sizes its map for 39,821,990 k-min-mers at Index::new): a hint that about
  * expected_kminmers k-min-mers will be inserted.  The table is allocated and cleared in the background while the references are

@@ -122,7 +122,7 @@ def load_library(path=None):
         L.mq_index_stage_piece.argtypes = [vp, u64, vp, u64, C.POINTER(u64)]
         L.mq_index_stage_done.argtypes = [vp, u64, C.c_int]
         L.mq_index_add_ref_staged.restype = C.c_int64
-        L.mq_index_add_ref_staged.argtypes = [vp, u32, C.c_char_p, u64, u64]
+        L.mq_index_add_ref_staged.argtypes = [vp, u32, C.c_char_p, u64, u64, u64]
         L.mq_host_register.argtypes = [vp, C.c_size_t]
         L.mq_host_unregister.argtypes = [vp]
         L.mq_ctx_submit_fasta.argtypes = [vp, vp, u64, u64]
@@ -286,8 +286,10 @@ class Index:
             raise _err(self._L, "mq_index_stage_done")
         return bool(r)
 
-    def add_ref_staged(self, ref_idx, name, at, length):
-        n = self._L.mq_index_add_ref_staged(self._h, ref_idx, name.encode(), int(at), int(length))
+    def add_ref_staged(self, ref_idx, name, at, length, after_ticket=None):
+        """ref_extract of the staging buffer's [at, at + length), behind piece `after_ticket` (None: every piece issued so far)."""
+        t = 0xFFFFFFFFFFFFFFFF if after_ticket is None else int(after_ticket)
+        n = self._L.mq_index_add_ref_staged(self._h, ref_idx, name.encode(), int(at), int(length), t)
         if n < 0:
             raise _err(self._L, "mq_index_add_ref_staged")
         return n

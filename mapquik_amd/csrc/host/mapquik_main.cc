@@ -296,7 +296,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             feeder::RefStreamer rs(o.reference, n_parse, hooks);
             std::vector<std::string> lines;  // printed once the file's shape is known to be regular (else the loader below prints its own)
             const feeder::RefStreamer::Result res = rs.run([&](size_t k, const std::string &id, uint64_t at, uint64_t len) {
-                const int64_t cnt = mq_index_add_ref_staged(h, (uint32_t)k, id.c_str(), at, len);  // index_mers, src/closures.rs:46-51
+                const int64_t cnt = mq_index_add_ref_staged(h, (uint32_t)k, id.c_str(), at, len, MQ_STAGE_ALL_ISSUED);  // index_mers, src/closures.rs:46-51
                 if (cnt < 0) throw Error("ref_extract: " + last_error());
                 lines.push_back("Indexed reference " + id + ": " + std::to_string(cnt) + " k-min-mers.");  // src/closures.rs:58
             });

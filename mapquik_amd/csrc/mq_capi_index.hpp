@@ -299,7 +299,7 @@ int mq_index_stage_done(mq_index *idx, uint64_t ticket, int wait) try {
     return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
-int64_t mq_index_add_ref_staged(mq_index *idx, uint32_t ref_id, const char *name, uint64_t at, uint64_t len) try {
+int64_t mq_index_add_ref_staged(mq_index *idx, uint32_t ref_id, const char *name, uint64_t at, uint64_t len, uint64_t after_ticket) try {
     if (!idx) return set_err(MQ_EINVAL, "idx is NULL");
     int rc = use_device(idx);
     if (rc) return rc;
@@ -308,8 +308,11 @@ int64_t mq_index_add_ref_staged(mq_index *idx, uint32_t ref_id, const char *name
         std::lock_guard<std::mutex> lk(idx->stg_mu);
         if (!idx->stg_buf) return set_err(MQ_ESTATE, "mq_index_add_ref_staged before mq_index_stage_begin");
         if (at > idx->stg_bytes || len > idx->stg_bytes - at) return set_err(MQ_EINVAL, "record outside the staging buffer");
-        // the build's kernels run on the null stream: it waits (on the device, not here) for every piece issued so far
-        if (idx->stg_issued) HIPCHK(hipStreamWaitEvent(0, idx->stg_events[(size_t)idx->stg_issued - 1], 0));
+        // the build's kernels run on the null stream: it waits (on the device, not here) for the piece named (pieces complete in issue
+        // order, so for every piece up to it), or for every piece issued so far
+        if (after_ticket != MQ_STAGE_ALL_ISSUED && after_ticket >= idx->stg_issued) return set_err(MQ_EINVAL, "unknown ticket");
+        const uint64_t upto = after_ticket == MQ_STAGE_ALL_ISSUED ? idx->stg_issued : after_ticket + 1;
+        if (upto) HIPCHK(hipStreamWaitEvent(0, idx->stg_events[(size_t)upto - 1], 0));
         d_seq = idx->stg_buf + at;
     }
     std::lock_guard<std::mutex> lk(idx->mu);

@@ -106,8 +106,9 @@ int mq_index_stage_done(mq_index *i, uint64_t ticket, int) {
     if (ticket >= i->stage_tickets) { g_err = "unknown ticket"; return MQ_EINVAL; }
     return 1;
 }
-int64_t mq_index_add_ref_staged(mq_index *i, uint32_t id, const char *name, uint64_t at, uint64_t len) {
+int64_t mq_index_add_ref_staged(mq_index *i, uint32_t id, const char *name, uint64_t at, uint64_t len, uint64_t after) {
     std::lock_guard<std::mutex> lk(i->stage_mu);
+    if (after != MQ_STAGE_ALL_ISSUED && after >= i->stage_tickets) { g_err = "unknown ticket"; return MQ_EINVAL; }
     if (!i->stage_begun || at + len + 1 > i->stage.size()) { g_err = "record outside the staging buffer"; return MQ_EINVAL; }
     return mq_index_add_ref(i, id, name, i->stage.data() + at, len);
 }

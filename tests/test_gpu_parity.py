@@ -133,8 +133,8 @@ def test_crowded_table_long_probe_walks(mq, oracle, simlib, monkeypatch, tmp_pat
     assert np.array_equal(d_h.to_numpy(mq.hit_dtype, offs.size - 1).view(np.uint8), hits.view(np.uint8))
 
 
-def _map_both(mq, oracle, g, off, names, reads, ps):
-    P, po = mq.Params(**ps), oracle.params(**ps)
+def _map_both(mq, oracle, g, off, names, reads, ps, variant=0):
+    P, po = mq.Params(seeding_variant=variant, **ps), oracle.params(**ps)
     ix, ox = mq.Index(P), oracle.Index()
     for r in range(off.size - 1):
         s = g[int(off[r]):int(off[r + 1])]
@@ -612,14 +612,25 @@ def test_fuzz_params_and_sequences(mq, oracle, simlib):
                 seg[:] = np.where(np.arange(seg.size) % 2 == 0, ord("A"), ord("C"))
         reads2 = dict(reads)
         reads2["bases"] = bases
-        ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads2, ps)
-        _cmp_hits(hits, want)
-        got = ix.kminmers_batch(bases, offs)
-        po = oracle.params(**ps)
-        for i in range(0, 40, 3):
-            s = bases[int(offs[i]):int(offs[i + 1])]
-            w = oracle.kminmers(s, po) if s.size >= po.l + po.k - 1 else np.zeros(0, dtype=oracle.kminmer_dtype)
-            _cmp_kmm(got[i], w, (it, ps, i))
+        # every third case under another reading of the third-party k-min-mer iterator (mq_params.flags bits 8..13 = the oracle's
+        # mqo_set_variant; bit 8 needs l >= 2): the variants' code paths see the same damaged inputs as the frozen reading's
+        variant = 0
+        if it % 3 == 2:
+            variant = int(rng.choice([1, 2, 4, 8, 16, 32, 12, 24, 28, 63]))
+            if l < 2:
+                variant &= ~8
+        oracle.lib().mqo_set_variant(variant)
+        try:
+            ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads2, ps, variant)
+            _cmp_hits(hits, want)
+            got = ix.kminmers_batch(bases, offs)
+            po = oracle.params(**ps)
+            for i in range(0, 40, 3):
+                s = bases[int(offs[i]):int(offs[i + 1])]
+                w = oracle.kminmers(s, po) if s.size >= po.l + po.k - 1 else np.zeros(0, dtype=oracle.kminmer_dtype)
+                _cmp_kmm(got[i], w, (it, ps, variant, i))
+        finally:
+            oracle.lib().mqo_set_variant(0)
 
 
 def test_no_device_memory_growth(mq, simlib):

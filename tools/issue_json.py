@@ -14,7 +14,7 @@ import sys
 
 pmc, bench, ceiling, source = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
 commit = sys.argv[5] if len(sys.argv) > 5 else subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-KERN = "map_kernel<64, false>"
+KERN = "map_kernel<64, false, false>"
 v = {}
 for ln in open(pmc + "/summary.txt"):
     m = re.match(r"(\S.*?)\s{2,}(\S+)\s+per-launch\s+(\S+)", ln)

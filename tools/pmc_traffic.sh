@@ -18,7 +18,7 @@ agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(sys.argv[1] + "/p/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         kn = re.sub(r"^void ", "", re.sub(r"\(.*", "", row.get("Kernel_Name", "")))
-        if any(t in kn for t in ("map_kernel<64, false>", "seed_reads_kernel", "map_lists_kernel<64, false>", "seed_general")):
+        if any(t in kn for t in ("map_kernel<64, false, false>", "seed_reads_kernel", "map_lists_kernel<64, false>", "seed_general")):
             agg[kn][0] += float(row["Counter_Value"]); agg[kn][1] += 1
 for k in sorted(agg):
     print("%s %s %s %.6g %d" % (sys.argv[2], sys.argv[3], k.replace(" ", ""), agg[k][0] / max(agg[k][1], 1), agg[k][1]))

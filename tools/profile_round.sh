@@ -23,4 +23,4 @@ python3 tools/traffic_json.py $OUT/traffic/raw.txt $OUT/bench_stats.json "$(cat 
 python3 tools/issue_json.py $OUT/pmc $OUT/bench_stats.json ${CEILING_CPI:-2.51} "${CEILING_SRC:-profiles/r04_valu_enc_stepb.txt: stage-B step as built (10 VALU, SDWA table offset): 25.1 cycles per step at 4 waves per SIMD as two 8-wave workgroups per CU}" "$(cat $ROOT/.commit 2>/dev/null || echo unknown)" > $OUT/pmc_issue.json 2> $OUT/issue_json.err
 if [ -f mapquik_amd/lib/clk4.so ]; then MQ_LIB=$ROOT/mapquik_amd/lib/clk4.so python3 tools/stage_clocks.py 2>&1 | grep -v amdgpu.ids > $OUT/stage_clocks.txt; fi
 python3 tools/probe_rate.py > $OUT/probe_rate.txt 2>&1
-head -3 $OUT/kernel_stats.csv; cat $OUT/pmc/summary.txt | grep "map_kernel<64, false>"; cat $OUT/traffic/raw.txt; cat $OUT/stage_clocks.txt; tail -12 $OUT/probe_rate.txt; tail -c 1200 $OUT/bench_stats.json
+head -3 $OUT/kernel_stats.csv; cat $OUT/pmc/summary.txt | grep "map_kernel<64, false, false>"; cat $OUT/traffic/raw.txt; cat $OUT/stage_clocks.txt; tail -12 $OUT/probe_rate.txt; tail -c 1200 $OUT/bench_stats.json

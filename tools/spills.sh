@@ -16,7 +16,7 @@ for l in L:
     m=re.search(r'Depth=(\d+)',l)
     if m and l.startswith('.LBB'): depth=int(m.group(1))
     elif l.startswith('.LBB'): depth=0
-    if 'scratch_' in l and k and os.environ.get("SPILL_KERNEL","map_kernelILi64ELb0") in k:
+    if 'scratch_' in l and k and os.environ.get("SPILL_KERNEL","map_kernelILi64ELb0ELb0") in k:
         kind='store' if 'store' in l else 'load'
         key=(loc,depth,kind)
         out[key]=out.get(key,0)+1

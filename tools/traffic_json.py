@@ -25,7 +25,7 @@ rocprof = None
 if len(sys.argv) > 4:
     import csv
     for row in csv.DictReader(open(sys.argv[4])):
-        if row["Name"].startswith("void map_kernel<64, false>"):
+        if row["Name"].startswith("void map_kernel<64, false, false>"):
             rocprof = {"calls": int(row["Calls"]), "average_ms": round(float(row["AverageNs"]) / 1e6, 4), "min_ms": round(float(row["MinNs"]) / 1e6, 4),
                        "max_ms": round(float(row["MaxNs"]) / 1e6, 4)}
 out = {
