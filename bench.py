@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--k", type=int, default=5, help="k-min-mer order (BASELINE config 4, experiments/table1.sh:50, runs -k 7)")
     ap.add_argument("--l", type=int, default=31)
     ap.add_argument("--density", type=float, default=0.01)
+    ap.add_argument("--seeding-variant", type=int, default=0,
+                    help="reading of the third-party k-min-mer iterator's unpinned decisions (mq_params.flags bits 8..13, include/mapquik_hip.h; "
+                         "0 = the frozen reading, the BASELINE configuration): the oracle is switched to the same variant for the column checks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end measurements (host buffers -> hits, file -> PAF)")
     ap.add_argument("--e2e-file-reads", type=int, default=196608, help="reads written to the FASTA the native driver maps")
@@ -382,7 +385,12 @@ def main():
 
     ncpu = effective_cpus()
     threads = max(1, ncpu // world)
-    P = mq.Params(k=args.k, l=args.l, density=args.density)  # defaults k=5 l=31 d=0.01, HPC on, c=4 s=11 g=2000 (src/main.rs:174-188)
+    P = mq.Params(k=args.k, l=args.l, density=args.density, seeding_variant=args.seeding_variant)  # defaults k=5 l=31 d=0.01, HPC on, c=4 s=11 g=2000 (src/main.rs:174-188)
+    if args.seeding_variant:  # the checker follows (a process-wide switch of the oracle; legs with their own Params are skipped below)
+        from oracle import oracle as _O
+        _O.lib().mqo_set_variant(args.seeding_variant)
+        args.no_configs = True
+        args.no_e2e = True
 
     # ---- a real reference (and real reads) when given: BASELINE configs 3 / 4 the day the files are on the box
     real_ref = args.reference_fasta is not None
@@ -784,6 +792,7 @@ def main():
                                "human-like repeats: 6% satellite arrays, 5% segmental duplications, young interspersed copies" if args.genome_preset == "human-like"
                                else "%g%% planted repeats + %g%% tandem arrays" % (100 * args.repeat_frac, 100 * args.tandem_frac),
                                args.k, args.l, args.density),
+                "seeding_variant": args.seeding_variant,
                 "reads_per_step_per_gpu": n,
                 "bases_per_step_per_gpu": total_bases,
                 "index_unique_kminmers": int(n_unique),

@@ -142,9 +142,19 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         FILE *unm = (o.unmapped || !o.second.empty()) ? fopen((prefix + ".unmapped.out").c_str(), "w") : nullptr;
         FILE *ufa = second_fa.empty() ? nullptr : fopen(second_fa.c_str(), "w");  // the unmapped reads as FASTA (seqtk subseq in the reference's script)
 
+        // An uncompressed reference FASTA is read into host memory (all threads, ref_loader.hpp) from HERE on -- before the first HIP call:
+        // bringing the HIP runtime up takes 0.15-0.3 s of one thread, reading 3.1 GB 0.08-0.1 s of the others.  --low-memory: not at
+        // all; the file is streamed through a small pool of page-locked blocks instead (RefStreamer, below).
+        const int n_parse = (int)std::max<size_t>(1, threads);
+        const bool ref_plain = ref_fasta && !ends_with(o.reference, ".gz") && !ends_with(o.reference, ".lz4");
+        const bool ref_host = getenv("MQ_DRIVER_REF_HOST") != nullptr;  // diagnostic: earlier rounds' path (records copied from pageable memory one by one)
+        std::unique_ptr<feeder::RefLoader> preload;
+        if (ref_plain && o.load_index.empty() && !o.low_memory) preload.reset(new feeder::RefLoader(o.reference, n_parse, !ref_host));
+
         // --gpus N: the index is replicated (every GPU indexes the same reference), read batches are dealt round-robin,
         // PAF lines are written in batch order = input order.  No collective: reads are independent.
         const int n_dev = mq_device_count();
+        tl("HIP runtime up (first HIP call returned)");
         const bool fake = getenv("MQ_FAKE_MULTI") != nullptr;  // test hook: several workers on one device
         if (!fake && o.device + o.gpus > n_dev && n_dev > 0) {
             fprintf(stderr, "mapquik: --gpus %d from device %d needs %d devices, %d visible\n", o.gpus, o.device, o.device + o.gpus, n_dev);
@@ -154,7 +164,6 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
 
         // The read feeder (constructed here, started below): parsing reads does not depend on the index.
         using feeder::Chunk;
-        const int n_parse = (int)std::max<size_t>(1, threads);
         const int n_slots = 3;  // stream slots per GPU: copy-in, kernels and copy-out of consecutive chunks overlap
         const int n_format = std::max(2, std::min(8, n_parse));  // PAF formatters (the reader threads of a mapped FASTA file have next to nothing to do)
         feeder::Feeder feed(reads_path, !reads_fasta, o.batch_bases, n_parse, n_parse + o.gpus * (n_slots + 1) + n_format + 2);
@@ -187,8 +196,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             building[0]->table_factor((uint32_t)o.table_factor);
             tl("Index::new returned (HIP runtime up, device chosen)");
         }
-        const bool ref_plain = ref_fasta && !ends_with(o.reference, ".gz") && !ends_with(o.reference, ".lz4");
-        const bool stream_ref = ref_plain && o.load_index.empty() && getenv("MQ_DRIVER_REF_HOST") == nullptr;  // RefStreamer (below)
+        const bool stream_ref = ref_plain && o.load_index.empty() && o.low_memory && !ref_host;  // RefStreamer (below)
         // The stream slots of the map phase (device staging, minimizer lists, Match scratch: a few hundred MB of device memory per
         // submitting thread) and the feeder's first page-locked chunk buffers depend on neither the reference nor the reads: the first
         // GPU's are set up by a thread of its own BESIDE the reference phase (0.03-0.04 s of a 0.1-s phase when they came after it).
@@ -240,6 +248,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             }
         };
         bool ref_done = false;
+        bool res_streamer_used = false;  // the streamer ran (and gave the file back): the index's staging buffer holds its pieces
         std::unique_ptr<ReadOnlyIndex> loaded;
         if (!o.load_index.empty()) {
             // --index: the finalized table from a file written by --save-index (occupied slots only; validated against its header on load)
@@ -264,9 +273,9 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             ref_done = true;
             tl("index file loaded");
         } else {
-            if (stream_ref) {
-                // the staging buffer of the streamed reference FIRST: device allocations queue behind each other, and this one (the file's
-                // size) must not wait behind the table's, which is several times larger and not needed before the last record is indexed
+            if (stream_ref || (preload && !ref_host)) {
+                // the device's staging buffer of the reference FIRST: device allocations queue behind each other, and this one (the file's
+                // size) must not wait behind the table's, which is larger and not needed before the last record is indexed
                 struct stat rst;
                 if (stat(o.reference.c_str(), &rst) != 0) throw Error("Error opening compressed file: " + o.reference);  // get_reader's message (src/main.rs:62)
                 if (mq_index_stage_begin(building[0]->handle(), (uint64_t)rst.st_size) != MQ_OK) throw Error("mq_index_stage_begin: " + last_error());
@@ -295,6 +304,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             };
             feeder::RefStreamer rs(o.reference, n_parse, hooks);
             std::vector<std::string> lines;  // printed once the file's shape is known to be regular (else the loader below prints its own)
+            res_streamer_used = true;
             const feeder::RefStreamer::Result res = rs.run([&](size_t k, const std::string &id, uint64_t at, uint64_t len) {
                 const int64_t cnt = mq_index_add_ref_staged(h, (uint32_t)k, id.c_str(), at, len, MQ_STAGE_ALL_ISSUED);  // index_mers, src/closures.rs:46-51
                 if (cnt < 0) throw Error("ref_extract: " + last_error());
@@ -320,17 +330,96 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         }
         if (ref_done) {
         } else if (ref_plain) {
-            // an uncompressed FASTA: the whole file read once by all threads, records handed over whole and in order (ref_loader.hpp)
-            feeder::RefLoader rl(o.reference, n_parse);
-            tl("reference loader constructed");
+            // an uncompressed FASTA: the whole file read once by all threads (since before the HIP runtime came up), multi-line records
+            // compacted in place by a pool, records handed over whole and in order (ref_loader.hpp).  The buffer is page-locked in one
+            // call (huge pages: milliseconds), every record's bytes are queued for the device the moment the record is ready
+            // (mq_index_stage_piece: the link runs at its full rate, 3.1 GB in 0.06 s) and a second thread indexes record after record
+            // behind its piece (mq_index_add_ref_staged) -- copied record by record from pageable memory this was 0.24 s.
+            if (!preload) preload.reset(new feeder::RefLoader(o.reference, n_parse, false));  // (the streamer above sent the file here)
+            feeder::RefLoader &rl = *preload;
+            rl.wait_read();
+            tl("reference file in host memory");
+            mq_index *h = building[0]->handle();
+            struct stat rst;
+            bool staged = !ref_host && stat(o.reference.c_str(), &rst) == 0 && (uint64_t)rst.st_size == rl.file_bytes();
+            if (staged && res_streamer_used) staged = false;  // (the staging buffer of an index the streamer gave up on may be gone)
+            bool locked = false;
+            if (staged) {
+                locked = mq_host_register(rl.data(), (size_t)rl.mapped_bytes()) == MQ_OK;  // (not locked: the copies still work, at the pageable rate)
+                tl(locked ? "reference buffer page-locked" : "reference buffer could not be page-locked: pageable copies");
+            }
+            struct Job {
+                size_t idx;
+                std::string id;
+                uint64_t at, len, ticket;
+            };
+            std::mutex jmu;
+            std::condition_variable jcv;
+            std::deque<Job> jobs;
+            bool jobs_done = false;
+            std::string jerr;
+            std::vector<std::string> lines;
+            std::thread indexer;
+            if (staged)
+                indexer = std::thread([&]() {
+                    for (;;) {
+                        Job j;
+                        {
+                            std::unique_lock<std::mutex> lk(jmu);
+                            jcv.wait(lk, [&] { return !jobs.empty() || jobs_done; });
+                            if (jobs.empty()) return;
+                            j = std::move(jobs.front());
+                            jobs.pop_front();
+                        }
+                        const int64_t cnt = mq_index_add_ref_staged(h, (uint32_t)j.idx, j.id.c_str(), j.at, j.len, j.ticket);  // index_mers, src/closures.rs:46-51
+                        if (cnt < 0) {
+                            std::lock_guard<std::mutex> lk(jmu);
+                            if (jerr.empty()) jerr = "ref_extract: " + last_error();
+                            return;
+                        }
+                        printf("Indexed reference %s: %lld k-min-mers.\n", j.id.c_str(), (long long)cnt);  // src/closures.rs:58
+                    }
+                });
             size_t ref_idx = 0;
-            rl.for_each([&](const feeder::RefLoader::Record &r, const uint8_t *seq) {
-                if (ref_idx == 0) tl("reference file read, first record ready");
-                if (prefetch) start_feed();  // the whole file has been read by now: the host threads are free
-                const size_t cnt = mers::ref_extract(ref_idx, r.id, seq, r.len, P, *building[0]);
-                printf("Indexed reference %s: %zu k-min-mers.\n", r.id.c_str(), cnt);  // src/closures.rs:58
-                ++ref_idx;
-            });
+            std::string ferr;
+            uint64_t last_ticket = 0;
+            bool any_ticket = false;
+            try {
+                rl.for_each([&](const feeder::RefLoader::Record &r, const uint8_t *seq) {
+                    if (ref_idx == 0) tl("first reference record ready");
+                    if (prefetch) start_feed();  // the whole file has been read by now: the host threads are free
+                    if (staged) {
+                        uint64_t t = 0;
+                        if (mq_index_stage_piece(h, r.seq, seq, r.len, &t) != MQ_OK) throw Error("mq_index_stage_piece: " + last_error());
+                        last_ticket = t;
+                        any_ticket = true;
+                        {
+                            std::lock_guard<std::mutex> lk(jmu);
+                            if (!jerr.empty()) throw Error(jerr);
+                            jobs.push_back(Job{ref_idx, r.id, r.seq, r.len, t});
+                        }
+                        jcv.notify_all();
+                    } else {
+                        const size_t cnt = mers::ref_extract(ref_idx, r.id, seq, r.len, P, *building[0]);
+                        printf("Indexed reference %s: %zu k-min-mers.\n", r.id.c_str(), cnt);  // src/closures.rs:58
+                    }
+                    ++ref_idx;
+                });
+            } catch (const std::exception &e) { ferr = e.what(); }
+            {
+                std::lock_guard<std::mutex> lk(jmu);
+                jobs_done = true;
+                if (!ferr.empty()) jobs.clear();
+            }
+            jcv.notify_all();
+            if (indexer.joinable()) indexer.join();
+            // the copies read the buffer until the last piece is done (a record too short to be seeded is "indexed" without waiting for its piece)
+            if (any_ticket) mq_index_stage_done(h, last_ticket, 1);
+            if (locked) mq_host_unregister(rl.data());
+            if (!ferr.empty()) throw Error(ferr);
+            if (!jerr.empty()) throw Error(jerr);
+            tl("every reference record indexed");
+            preload.reset();
         } else {
             // compressed (or FASTQ) reference: through the chunked feeder, pageable chunk buffers (every reference byte is copied to
             // the device exactly once)

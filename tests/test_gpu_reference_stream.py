@@ -80,14 +80,20 @@ def test_streamed_reference_equals_host_loader_and_oracle(world, shape):
     w = world
     ref = w["wd"] / ("ref_%s.fa" % shape)
     _write_ref(ref, w, nl=b"\r\n" if shape == "crlf" else b"\n", final=shape != "nofinal", lower=shape == "lower", blank_between=shape == "blank_between")
-    r, paf = _run(w, ref)
-    assert "reference streamed: every record handed to ref_extract" in r.stderr, r.stderr[-1500:]
-    assert paf == w["want_txt"] and len(paf) > 50000
     want_lines = ["Indexed reference %s: %d k-min-mers." % (n, c) for n, c in zip(w["names"], w["counts"])]
+    # default: the file read into host memory while the HIP runtime comes up, page-locked, every record's bytes queued for the device
+    r, paf = _run(w, ref)
+    assert "reference buffer page-locked" in r.stderr and "every reference record indexed" in r.stderr, r.stderr[-1500:]
+    assert paf == w["want_txt"] and len(paf) > 50000
     assert _index_lines(r.stdout) == want_lines
     assert "Indexed %d unique k-min-mers in " % w["unique"] in r.stdout
+    # --low-memory: never in host memory -- streamed through a pool of page-locked 16-MB blocks
+    r1, paf1 = _run(w, ref, extra=["--low-memory"])
+    assert "reference streamed: every record handed to ref_extract" in r1.stderr, r1.stderr[-1500:]
+    assert paf1 == paf and _index_lines(r1.stdout) == want_lines
+    # earlier rounds' path: records copied from pageable memory one by one
     r2, paf2 = _run(w, ref, env={"MQ_DRIVER_REF_HOST": "1"})
-    assert "reference streamed" not in r2.stderr and paf2 == paf and _index_lines(r2.stdout) == want_lines
+    assert "reference streamed" not in r2.stderr and "page-locked" not in r2.stderr and paf2 == paf and _index_lines(r2.stdout) == want_lines
 
 
 def test_other_reference_shapes_fall_back_to_the_host_loader(world):
@@ -98,11 +104,15 @@ def test_other_reference_shapes_fall_back_to_the_host_loader(world):
     want_lines = ["Indexed reference %s: %d k-min-mers." % (n, c) for n, c in zip(w["names"], w["counts"])]
     wrapped = w["wd"] / "ref_wrapped.fa"
     _write_ref(wrapped, w, wrap=80)
-    r, paf = _run(w, wrapped)
+    r, paf = _run(w, wrapped)  # the default loader joins the lines of a wrapped record in place before its bytes go to the device
+    assert "reference buffer page-locked" in r.stderr and paf == w["want_txt"] and _index_lines(r.stdout) == want_lines
+    r, paf = _run(w, wrapped, extra=["--low-memory"])
     assert "reference is not one line per record: host loader" in r.stderr and paf == w["want_txt"] and _index_lines(r.stdout) == want_lines
     late = w["wd"] / "ref_late_wrap.fa"
     _write_ref(late, w, wrap=70, wrap_from=2)
     r, paf = _run(w, late)
+    assert paf == w["want_txt"] and _index_lines(r.stdout) == want_lines
+    r, paf = _run(w, late, extra=["--low-memory"])
     assert "reference is not one line per record: host loader" in r.stderr and paf == w["want_txt"] and _index_lines(r.stdout) == want_lines
     junk = w["wd"] / "ref_junk.fa"
     junk.write_bytes(b"this is not FASTA\n>a\nACGT\n")
@@ -139,7 +149,7 @@ def test_stage_api_pieces_in_any_order(mq, oracle, simlib):
     for r in range(3):
         pos += len(names[r]) + 2
         n = int(off[r + 1] - off[r])
-        got.append(b.add_ref_staged(r, names[r], pos, n))
+        got.append(b.add_ref_staged(r, names[r], pos, n, after_ticket=None if r != 1 else tickets[-1]))  # (every piece issued so far / behind the last one)
         pos += n + 1
     assert got == want
     assert all(b.stage_done(t, wait=True) for t in tickets)
@@ -158,6 +168,8 @@ def test_stage_api_pieces_in_any_order(mq, oracle, simlib):
         c.stage_begin(100)                   # one buffer per index
     with pytest.raises(mq.MapquikError):
         c.add_ref_staged(0, "x", 50, 51)
+    with pytest.raises(mq.MapquikError):
+        c.add_ref_staged(0, "x", 0, 10, after_ticket=5)   # a ticket nobody was given
     for x in (a, b, c):
         x.close()
     pin.close()
