@@ -82,14 +82,7 @@ class Feeder {
                 }
             }
         }
-        if (kind_ == 0 && fastq_ && file_size_ > 0 && !getenv("MQ_FEEDER_NO_LEAN_FASTQ")) {
-            const uint8_t *m = (const uint8_t *)mmap(nullptr, file_size_, PROT_READ, MAP_SHARED, fd_, 0);
-            if (m != MAP_FAILED) {
-                map_ = m;
-                map_size_ = file_size_;
-                lean_fastq_ = true;
-            }
-        }
+        if (kind_ == 0 && fastq_ && file_size_ > 0 && !getenv("MQ_FEEDER_NO_LEAN_FASTQ")) lean_fastq_ = true;
         if (kind_ == 0 || kind_ == 3) {
             if (chunk_bytes_ > file_size_ + 1) chunk_bytes_ = file_size_ + 1;
             n_raw_chunks_ = (size_t)((file_size_ + chunk_bytes_ - 1) / chunk_bytes_);
@@ -379,17 +372,57 @@ class Feeder {
         worker_done(err);
     }
 
-    // uncompressed FASTQ: chunk i owns the records whose first byte lies in [i*CH, (i+1)*CH) of the mapped file and copies their
-    // header and sequence lines ("@id ...\nSEQ\n") into its buffer; '+' and quality lines stay where they are, untouched
+    // uncompressed FASTQ, lean: chunk i owns the records whose first byte lies in [i*CH, (i+1)*CH) of the file and reads their header and
+    // sequence lines -- and nothing else -- straight into its page-locked buffer: one pread per record of about the record's header +
+    // sequence length (estimated from the records before it; what it reads too much, the start of the '+' and quality lines, is
+    // overwritten by the next record), the '+' line found in that surplus, and ONE byte read at the place where the quality line must
+    // end if it is as long as the sequence line (the validator's test, fastq_record_at).  Half the file's bytes never leave the page
+    // cache: 1 byte per base from the file and over the link instead of 2 (a reader that maps the file pays for the page tables of
+    // all of it: 12-17 GB/s at any thread count, profiles/r04_file_h2d.txt; this one runs at pread's rate).
     void lean_fastq_worker() {
         std::string err;
         try {
-            const uint8_t *m = map_;
             const uint64_t end = file_size_;
-            auto line_end = [&](uint64_t from) -> uint64_t {
-                const uint8_t *e = (const uint8_t *)memchr(m + from, '\n', end - from);
-                return e ? (uint64_t)(e - m) : end;
+            std::vector<uint8_t> win;  // scratch of the boundary searches
+            auto rd = [&](uint8_t *dst, uint64_t off, uint64_t n) {
+                uint64_t got = 0;
+                while (got < n) {
+                    const ssize_t r = pread(fd_, dst + got, n - got, (off_t)(off + got));
+                    if (r <= 0) throw FeederError("read error: " + path_);
+                    got += (uint64_t)r;
+                }
             };
+            // first record start at or after `from`, decided like the chunked reader's cut (next_record_start over a window that grows until
+            // the validator can tell)
+            auto record_start_from = [&](uint64_t from) -> uint64_t {
+                uint64_t W = 1u << 18;
+                for (;;) {
+                    const uint64_t a = from - 1, b = std::min<uint64_t>(end, from + W);
+                    win.resize((size_t)(b - a));
+                    rd(win.data(), a, b - a);
+                    const uint64_t r = next_record_start(win.data(), 1, b - a, true, b >= end);
+                    if (r != NEED_MORE) return a + r;
+                    W *= 4;
+                }
+            };
+            auto byte_at = [&](uint64_t off) -> uint8_t {
+                uint8_t x = 0;
+                rd(&x, off, 1);
+                return x;
+            };
+            // the line end at or after `from` (file offsets), read in small steps: only for what the surplus of a record's read did not hold
+            auto line_end_from = [&](uint64_t from) -> uint64_t {
+                uint8_t tmp[4096];
+                for (uint64_t q = from; q < end;) {
+                    const uint64_t n = std::min<uint64_t>(sizeof(tmp), end - q);
+                    rd(tmp, q, n);
+                    const uint8_t *e = (const uint8_t *)memchr(tmp, '\n', (size_t)n);
+                    if (e) return q + (uint64_t)(e - tmp);
+                    q += n;
+                }
+                return end;
+            };
+            uint64_t est = 32768;  // bytes to ask for per record: header + sequence line of the records before it, and a margin
             for (;;) {
                 Chunk *c = get_buffer(std::min<uint64_t>(chunk_bytes_ / 2 + (1u << 20) + 2, file_size_ + 2));
                 const size_t i = next_raw_.fetch_add(1);
@@ -398,56 +431,75 @@ class Feeder {
                     break;
                 }
                 const uint64_t lo = (uint64_t)i * chunk_bytes_, hi = std::min<uint64_t>(lo + chunk_bytes_, file_size_);
-#ifdef MADV_POPULATE_READ
-                {  // map the chunk's pages in one call instead of one fault per 4 KB from every thread at once (they all share one mm)
-                    const uint64_t a = lo & ~4095ull, e = std::min<uint64_t>(file_size_, hi + (1u << 20));
-                    madvise(const_cast<uint8_t *>(m) + a, e - a, MADV_POPULATE_READ);
-                }
-#endif
                 // [first, last): from the first record start at or after lo to the first one at or after hi -- the same cut as the
                 // chunked reader's, so that a last record the validator cannot vouch for (CR-LF file without a final newline)
                 // stays with its predecessor
-                uint64_t p = lo ? next_record_start(m, lo, end, true, true) : 0;
-                const uint64_t last = hi < end ? next_record_start(m, hi, end, true, true) : end;
+                uint64_t p = lo ? record_start_from(lo) : 0;
+                const uint64_t last = hi < end ? record_start_from(hi) : end;
                 if (p >= hi) p = last;  // no record starts in this chunk
-                uint64_t w = 0;  // bytes written to the chunk
+                uint64_t w = 0;  // bytes of the chunk in use
                 while (p < last) {
-                    if (m[p] == '\n' || m[p] == '\r') { ++p; continue; }
-                    if (m[p] != '@') throw FeederError("malformed FASTQ record");
-                    const uint64_t e1 = line_end(p);                      // header
-                    const uint64_t s = e1 + 1 < end ? e1 + 1 : end;
-                    const uint64_t e2 = line_end(s);                      // sequence
-                    uint64_t sl = e2 - s;
-                    if (sl && m[s + sl - 1] == '\r') --sl;
-                    if (sl >= (1ull << 32)) throw FeederError("sequence length must be < 2^32");
-                    const uint64_t need = (e1 - p) + 1 + sl + 1;
-                    if (w + need > c->cap) {  // a record longer than the buffer: a private, larger one
-                        Chunk *big = get_buffer(std::max<uint64_t>(w + need, 2 * c->cap), true);
-                        if (w) memcpy(big->buf, c->buf, w);
-                        big->starts.swap(c->starts);
-                        big->lens.swap(c->lens);
-                        big->ids.swap(c->ids);
-                        recycle(c);
-                        c = big;
+                    // the record's header and sequence lines into the buffer at w: `est` bytes, more while a line end is missing
+                    uint64_t got = 0, e1 = NEED_MORE, e2 = NEED_MORE;  // e1, e2: indices in c->buf of the two line ends (or of the data's end at EOF)
+                    for (;;) {
+                        const uint64_t want = std::min<uint64_t>(got ? got * 2 : est, end - p);
+                        if (w + want + 64 > c->cap) {  // records longer than the buffer: a private, larger one
+                            Chunk *big = get_buffer(std::max<uint64_t>(w + want + 64, 2 * c->cap), true);
+                            if (w + got) memcpy(big->buf, c->buf, w + got);
+                            big->starts.swap(c->starts);
+                            big->lens.swap(c->lens);
+                            big->ids.swap(c->ids);
+                            recycle(c);
+                            c = big;
+                        }
+                        rd(c->buf + w + got, p + got, want - got);
+                        const uint64_t from = e1 == NEED_MORE ? w : e1 + 1;  // (what was searched already holds no line end)
+                        got = want;
+                        const bool at_eof = p + got >= end;
+                        if (e1 == NEED_MORE) {
+                            const uint8_t *e = (const uint8_t *)memchr(c->buf + from, '\n', (size_t)(w + got - from));
+                            if (e) e1 = (uint64_t)(e - c->buf);
+                            else if (at_eof) e1 = e2 = w + got;
+                        }
+                        if (e1 != NEED_MORE && e2 == NEED_MORE) {
+                            const uint64_t s = e1 + 1 < w + got ? e1 + 1 : w + got;
+                            const uint8_t *e = (const uint8_t *)memchr(c->buf + s, '\n', (size_t)(w + got - s));
+                            if (e) e2 = (uint64_t)(e - c->buf);
+                            else if (at_eof) e2 = w + got;
+                        }
+                        if (e2 != NEED_MORE) break;
                     }
+                    if (c->buf[w] == '\n' || c->buf[w] == '\r') {  // blank bytes between records (rare): step over them
+                        ++p;
+                        continue;
+                    }
+                    if (c->buf[w] != '@') throw FeederError("malformed FASTQ record");
+                    const uint64_t E2 = p + (e2 - w);                            // file offset of the sequence line's end
+                    const uint64_t s = e1 + 1 < e2 ? e1 + 1 : e2;                // the sequence line in the buffer: [s, e2)
+                    const uint64_t S = p + (s - w);
+                    uint64_t sl = e2 - s;
+                    if (sl && c->buf[s + sl - 1] == '\r') --sl;
+                    if (sl >= (1ull << 32)) throw FeederError("sequence length must be < 2^32");
                     uint64_t h1 = e1;
-                    if (h1 > p + 1 && m[h1 - 1] == '\r') --h1;
-                    memcpy(c->buf + w, m + p, h1 - p);
-                    uint64_t ie = 1;
-                    while (ie < h1 - p && c->buf[w + ie] != ' ') ++ie;  // seq_io's id(): up to the first space
-                    c->ids.push_back({w + 1, (uint32_t)(ie - 1)});
-                    w += h1 - p;
-                    c->buf[w++] = '\n';
-                    memcpy(c->buf + w, m + s, sl);
-                    c->starts.push_back(w);
+                    if (h1 > w + 1 && c->buf[h1 - 1] == '\r') --h1;
+                    uint64_t ie = w + 1;
+                    while (ie < h1 && c->buf[ie] != ' ') ++ie;  // seq_io's id(): up to the first space
+                    c->ids.push_back({w + 1, (uint32_t)(ie - (w + 1))});
+                    c->starts.push_back(s);
                     c->lens.push_back((uint32_t)sl);
-                    w += sl;
-                    c->buf[w++] = '\n';
-                    // '+' line, then a quality line as long as the sequence line (else: to the next line end, like parse_chunk)
-                    const uint64_t e3 = e2 < end ? line_end(e2 + 1) : end;
-                    uint64_t e4 = e3 < end ? e3 + 1 + (e2 - s) : end;
-                    if (e4 > end || (e4 < end && m[e4] != '\n')) e4 = e3 < end ? line_end(e3 + 1) : end;
-                    p = e4 < end ? e4 + 1 : end;
+                    // '+' line: its end is in the surplus of the read more often than not; then a quality line as long as the sequence
+                    // line (else: to the next line end, like parse_chunk)
+                    uint64_t E3 = end;
+                    if (E2 < end) {
+                        const uint64_t ps = e2 + 1;
+                        const uint8_t *e = ps < w + got ? (const uint8_t *)memchr(c->buf + ps, '\n', (size_t)(w + got - ps)) : nullptr;
+                        E3 = e ? p + ((uint64_t)(e - c->buf) - w) : line_end_from(p + got);
+                    }
+                    uint64_t E4 = E3 < end ? E3 + 1 + (E2 - S) : end;
+                    if (E4 > end || (E4 < end && byte_at(E4) != '\n')) E4 = E3 < end ? line_end_from(E3 + 1) : end;
+                    est = std::max<uint64_t>(4096, (E2 - p) + (E2 - p) / 8 + 256);
+                    w = e2 < w + got ? e2 + 1 : e2;  // the next record overwrites what was read beyond the sequence line
+                    p = E4 < end ? E4 + 1 : end;
                 }
                 c->begin = 0;
                 c->bytes = w;
@@ -879,7 +931,7 @@ class Feeder {
     std::function<int(void *, size_t)> lock_;  // page-lock / release whole pages of the mapped file (mq_host_register / mq_host_unregister)
     std::function<int(void *)> unlock_;
     int kind_ = 0;  // 0 raw, 1 gzip, 2 lz4, 3 BGZF (indexed, read like raw)
-    bool lean_fastq_ = false;  // raw FASTQ through the mapping: header and sequence lines only
+    bool lean_fastq_ = false;  // raw FASTQ read lean: header and sequence lines only (lean_fastq_worker)
     bool leave_unparsed_ = false;
     bool mapped_fasta_ = false;  // raw FASTA, records found by the consumer: chunks are views of the mapped file
     bool lock_pages_ = false;    // ... and their pages are locked for the copy to the device

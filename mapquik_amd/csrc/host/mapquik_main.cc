@@ -170,7 +170,16 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         // An uncompressed FASTA file goes to the GPU as it lies in the file: the reader threads only copy file bytes into page-locked
         // chunks (pread, cut at record starts), the records are found on the device (mq_ctx_submit_fasta) and the host reads a header
         // only to print it.  MQ_DRIVER_HOST_PARSE=1: every chunk is parsed by the reader threads as in earlier rounds (same PAF; tests compare).
-        feed.leave_unparsed(getenv("MQ_DRIVER_HOST_PARSE") == nullptr);  // (acts on uncompressed input only, FASTA or FASTQ)
+        // FASTQ: found on the device, the whole file crosses the link (2 file bytes per base: 17 / 22 / 23 Gbases/s at 4 / 8 / 16 reader
+        // threads, the last two the link's rate); with a dozen reader threads or more the lean host reader (header and sequence lines
+        // copied out of the mapped file, qualities never touched, 1 byte per base on the link) is faster on a large file (34 at 16
+        // threads).  MQ_DRIVER_FASTQ=device|lean overrides.
+        bool on_device = getenv("MQ_DRIVER_HOST_PARSE") == nullptr;
+        if (on_device && !reads_fasta) {
+            const char *fq = getenv("MQ_DRIVER_FASTQ");
+            on_device = fq ? strcmp(fq, "lean") != 0 : n_parse < 12;
+        }
+        feed.leave_unparsed(on_device);  // (acts on uncompressed input only, FASTA or FASTQ)
         const uint32_t fx_format = reads_fasta ? MQ_FASTX_FASTA : MQ_FASTX_FASTQ, fx_lpr = reads_fasta ? 2u : 4u;
         feed.premap();  // MQ_FEEDER_MAPPED_FASTA=1 only (experiment): the file is mapped, not read, while the reference is indexed
         // The read feeder starts when the index is ready.  MQ_DRIVER_PREFETCH=1 starts it while the reference is still being indexed

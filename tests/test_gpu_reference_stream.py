@@ -93,7 +93,7 @@ def test_streamed_reference_equals_host_loader_and_oracle(world, shape):
     assert paf1 == paf and _index_lines(r1.stdout) == want_lines
     # earlier rounds' path: records copied from pageable memory one by one
     r2, paf2 = _run(w, ref, env={"MQ_DRIVER_REF_HOST": "1"})
-    assert "reference streamed" not in r2.stderr and "page-locked" not in r2.stderr and paf2 == paf and _index_lines(r2.stdout) == want_lines
+    assert "reference streamed" not in r2.stderr and "reference buffer page-locked" not in r2.stderr and paf2 == paf and _index_lines(r2.stdout) == want_lines
 
 
 def test_other_reference_shapes_fall_back_to_the_host_loader(world):

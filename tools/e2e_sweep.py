@@ -56,10 +56,10 @@ with tempfile.TemporaryDirectory(dir=base) as wd:
             return wall, grab(r"unique k-min-mers in"), grab(r"Mapped query sequences in"), grab(r"Total execution time:"), r.returncode
         once(["--threads", "4"], {})
         reps = int(os.environ["E2E_R5M"])
-        for env in ({}, {"MQ_DRIVER_LATE_SLOTS": "1"}, {"MQ_DRIVER_NO_RESERVE": "1"}, {"MQ_DRIVER_LATE_SLOTS": "1", "MQ_DRIVER_NO_RESERVE": "1"},
+        for env in ({}, {"LOWMEM": "1"}, {"MQ_DRIVER_LATE_SLOTS": "1"}, {"MQ_DRIVER_NO_RESERVE": "1"}, {"LOWMEM": "1", "MQ_DRIVER_NO_RESERVE": "1"},
                     {"MQ_DRIVER_FAST_EXIT": "1"}, {"MQ_DRIVER_REF_HOST": "1"}, {"MQ_TABLE_FACTOR": "8"}):
             for th in (4, 8):
-                rows = [once(["--threads", str(th)], env) for _ in range(reps)]
+                rows = [once(["--threads", str(th)] + (["--low-memory"] if env.get("LOWMEM") else []), env) for _ in range(reps)]
                 med = lambda i: statistics.median(r[i] for r in rows)
                 print("%-62s %d thr: wall %.3f  index %.3f  map %.3f  total-in-main %.3f  (outside main %.3f)  rc %s" %
                       (env, th, med(0), med(1), med(2), med(3), med(0) - med(3), {r[4] for r in rows}), flush=True)
@@ -76,7 +76,11 @@ with tempfile.TemporaryDirectory(dir=base) as wd:
                 if "unique k-min-mers" in ln or "Mapped query" in ln or "Total execution" in ln:
                     print("      " + ln, flush=True)
         tline(["--threads", "4"], "warm-up", {})
-        for extra_env in ({}, {"MQ_TABLE_FACTOR": "4"}, {"MQ_TABLE_FACTOR": "2"}, {"MQ_DRIVER_NO_RESERVE": "1"}):
+        for rep in range(2):
+            for extra in ([], ["--low-memory"]):
+                for th in (4, 8):
+                    tline(["--threads", str(th)] + extra, "FASTA %d threads %s" % (th, extra), {})
+        for extra_env in ({"MQ_TABLE_FACTOR": "8"}, {"MQ_DRIVER_NO_RESERVE": "1"}, {"MQ_DRIVER_REF_HOST": "1"}):
             for th in (4, 8):
                 tline(["--threads", str(th)], "FASTA %d threads %s" % (th, extra_env), extra_env)
         sys.exit(0)
