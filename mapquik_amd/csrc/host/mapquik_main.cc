@@ -256,6 +256,11 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                 building[0]->with_capacity((uint64_t)((double)rst.st_size * (1.0 - (1.0 - d) * (1.0 - d)) * (P.use_hpc ? 0.75 : 1.0)) + 1);
             }
         };
+        std::thread ref_reaper;
+        struct ReaperGuard {
+            std::thread &t;
+            ~ReaperGuard() { if (t.joinable()) t.join(); }
+        } reaper_guard{ref_reaper};
         bool ref_done = false;
         bool res_streamer_used = false;  // the streamer ran (and gave the file back): the index's staging buffer holds its pieces
         std::unique_ptr<ReadOnlyIndex> loaded;
@@ -428,7 +433,8 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             if (!ferr.empty()) throw Error(ferr);
             if (!jerr.empty()) throw Error(jerr);
             tl("every reference record indexed");
-            preload.reset();
+            // the buffer goes back to the system on a thread of its own (unmapping 3.1 GB takes 0.14 s that nothing has to wait for)
+            ref_reaper = std::thread([pl = preload.release()]() { delete pl; });
         } else {
             // compressed (or FASTQ) reference: through the chunked feeder, pageable chunk buffers (every reference byte is copied to
             // the device exactly once)
@@ -745,8 +751,17 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             fflush(stderr);
             _exit(0);
         }
-        for (auto &v : slots) for (auto c : v) mq_ctx_free(c);
-        tl("stream slots freed");
+        // teardown, side by side: the stream slots and then the indexes (contexts go before their index) on one thread, the feeder's
+        // page-locked pool on this one -- 0.08 s one after the other on a 0.6-s job
+        {
+            std::thread dev_side([&]() {
+                for (auto &v : slots) for (auto c : v) mq_ctx_free(c);
+                ro.clear();
+            });
+            feed.release_buffers();
+            dev_side.join();
+        }
+        tl("stream slots, indexes and the page-locked pool released");
     return 0;
 }
 
