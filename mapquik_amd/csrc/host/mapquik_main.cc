@@ -142,14 +142,18 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         FILE *unm = (o.unmapped || !o.second.empty()) ? fopen((prefix + ".unmapped.out").c_str(), "w") : nullptr;
         FILE *ufa = second_fa.empty() ? nullptr : fopen(second_fa.c_str(), "w");  // the unmapped reads as FASTA (seqtk subseq in the reference's script)
 
-        // An uncompressed reference FASTA is read into host memory (all threads, ref_loader.hpp) from HERE on -- before the first HIP call:
-        // bringing the HIP runtime up takes 0.15-0.3 s of one thread, reading 3.1 GB 0.08-0.1 s of the others.  --low-memory: not at
-        // all; the file is streamed through a small pool of page-locked blocks instead (RefStreamer, below).
+        // An uncompressed reference FASTA goes to the device through a small pool of page-locked blocks as it is read (RefStreamer, below);
+        // a file that is not one sequence line per record is read into host memory whole, its records joined there (RefLoader).
+        // MQ_DRIVER_REF_PRELOAD=1 (experiment): the whole-file read starts HERE, before the first HIP call -- bringing the HIP runtime up
+        // takes 0.15-0.3 s of one thread, reading 3.1 GB 0.08-0.1 s of the others -- and the records go to the device from that buffer,
+        // page-locked in one call.  Measured slower than streaming on the bench's job (profiles/r05_driver_medians.txt): 3 GB of host
+        // memory cost 0.14 s to hand back on this platform (pages are cleared when freed: tools/thp_probe.c, 45 ms per GB), whoever does it.
         const int n_parse = (int)std::max<size_t>(1, threads);
         const bool ref_plain = ref_fasta && !ends_with(o.reference, ".gz") && !ends_with(o.reference, ".lz4");
         const bool ref_host = getenv("MQ_DRIVER_REF_HOST") != nullptr;  // diagnostic: earlier rounds' path (records copied from pageable memory one by one)
+        const bool ref_preload = getenv("MQ_DRIVER_REF_PRELOAD") != nullptr && !o.low_memory;
         std::unique_ptr<feeder::RefLoader> preload;
-        if (ref_plain && o.load_index.empty() && !o.low_memory) preload.reset(new feeder::RefLoader(o.reference, n_parse, !ref_host));
+        if (ref_plain && o.load_index.empty() && (ref_preload || ref_host)) preload.reset(new feeder::RefLoader(o.reference, n_parse, !ref_host));
 
         // --gpus N: the index is replicated (every GPU indexes the same reference), read batches are dealt round-robin,
         // PAF lines are written in batch order = input order.  No collective: reads are independent.
@@ -205,7 +209,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             building[0]->table_factor((uint32_t)o.table_factor);
             tl("Index::new returned (HIP runtime up, device chosen)");
         }
-        const bool stream_ref = ref_plain && o.load_index.empty() && o.low_memory && !ref_host;  // RefStreamer (below)
+        const bool stream_ref = ref_plain && o.load_index.empty() && !ref_preload && !ref_host;  // RefStreamer (below)
         // The stream slots of the map phase (device staging, minimizer lists, Match scratch: a few hundred MB of device memory per
         // submitting thread) and the feeder's first page-locked chunk buffers depend on neither the reference nor the reads: the first
         // GPU's are set up by a thread of its own BESIDE the reference phase (0.03-0.04 s of a 0.1-s phase when they came after it).
@@ -263,6 +267,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         } reaper_guard{ref_reaper};
         bool ref_done = false;
         bool res_streamer_used = false;  // the streamer ran (and gave the file back): the index's staging buffer holds its pieces
+        bool streamer_index_dropped = false;  // ... after records had been indexed: that index was replaced by a new one
         std::unique_ptr<ReadOnlyIndex> loaded;
         if (!o.load_index.empty()) {
             // --index: the finalized table from a file written by --save-index (occupied slots only; validated against its header on load)
@@ -337,13 +342,14 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                     building[0].reset();
                     building[0].reset(new Index(P, dev_of(0)));
                     building[0]->table_factor((uint32_t)o.table_factor);
+                    streamer_index_dropped = true;
                     reserve_table();
                 }
                 tl("reference is not one line per record: host loader");
             }
         }
         if (ref_done) {
-        } else if (ref_plain) {
+        } else if (ref_plain && !(o.low_memory && res_streamer_used)) {  // (--low-memory: a file the streamer gave back goes through the chunked reader below, record by record)
             // an uncompressed FASTA: the whole file read once by all threads (since before the HIP runtime came up), multi-line records
             // compacted in place by a pool, records handed over whole and in order (ref_loader.hpp).  The buffer is page-locked in one
             // call (huge pages: milliseconds), every record's bytes are queued for the device the moment the record is ready
@@ -356,7 +362,9 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             mq_index *h = building[0]->handle();
             struct stat rst;
             bool staged = !ref_host && stat(o.reference.c_str(), &rst) == 0 && (uint64_t)rst.st_size == rl.file_bytes();
-            if (staged && res_streamer_used) staged = false;  // (the staging buffer of an index the streamer gave up on may be gone)
+            if (staged && streamer_index_dropped) {  // the streamer's index went away with its staging buffer: the new index gets one
+                if (mq_index_stage_begin(h, rl.file_bytes()) != MQ_OK) staged = false;
+            }
             bool locked = false;
             if (staged) {
                 locked = mq_host_register(rl.data(), (size_t)rl.mapped_bytes()) == MQ_OK;  // (not locked: the copies still work, at the pageable rate)
@@ -433,8 +441,8 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             if (!ferr.empty()) throw Error(ferr);
             if (!jerr.empty()) throw Error(jerr);
             tl("every reference record indexed");
-            // the buffer goes back to the system on a thread of its own (unmapping 3.1 GB takes 0.14 s that nothing has to wait for)
-            ref_reaper = std::thread([pl = preload.release()]() { delete pl; });
+            // (the buffer goes back to the system at the end of the run, beside the rest of the teardown: handing 3 GB back takes 0.14 s
+            // here and stalls whoever maps or allocates memory meanwhile -- index finalisation, stream-slot set-up)
         } else {
             // compressed (or FASTQ) reference: through the chunked feeder, pageable chunk buffers (every reference byte is copied to
             // the device exactly once)
@@ -758,8 +766,10 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                 for (auto &v : slots) for (auto c : v) mq_ctx_free(c);
                 ro.clear();
             });
+            if (preload) ref_reaper = std::thread([pl = preload.release()]() { delete pl; });
             feed.release_buffers();
             dev_side.join();
+            if (ref_reaper.joinable()) ref_reaper.join();
         }
         tl("stream slots, indexes and the page-locked pool released");
     return 0;

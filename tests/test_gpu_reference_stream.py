@@ -81,15 +81,17 @@ def test_streamed_reference_equals_host_loader_and_oracle(world, shape):
     ref = w["wd"] / ("ref_%s.fa" % shape)
     _write_ref(ref, w, nl=b"\r\n" if shape == "crlf" else b"\n", final=shape != "nofinal", lower=shape == "lower", blank_between=shape == "blank_between")
     want_lines = ["Indexed reference %s: %d k-min-mers." % (n, c) for n, c in zip(w["names"], w["counts"])]
-    # default: the file read into host memory while the HIP runtime comes up, page-locked, every record's bytes queued for the device
+    # default (and --low-memory): never in host memory -- streamed through a pool of page-locked 16-MB blocks
     r, paf = _run(w, ref)
-    assert "reference buffer page-locked" in r.stderr and "every reference record indexed" in r.stderr, r.stderr[-1500:]
+    assert "reference streamed: every record handed to ref_extract" in r.stderr, r.stderr[-1500:]
     assert paf == w["want_txt"] and len(paf) > 50000
     assert _index_lines(r.stdout) == want_lines
     assert "Indexed %d unique k-min-mers in " % w["unique"] in r.stdout
-    # --low-memory: never in host memory -- streamed through a pool of page-locked 16-MB blocks
-    r1, paf1 = _run(w, ref, extra=["--low-memory"])
-    assert "reference streamed: every record handed to ref_extract" in r1.stderr, r1.stderr[-1500:]
+    r0, paf0 = _run(w, ref, extra=["--low-memory"])
+    assert "reference streamed: every record handed to ref_extract" in r0.stderr and paf0 == paf and _index_lines(r0.stdout) == want_lines
+    # MQ_DRIVER_REF_PRELOAD=1: the file read into host memory while the HIP runtime comes up, page-locked, every record's bytes queued for the device
+    r1, paf1 = _run(w, ref, env={"MQ_DRIVER_REF_PRELOAD": "1"})
+    assert "reference buffer page-locked" in r1.stderr and "every reference record indexed" in r1.stderr, r1.stderr[-1500:]
     assert paf1 == paf and _index_lines(r1.stdout) == want_lines
     # earlier rounds' path: records copied from pageable memory one by one
     r2, paf2 = _run(w, ref, env={"MQ_DRIVER_REF_HOST": "1"})
@@ -104,16 +106,23 @@ def test_other_reference_shapes_fall_back_to_the_host_loader(world):
     want_lines = ["Indexed reference %s: %d k-min-mers." % (n, c) for n, c in zip(w["names"], w["counts"])]
     wrapped = w["wd"] / "ref_wrapped.fa"
     _write_ref(wrapped, w, wrap=80)
-    r, paf = _run(w, wrapped)  # the default loader joins the lines of a wrapped record in place before its bytes go to the device
-    assert "reference buffer page-locked" in r.stderr and paf == w["want_txt"] and _index_lines(r.stdout) == want_lines
-    r, paf = _run(w, wrapped, extra=["--low-memory"])
-    assert "reference is not one line per record: host loader" in r.stderr and paf == w["want_txt"] and _index_lines(r.stdout) == want_lines
+    for ref_file in (wrapped,):
+        # the streamer gives the file back in its first block; the loader joins the lines of every record in host memory and queues its bytes
+        r, paf = _run(w, ref_file)
+        assert "reference is not one line per record: host loader" in r.stderr and "reference buffer page-locked" in r.stderr
+        assert paf == w["want_txt"] and _index_lines(r.stdout) == want_lines
+        # --low-memory: ... through the chunked reader instead (one record in host memory at a time)
+        r, paf = _run(w, ref_file, extra=["--low-memory"])
+        assert "reference is not one line per record: host loader" in r.stderr and "reference buffer page-locked" not in r.stderr
+        assert paf == w["want_txt"] and _index_lines(r.stdout) == want_lines
+        # the whole-file loader from the start
+        r, paf = _run(w, ref_file, env={"MQ_DRIVER_REF_PRELOAD": "1"})
+        assert "reference buffer page-locked" in r.stderr and paf == w["want_txt"] and _index_lines(r.stdout) == want_lines
     late = w["wd"] / "ref_late_wrap.fa"
     _write_ref(late, w, wrap=70, wrap_from=2)
-    r, paf = _run(w, late)
-    assert paf == w["want_txt"] and _index_lines(r.stdout) == want_lines
-    r, paf = _run(w, late, extra=["--low-memory"])
-    assert "reference is not one line per record: host loader" in r.stderr and paf == w["want_txt"] and _index_lines(r.stdout) == want_lines
+    for extra in ([], ["--low-memory"]):  # noticed after records were indexed: that index is dropped, the file indexed again by the fallback
+        r, paf = _run(w, late, extra=extra)
+        assert "reference is not one line per record: host loader" in r.stderr and paf == w["want_txt"] and _index_lines(r.stdout) == want_lines
     junk = w["wd"] / "ref_junk.fa"
     junk.write_bytes(b"this is not FASTA\n>a\nACGT\n")
     rr = subprocess.run([w["exe"], w["reads"], "--reference", str(junk), "-p", str(w["wd"] / "junk"), "--threads", "2"], capture_output=True, text=True, timeout=600)

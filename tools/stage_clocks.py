@@ -28,6 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=196608)
     ap.add_argument("--genome-scale", type=float, default=1.0)
+    ap.add_argument("--seeding-variant", type=int, default=0)
     a = ap.parse_args()
     import torch
     import mapquik_amd as mq
@@ -35,7 +36,7 @@ def main():
     dev = torch.device("cuda", 0)
     lens = [max(40, int(x * a.genome_scale)) for x in sim.CHM13_LIKE]
     g, off, names = sim.make_genome(lens, seed=2013, threads=8, repeat_frac=0.05, tandem_frac=0.01, div=0.01)
-    ix = mq.Index(mq.Params(), device=0)
+    ix = mq.Index(mq.Params(seeding_variant=a.seeding_variant), device=0)
     for r in range(len(lens)):
         d = torch.from_numpy(g[int(off[r]):int(off[r + 1])]).to(dev)
         ix.add_ref_device(r, names[r], d.data_ptr(), int(off[r + 1] - off[r]))
@@ -53,6 +54,7 @@ def main():
     torch.cuda.synchronize()
     clk = ix.last_stage_clocks()
     tot = float(sum(clk)) or 1.0
+    print("fast-path / general-path reads: %s" % (ix.last_map_path_counts(),))
     print("launch %.3f ms; wave-cycles per stage (share of the stamped total %.4g):" % (ix.last_map_ms(), tot))
     for nm, c in zip(NAMES, clk):
         print("  %-32s %6.2f %%  %.4g" % (nm, 100.0 * c / tot, c))
