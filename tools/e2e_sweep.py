@@ -42,6 +42,18 @@ with tempfile.TemporaryDirectory(dir=base) as wd:
                 print("      " + ln, flush=True)
 
     NP = {"MQ_DRIVER_NO_PREFETCH": "1"}
+    if os.environ.get("E2E_R5Q"):  # round 5: FASTQ (-k 7, BASELINE config 4's shape) by reader and thread count; the whole read set as FASTQ
+        fqa = os.path.join(wd, "all.fastq")
+        sim.write_fastx(fqa, reads["bases"], o, n_reads, fastq=True, threads=16)
+        k7 = ["-k", "7", "-l", "31", "-d", "0.01"]
+        run(fqa, bases, ["--threads", "8"] + k7, "warm-up")
+        for rep in range(2):
+            for mode in ("lean", "device"):
+                for th in (2, 4, 8, 16):
+                    run(fqa, bases, ["--threads", str(th)] + k7, "FASTQ %-6s %2d threads" % (mode, th), {"MQ_DRIVER_FASTQ": mode})
+        run(rd, bases, ["--threads", "4"] + k7, "FASTA (for the ratio) 4 threads")
+        run(rd, bases, ["--threads", "16"] + k7, "FASTA (for the ratio) 16 threads")
+        sys.exit(0)
     if os.environ.get("E2E_R5M"):  # round 5: medians of the job's phases over repeated runs, by driver option
         import statistics
         def once(extra, env):
