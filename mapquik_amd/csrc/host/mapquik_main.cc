@@ -174,14 +174,14 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         // An uncompressed FASTA file goes to the GPU as it lies in the file: the reader threads only copy file bytes into page-locked
         // chunks (pread, cut at record starts), the records are found on the device (mq_ctx_submit_fasta) and the host reads a header
         // only to print it.  MQ_DRIVER_HOST_PARSE=1: every chunk is parsed by the reader threads as in earlier rounds (same PAF; tests compare).
-        // FASTQ: found on the device, the whole file crosses the link (2 file bytes per base: 17 / 22 / 23 Gbases/s at 4 / 8 / 16 reader
-        // threads, the last two the link's rate); with a dozen reader threads or more the lean host reader (header and sequence lines
-        // copied out of the mapped file, qualities never touched, 1 byte per base on the link) is faster on a large file (34 at 16
-        // threads).  MQ_DRIVER_FASTQ=device|lean overrides.
+        // FASTQ: the lean reader by default -- header and sequence lines only, one pread per record, qualities never read: 1 byte per base
+        // from the file and on the link: 12 / 20 / 31 / 35 Gbases/s at 2 / 4 / 8 / 16 reader threads against 9 / 17 / 22 / 21 with the
+        // records found on the device, where the whole file (2 bytes per base) is read and crosses the link
+        // (profiles/r05_fastq_readers.txt).  MQ_DRIVER_FASTQ=device selects that path (mq_ctx_submit_fastx).
         bool on_device = getenv("MQ_DRIVER_HOST_PARSE") == nullptr;
         if (on_device && !reads_fasta) {
             const char *fq = getenv("MQ_DRIVER_FASTQ");
-            on_device = fq ? strcmp(fq, "lean") != 0 : n_parse < 12;
+            on_device = fq && strcmp(fq, "device") == 0;
         }
         feed.leave_unparsed(on_device);  // (acts on uncompressed input only, FASTA or FASTQ)
         const uint32_t fx_format = reads_fasta ? MQ_FASTX_FASTA : MQ_FASTX_FASTQ, fx_lpr = reads_fasta ? 2u : 4u;

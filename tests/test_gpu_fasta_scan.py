@@ -225,11 +225,11 @@ def test_irregular_fastq_pieces_are_handed_back(mq, world):
 
 
 def test_native_driver_fastq_device_and_host_parse(mq, oracle, world, tmp_path):
-    """FASTQ file -> PAF through the native driver: records found on the device (default: the reader threads never look at a base or a
-    quality), parsed by the reader threads (MQ_DRIVER_HOST_PARSE=1: the lean reader), CR-LF without a final newline, quality lines that
-    begin with '@' / '+' -- the oracle's PAF every time, at chunk sizes that put boundaries everywhere; a file whose records have
-    their sequences over two lines comes back irregular chunk by chunk and is parsed on the host (an error there: four-line FASTQ only,
-    as in the reference's reader)."""
+    """FASTQ file -> PAF through the native driver, three readers: the lean one (default: header and sequence lines read with one pread per
+    record, qualities never read), records found on the device (MQ_DRIVER_FASTQ=device: the reader threads never look at a base or a
+    quality, the whole file crosses the link), and the chunked reader + host parser (MQ_FEEDER_NO_LEAN_FASTQ=1 with MQ_DRIVER_HOST_PARSE=1);
+    CR-LF without a final newline, quality lines that begin with '@' / '+', '+id' separator lines -- the oracle's PAF every time, at chunk
+    sizes that put boundaries everywhere."""
     from mapquik_amd import build
     exe = build.build_cli()
     ox, po, rd, rn = world["ox"], world["po"], world["reads"], world["names"]
@@ -248,7 +248,7 @@ def test_native_driver_fastq_device_and_host_parse(mq, oracle, world, tmp_path):
     k = 0
     for path in (plain, crlf):
         for chunk in ("30000", "400000", "33554432"):
-            for env in ({}, {"MQ_DRIVER_HOST_PARSE": "1"}):
+            for env in ({}, {"MQ_DRIVER_FASTQ": "device"}, {"MQ_DRIVER_HOST_PARSE": "1", "MQ_FEEDER_NO_LEAN_FASTQ": "1"}):
                 k += 1
                 prefix = str(tmp_path / ("q%d" % k))
                 r = subprocess.run([exe, str(path), "--reference", str(ref), "-p", prefix, "--batch-bases", chunk, "--threads", "3", "--unmapped"],
