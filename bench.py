@@ -753,7 +753,8 @@ def main():
                 try:
                     big = reads if args.e2e_fastq_reads <= n else sim.make_reads(genome, ctg_off, args.e2e_fastq_reads, seed=args.seed + 5000, threads=threads)
                     k7 = ["-k", "7", "-l", "31", "-d", "0.01"]
-                    # (records found on the device: the reader threads only pread the file -- 2 file bytes per base -- into page-locked chunks)
+                    # (the driver's lean reader: header + sequence lines read with one pread per record, qualities never read; the other reader --
+                    # records found on the device, the whole file on the link -- is profiles/r05_fastq_readers.txt)
                     leg("fastq_k7_to_paf", reads=big, n_reads=args.e2e_fastq_reads, threads=ncpu, workdir=wd, fastq=True, extra_args=k7, more_threads=(4, 8))
                     leg("fasta_k7_to_paf", reads=big, n_reads=args.e2e_fastq_reads, threads=ncpu, workdir=wd, fastq=False, extra_args=k7)
                     a_, b_ = e2e["fastq_k7_to_paf"].get("no_prefetch_gbases_s"), e2e["fasta_k7_to_paf"].get("no_prefetch_gbases_s")
