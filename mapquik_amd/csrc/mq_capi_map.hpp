@@ -607,7 +607,7 @@ void *mq_host_alloc(size_t bytes) {
     if (p != MAP_FAILED) {
         madvise(p, mapped, MADV_HUGEPAGE);
         for (size_t o = 0; o < mapped; o += 4096) ((volatile uint8_t *)p)[o] = 0;  // fault the pages in (2 MB at a time under THP)
-        if (hipHostRegister(p, mapped, hipHostRegisterDefault) == hipSuccess) {
+        if (hipHostRegister(p, mapped, hipHostRegisterPortable) == hipSuccess) {  // portable: a feeder's chunk goes to whichever GPU's worker takes it
             std::lock_guard<std::mutex> lk(g_host_mu);
             g_host_allocs[p] = std::make_pair(mapped, true);
             return p;
@@ -616,7 +616,7 @@ void *mq_host_alloc(size_t bytes) {
         munmap(p, mapped);
     }
     p = nullptr;
-    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable);
     if (e != hipSuccess) {
         set_err(e == hipErrorOutOfMemory ? MQ_ENOMEM : MQ_EHIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
         return nullptr;
@@ -630,7 +630,7 @@ void *mq_host_alloc(size_t bytes) {
 // asynchronously, at the link's rate -- tools/file_h2d.hip).  ptr and bytes whole pages.  0 on success.
 int mq_host_register(void *ptr, size_t bytes) {
     if (!ptr || !bytes) return set_err(MQ_EINVAL, "bad arguments");
-    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return set_err(MQ_EHIP, std::string("hipHostRegister: ") + hipGetErrorString(e));
