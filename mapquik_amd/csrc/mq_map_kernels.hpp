@@ -103,8 +103,11 @@ __device__ __forceinline__ uint32_t seed_read_general(const SplitArgs &A, WaveLd
     return cnt;
 }
 
+// 6: a 24-kb HiFi read lists ~350 minimizers = 5.4 lane-batches, so six cover four reads in five in one chunk; 7 (rounds 3-4) covered
+// nearly all at two more key + four more payload registers across probe_all: 1255-1257 against 1249-1250 Gbases/s (round 5, same box); 8
+// does not fit 128 registers at all (169)
 #ifndef MQ_ML_NB
-#define MQ_ML_NB 7
+#define MQ_ML_NB 6
 #endif
 constexpr int ML_NB = MQ_ML_NB;                              // lane-batches of 64 k-min-mers hashed and probed together
 constexpr uint32_t ML_LIST_CAP = 64 * ML_NB + MAX_L;   // minimizers staged in LDS at a time (64 * ML_NB + k - 1 used, k <= 32)

@@ -29,7 +29,8 @@ def _inputs(tmp_path):
     ref = ">chrA x\n" + "".join(rng.choice("ACGT") for _ in range(300000)) + "\n>chrB\n" + "\n".join(
         "".join(rng.choice("ACGT") for _ in range(80)) for _ in range(2000)) + "\n"
     p = {}
-    for name, text in (("reads.fa", fa), ("reads.fastq", fq), ("ref.fa", ref)):
+    ref1 = ">chrA x\n" + "".join(rng.choice("ACGTacgt") for _ in range(300000)) + "\n>chrB\n" + "".join(rng.choice("ACGT") for _ in range(160000)) + "\n"
+    for name, text in (("reads.fa", fa), ("reads.fastq", fq), ("ref.fa", ref), ("ref1.fa", ref1)):
         p[name] = str(tmp_path / name)
         with open(p[name], "w") as f:
             f.write(text)
@@ -92,8 +93,14 @@ def test_driver_pipeline_under_sanitizers(built, tmp_path, san):
     p, recs = _inputs(tmp_path)
     exe = built["mapquik_" + san]
     n_long = sum(1 for _, b in recs if len(b) >= 50)
+    # ref.fa: a single-line record, then a line-wrapped one (the streamer gives the file back after it indexed the first: the index is
+    # dropped, the loader joins the lines and queues the records' bytes); ref1.fa: single-line all through (the streamer's own path)
     for reads, extra, env in ((p["reads.fa"], [], {}), (p["reads.fastq"], ["--gpus", "2", "--unmapped"], {"MQ_STUB_DEVICES": "2"}),
-                              (p["reads.fa.gz"], ["--threads", "3"], {}), (p["reads.fa"], [], {"MQ_DRIVER_PREFETCH": "1"})):
+                              (p["reads.fa.gz"], ["--threads", "3"], {}), (p["reads.fa"], [], {"MQ_DRIVER_PREFETCH": "1"}),
+                              (p["reads.fa"], ["--reference", p["ref1.fa"]], {}), (p["reads.fa"], ["--reference", p["ref1.fa"], "--low-memory"], {}),
+                              (p["reads.fa"], ["--low-memory"], {}), (p["reads.fa"], [], {"MQ_DRIVER_REF_PRELOAD": "1"}),
+                              (p["reads.fa"], ["--reference", p["ref1.fa"]], {"MQ_DRIVER_REF_PRELOAD": "1"}), (p["reads.fa"], [], {"MQ_DRIVER_REF_HOST": "1"}),
+                              (p["reads.fastq"], [], {"MQ_DRIVER_FASTQ": "device"}), (p["reads.fastq"], [], {"MQ_DRIVER_HOST_PARSE": "1", "MQ_FEEDER_NO_LEAN_FASTQ": "1"})):
         prefix = str(tmp_path / "out")
         r = subprocess.run([exe, reads, "--reference", p["ref.fa"], "-p", prefix, "--batch-bases", "20000", "--threads", "4"] + extra,
                            capture_output=True, text=True, timeout=600, env=dict(_ENV, **env))
