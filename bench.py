@@ -568,7 +568,8 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("reads") == n and abs(tj.get("genome_scale", -1) - args.genome_scale) < 1e-9 and not real_ref:
+            if (tj.get("reads") == n and abs(tj.get("genome_scale", -1) - args.genome_scale) < 1e-9 and not real_ref and args.genome_preset == "planted-repeats"
+                    and args.k == 5 and args.l == 31 and not args.seeding_variant):  # (the counters were taken on the headline workload)
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_commit = tj.get("commit")
         except Exception:
@@ -585,7 +586,8 @@ def main():
     if os.path.exists(ipath):
         try:
             ij = json.load(open(ipath))
-            if ij.get("reads") == n and abs(ij.get("genome_scale", -1) - args.genome_scale) < 1e-9 and ij.get("k") == args.k and not strong and not real_ref:
+            if (ij.get("reads") == n and abs(ij.get("genome_scale", -1) - args.genome_scale) < 1e-9 and ij.get("k") == args.k and not strong and not real_ref
+                    and args.genome_preset == "planted-repeats" and args.l == 31 and not args.seeding_variant):
                 n_simd = int(ij["n_simd"])
                 # cycles: the launch's busy cycles as the counters gave them (GRBM_GUI_ACTIVE / 8 XCDs) -- a property of the kernel on this
                 # workload; this run's launch time only says what shader clock that implies here (the clock moves with the power state:
