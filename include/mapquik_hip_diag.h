@@ -20,6 +20,10 @@ int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general
 int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases, mq_hit *d_out,
                        uint64_t *lookups, uint64_t *extra_steps);
 
+/* Diagnostic (tools/read_tail.py): after mq_map_probe_stats -- what each of the n reads of that launch cost its wave (shader-clock cycles) and
+ * when the wave took it up (ticks of the 100-MHz constant clock): which reads make a launch's tail. */
+int mq_last_read_cycles(mq_index *idx, uint32_t n, uint32_t *cycles, uint64_t *start_ticks);
+
 /* Diagnostic (tools/probe_rate.py): blocks*256 threads each probe per_thread pseudo-random (absent) keys of the finalized table;
  * returns the kernel time, the lookups made and the slots visited beyond the home slots.  Measures the random-access rate the
  * memory system sustains on this table, detached from the map path.  bitmap_log2 != 0: test a stand-in bitmap of 2^bitmap_log2

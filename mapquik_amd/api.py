@@ -35,7 +35,7 @@ EXPORTS = ["mq_index_set_table_factor", "mq_ctx_submit_fastx", "mq_index_get_par
            "mq_index_add_ref", "mq_index_add_ref_device", "mq_index_finalize", "mq_index_get_stats", "mq_index_ref_info",
            "mq_map_batch", "mq_map_batch_device", "mq_map_reserve", "mq_kminmers_batch", "mq_index_lookup", "mq_format_paf",
            "mq_last_map_ms", "mq_last_map_path_counts", "mq_host_alloc", "mq_host_free", "mq_index_save", "mq_index_load", "mq_index_clone", "mq_map_probe_stats",
-           "mq_ctx_new", "mq_ctx_free", "mq_ctx_map_batch", "mq_ctx_submit", "mq_ctx_submit_spans", "mq_ctx_wait", "mq_ctx_reserve", "mq_ctx_map_batch_device", "mq_ctx_last_map_ms", "mq_probe_rate", "mq_last_stage_clocks"]
+           "mq_ctx_new", "mq_ctx_free", "mq_ctx_map_batch", "mq_ctx_submit", "mq_ctx_submit_spans", "mq_ctx_wait", "mq_ctx_reserve", "mq_ctx_map_batch_device", "mq_ctx_last_map_ms", "mq_probe_rate", "mq_last_stage_clocks", "mq_last_read_cycles"]
 
 
 class MapquikError(RuntimeError):
@@ -138,6 +138,8 @@ def load_library(path=None):
     L.mq_format_paf.argtypes = [vp, C.c_char_p, u64, vp, C.c_char_p, C.c_size_t]
     L.mq_last_map_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.mq_last_stage_clocks.argtypes = [vp, vp]
+    if hasattr(L, "mq_last_read_cycles"):
+        L.mq_last_read_cycles.argtypes = [vp, u32, vp, vp]
     L.mq_map_probe_stats.argtypes = [vp, vp, vp, u32, u64, vp, C.POINTER(u64), C.POINTER(u64)]
     L.mq_index_save.argtypes = [vp, C.c_char_p]
     L.mq_index_clone.restype = vp
@@ -247,6 +249,14 @@ class Index:
         if n < 0:
             raise _err(self._L, "mq_index_add_ref_device")
         return n
+
+    def last_read_cycles(self, n):
+        """(cycles, start_ticks) of the n reads of the last probe_stats launch: what each read cost its wave, when it was taken up."""
+        cyc = np.zeros(n, dtype=np.uint32)
+        st = np.zeros(n, dtype=np.uint64)
+        if self._L.mq_last_read_cycles(self._h, n, _p(cyc), _p(st)) != 0:
+            raise _err(self._L, "mq_last_read_cycles")
+        return cyc, st
 
     def set_table_factor(self, slots_per_kminmer):
         """Table slots per inserted k-min-mer (default 8; 2 for file-fed, host-bound runs).  Before reserve_table / finalize."""

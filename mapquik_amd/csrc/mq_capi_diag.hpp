@@ -115,6 +115,25 @@ int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_
     return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
+// Diagnostic: what every read of the last mq_map_probe_stats launch cost its wave (shader-clock cycles from the read's first instruction to
+// its result's store) and when the wave took it up (the 100-MHz constant clock): where a launch's tail comes from.
+int mq_last_read_cycles(mq_index *idx, uint32_t n, uint32_t *cycles, uint64_t *start_ticks) try {
+    if (!idx || !cycles || !start_ticks) return set_err(MQ_EINVAL, "bad arguments");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    mq_ctx *c = idx->def_ctx;
+    if (!c->ev_valid || n > c->reads_cap) return set_err(MQ_ESTATE, "no instrumented launch of that size recorded");
+    int rc = use_device(idx);
+    if (rc) return rc;
+    HIPCHK(hipEventSynchronize(c->ev1));
+    HIPCHK(hipMemcpy(cycles, c->mz_count, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(start_ticks, c->mz_base, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return MQ_OK;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+}
+
 // Diagnostic (-DMQ_STAGE_CLOCKS builds; zeros otherwise): shader-clock cycles the waves of the last map_kernel launch of the default
 // context spent per stage, summed over waves (stage list: mq_device.hpp, mq_clk).
 int mq_last_stage_clocks(mq_index *idx, uint64_t *out16) try {

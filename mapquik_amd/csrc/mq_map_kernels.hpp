@@ -323,6 +323,9 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
     APre pre;                // the current read's first super-row when pre_valid (MQ_LDS_PREFETCH: picked up from LDS at the end of the
     bool pre_valid = false;  // iteration before)
     while (r < A.n) {
+        // the instrumented launch (TIMING, never timed) also notes what every read cost its wave: mq_last_read_cycles
+        const unsigned long long t_read0 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long t_real0 = TIMING ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #if !MQ_LDS_PREFETCH
         uint32_t rn_v = 0;
         if (lane == 0) rn_v = atomicAdd(&A.counters[0], 1u);
@@ -468,6 +471,11 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         len = A.lens ? (uint64_t)rdfirst(n_len) : rdlane64(n_o1, 0) - o0;
         asm volatile("" ::: "memory");  // the prefetched offsets are out of their registers before the result's store is issued
         store_hit(A, r_done, h);
+        if (TIMING && lane == 0) {
+            const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_read0;
+            A.mz_count[r_done] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
+            A.mz_base[r_done] = t_real0;
+        }
     }
 #endif
     if (lane == 0) {
