@@ -301,13 +301,14 @@ def kernel_leg(mq, sim, O, torch, dev, local_rank, P, po, genome, ctg_off, ctg_n
         pafs[a_] = hits[a_]
     n_m, n_q60, n_q60_wrong = sim.mapeval(truth, pafs)
     n_fast, n_general = ix.last_map_path_counts()
+    n_flagged, n_first = ix.last_map_order()
     same, ouniq = oracle_sample_check(mq, O, genome, ctg_off, ctg_names, po, ncpu, reads, hits, sample_reads)
     st = ix.stats()
     ix.close()
     del d_bases, d_offs, d_out
     return dict(workload=workload, value=round(total_bases / (ms * 1e-3) / 1e9, 3), unit="Gbases/s", ms_per_launch=round(ms, 4), steps=steps,
                 reads_per_step=n, bases_per_step=total_bases, kminmers_per_step=int(hits["n_kminmers"].astype(np.int64).sum()),
-                mapped_frac=round(n_m / max(n, 1), 4), q60=n_q60, q60_wrong=n_q60_wrong, overflow_reads=int((hits["status"] == 2).sum()),
+                mapped_frac=round(n_m / max(n, 1), 4), q60=n_q60, q60_wrong=n_q60_wrong, overflow_reads=int((hits["status"] == 2).sum()), reads_first=n_first,
                 general_path_reads=int(n_general), index_unique_kminmers=int(n_unique), index_keys=int(st["n_keys"]), index_build_s=round(t_build, 3),
                 paf_columns_identical_to_oracle=same, oracle_sample_reads=min(sample_reads, n), unique_kminmers_equal_oracle=bool(ouniq == n_unique))
 
@@ -545,6 +546,7 @@ def main():
     avg_kern_s = float(np.mean(kern_ms)) / 1e3
 
     hits = np.frombuffer(d_out.cpu().numpy().tobytes(), dtype=mq.hit_dtype)
+    launch_order = dict(zip(("reads_flagged", "reads_first"), ix.last_map_order()))  # order_reads_kernel: reads taken up first
     if os.environ.get("MQ_BENCH_DUMP_HITS"):  # test hook: this rank's hits (strong scaling: of its shard of the one read set)
         np.save(os.path.join(os.environ["MQ_BENCH_DUMP_HITS"], "hits_rank%d_of_%d.npy" % (rank, world)), hits.view(np.uint8))
     n_kmm = int(hits["n_kminmers"].astype(np.int64).sum())
@@ -809,6 +811,7 @@ def main():
             "mapped_frac": round(n_mapped / max(n, 1), 4),
             "overflow_reads": n_over,
             "kminmers_per_step": n_kmm,
+            "launch_order": launch_order,
             "setup_s": {"genome": round(t_genome, 1), "genome_upload": round(t_upload, 2), "gpu_index": round(t_index, 3), "reads": round(t_reads, 1)},
             "index_build": index_build,
             "q60": n_q60,

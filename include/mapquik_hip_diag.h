@@ -15,6 +15,10 @@ extern "C" {
  * the general streaming path.  Both produce identical results.  Synchronises on the launch. */
 int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general);
 
+/* The launch order of the last map launch: how many reads looked like short-period tandem arrays to the ordering pass (n_flagged) and
+ * how many of them were taken up first (n_first <= n_flagged: the front of the order holds 32,768). */
+int mq_last_map_order(mq_index *idx, uint32_t *n_flagged, uint32_t *n_first);
+
 /* Measurement aid: one instrumented (slower, never timed) launch of the same batch that counts index lookups and the slots
  * visited beyond each lookup's home slot: mean probes per lookup = 1 + extra_steps / lookups (SURVEY 8d's p-bar). */
 int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases, mq_hit *d_out,

@@ -34,7 +34,7 @@ EXPORTS = ["mq_index_set_table_factor", "mq_ctx_submit_fastx", "mq_index_get_par
            "mq_last_error", "mq_abi_version", "mq_device_count", "mq_params_default", "mq_index_new", "mq_index_free",
            "mq_index_add_ref", "mq_index_add_ref_device", "mq_index_finalize", "mq_index_get_stats", "mq_index_ref_info",
            "mq_map_batch", "mq_map_batch_device", "mq_map_reserve", "mq_kminmers_batch", "mq_index_lookup", "mq_format_paf",
-           "mq_last_map_ms", "mq_last_map_path_counts", "mq_host_alloc", "mq_host_free", "mq_index_save", "mq_index_load", "mq_index_clone", "mq_map_probe_stats",
+           "mq_last_map_ms", "mq_last_map_path_counts", "mq_last_map_order", "mq_host_alloc", "mq_host_free", "mq_index_save", "mq_index_load", "mq_index_clone", "mq_map_probe_stats",
            "mq_ctx_new", "mq_ctx_free", "mq_ctx_map_batch", "mq_ctx_submit", "mq_ctx_submit_spans", "mq_ctx_wait", "mq_ctx_reserve", "mq_ctx_map_batch_device", "mq_ctx_last_map_ms", "mq_probe_rate", "mq_last_stage_clocks", "mq_last_read_cycles"]
 
 
@@ -150,6 +150,7 @@ def load_library(path=None):
     L.mq_host_alloc.argtypes = [C.c_size_t]
     L.mq_host_free.argtypes = [vp]
     L.mq_last_map_path_counts.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.mq_last_map_order.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     if path is None:
         _lib = L
     return L
@@ -386,6 +387,13 @@ class Index:
         a, b = C.c_uint32(), C.c_uint32()
         if self._L.mq_last_map_path_counts(self._h, C.byref(a), C.byref(b)) != 0:
             raise _err(self._L, "mq_last_map_path_counts")
+        return a.value, b.value
+
+    def last_map_order(self):
+        """(reads the ordering pass of the last launch took for short-period tandem arrays, reads it put first)."""
+        a, b = C.c_uint32(), C.c_uint32()
+        if self._L.mq_last_map_order(self._h, C.byref(a), C.byref(b)) != 0:
+            raise _err(self._L, "mq_last_map_order")
         return a.value, b.value
 
     def kminmers_batch(self, bases, offsets, caps=None):

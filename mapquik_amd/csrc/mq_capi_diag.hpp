@@ -96,6 +96,25 @@ int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general
     return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
+int mq_last_map_order(mq_index *idx, uint32_t *n_flagged, uint32_t *n_first) try {
+    if (!idx || !n_flagged || !n_first) return set_err(MQ_EINVAL, "bad arguments");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    mq_ctx *c = idx->def_ctx;
+    if (!c->ev_valid) return set_err(MQ_ESTATE, "no map launch recorded");
+    int rc = use_device(idx);
+    if (rc) return rc;
+    HIPCHK(hipEventSynchronize(c->ev1));
+    uint32_t v = 0;
+    HIPCHK(hipMemcpy(&v, c->d_counter + WORK_NF, 4, hipMemcpyDeviceToHost));
+    *n_flagged = v;
+    *n_first = v < WORK_FRONT_CAP ? v : WORK_FRONT_CAP;
+    return MQ_OK;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+}
+
 int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases, mq_hit *d_out,
                        uint64_t *lookups, uint64_t *extra_steps) try {
     if (!idx || !lookups || !extra_steps) return set_err(MQ_EINVAL, "bad arguments");

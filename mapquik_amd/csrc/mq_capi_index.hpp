@@ -58,6 +58,8 @@ mq_index *mq_index_new(const mq_params *params, int device) try {
     if (cc && atoi(cc) == 4) idx->chain_chunk = 4;
     const char *fg = getenv("MQ_FORCE_GENERAL");
     idx->force_general = fg && atoi(fg) != 0;
+    const char *hf = getenv("MQ_HEAVY_FIRST");
+    idx->heavy_first = !(hf && atoi(hf) == 0);
     const char *pl = getenv("MQ_PIPELINE");
     idx->split = pl && strcmp(pl, "split") == 0;
     hipDeviceProp_t prop;

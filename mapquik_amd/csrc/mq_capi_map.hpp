@@ -49,7 +49,11 @@ static int launch_map(mq_ctx *c, const uint8_t *d_bases, const uint64_t *d_offse
     A.dump_off = o.d_dump_off;
     A.dump_counts = o.d_dump_counts;
     A.stats64 = reinterpret_cast<unsigned long long *>(c->d_counter + 8);
+    A.work = c->work;
+    A.heavy_first = idx->heavy_first ? 1u : 0u;
     if (!idx->split) {
+        if (n > WORK_ID_MASK) return set_err(MQ_EINVAL, "more than 2^30 - 1 reads in one batch");
+        hipLaunchKernelGGL(order_reads_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, A);  // the launch order (and map_kernel's work descriptors)
         uint32_t grid = std::min<uint32_t>(idx->grid_fused, (n + MAP_WAVES - 1) / MAP_WAVES);
         if (o.grid_override) grid = std::min(grid, o.grid_override);
         const dim3 blk(64 * MAP_WAVES);

@@ -38,6 +38,7 @@ struct mq_ctx {
     uint32_t *mz_count = nullptr;
     uint64_t *mz_base = nullptr;
     uint32_t *queue = nullptr;
+    uint4 *work = nullptr;          // map_kernel's work items (order_reads_kernel): WORK_FRONT_CAP + reads_cap descriptors
     uint64_t reads_cap = 0;
     uint64_t pool_base = 0, pool_cap = 0;  // of the last ctx_ensure: the pool behind the regular list regions
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -115,6 +116,7 @@ struct mq_index {
     uint32_t cap_matches = 0;
     bool split = false;             // diagnostic MQ_PIPELINE=split: the two phases as separate launches (a profiler then prices each)
     bool force_general = false;     // test hook MQ_FORCE_GENERAL=1: never take the fast seeding path
+    bool heavy_first = true;        // order_reads_kernel puts reads that look like short-period tandem arrays first (MQ_HEAVY_FIRST=0: A/B hook, reads in their own order)
     int chain_chunk = 64;           // test hook: MQ_CHAIN_CHUNK=4 exercises the multi-chunk chain path
     mq_ctx *def_ctx = nullptr;      // the context behind the index-level map entry points
     double t_add_ms = 0;            // MQ_BUILD_TIMING: wall time spent in mq_index_add_ref[_device] so far
@@ -325,13 +327,16 @@ static int ctx_ensure(mq_ctx *c, uint32_t n, uint64_t total_bases, uint32_t f16)
         if (c->mz_count) HIPCHK(hipFree(c->mz_count));
         if (c->mz_base) HIPCHK(hipFree(c->mz_base));
         if (c->queue) HIPCHK(hipFree(c->queue));
+        if (c->work) HIPCHK(hipFree(c->work));
         c->mz_count = c->queue = nullptr;
         c->mz_base = nullptr;
+        c->work = nullptr;
         c->reads_cap = 0;
         const uint64_t nc = (uint64_t)n + n / 4 + 64;
         HIPCHK(hipMalloc((void **)&c->mz_count, nc * 4));
         HIPCHK(hipMalloc((void **)&c->mz_base, nc * 8));
         HIPCHK(hipMalloc((void **)&c->queue, nc * 4));
+        HIPCHK(hipMalloc((void **)&c->work, (nc + WORK_FRONT_CAP) * sizeof(uint4)));
         c->reads_cap = nc;
     }
     // regular regions, then the pool for lists denser than their region (an eighth of the regular space, at least 1 M entries)
@@ -368,6 +373,7 @@ static void ctx_release(mq_ctx *c) {
     hipFree(c->mz_count);
     hipFree(c->mz_base);
     hipFree(c->queue);
+    hipFree(c->work);
     hipFree(c->st_bases);
     hipFree(c->st_off);
     hipFree(c->st_out);

@@ -45,7 +45,69 @@ struct SplitArgs {
     const uint64_t *dump_off;
     uint32_t *dump_counts;
     unsigned long long *stats64;  // instrumented launch only: [0] slots visited beyond the home slot, [1] lookups
+    uint4 *work;                  // map_kernel's work items in launch order (order_reads_kernel)
+    uint32_t heavy_first;         // order_reads_kernel: reads that look like short-period tandem arrays go first
 };
+
+// ------------------------------------------------------------------- launch order
+// map_kernel takes work item i (an atomic counter) = descriptor work[WORK_FRONT_CAP - nf + i], i < nf + n:
+//   {offset lo, offset hi, length (low 32 bits), read | WORK_SKIP | WORK_TOO_LONG}
+// written per launch by order_reads_kernel (one lane per read): entry WORK_FRONT_CAP + r describes read r, and the nf = counters[7] reads
+// that go FIRST sit in front of them (growing downwards; their natural entries carry WORK_SKIP).  One 16-byte load per read instead of
+// two or three dependent on the layout of the caller's arrays -- and a place to decide the order.
+// Which reads go first: those that look like a short-period tandem array.  A read inside an array of period p < l has p distinct l-mers;
+// when one of them passes the density test the read lists a minimizer every p bases -- thousands instead of ~350 -- and costs its wave 10-40
+// times the ordinary read (profiles/r05_read_tail.txt).  Taken up in the last third of a launch such a read IS the launch's tail (every
+// other wave has left); taken up first it costs nothing but its own work.  The test (three windows of 48 bases at 1/6, 3/6, 5/6 of the read:
+// some lag 1..16 matches in >= 27 of 32 positions) costs ~800 instructions per READ against map_kernel's ~13,000 per read per WAVE;
+// it flags 0.1-0.3 % of the reads of a human-like batch, among them every read with > 10 x the median minimizer count and 21 of 23
+// with > 5 x (tools/heavy_study.py).  The order changes nothing but the order: results are stored by read number.
+constexpr uint32_t WORK_FRONT_CAP = 32768;  // reads that can go first (more are flagged: the rest stay where they are)
+constexpr uint32_t WORK_SKIP = 0x80000000u, WORK_TOO_LONG = 0x40000000u, WORK_ID_MASK = 0x3FFFFFFFu;
+constexpr uint32_t WORK_NF = 7;             // counters[WORK_NF]: reads flagged (may exceed WORK_FRONT_CAP)
+
+// 48 bases at p: does some lag 1..16 match in >= 27 of the first 32 positions?
+__device__ __forceinline__ bool window_periodic(const uint8_t *p) {
+    uint32_t by[12];  // four 2-bit codes per byte: (c >> 1) & 3 of A C G T (either case), gathered by a multiplication without carries
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint4 v = *reinterpret_cast<const uint4_unaligned *>(p + 16 * j);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) by[4 * j + i] = ((((w[i] >> 1) & 0x03030303u) * 0x01041040u) >> 24);
+    }
+    const uint64_t s0 = (uint64_t)(by[0] | (by[1] << 8) | (by[2] << 16) | (by[3] << 24)) | ((uint64_t)(by[4] | (by[5] << 8) | (by[6] << 16) | (by[7] << 24)) << 32);
+    const uint64_t s1 = (uint64_t)(by[8] | (by[9] << 8) | (by[10] << 16) | (by[11] << 24));
+    bool hit = false;
+#pragma unroll
+    for (uint32_t lag = 1; lag <= 16; ++lag) {
+        const uint64_t sh = (s0 >> (2u * lag)) | (s1 << (64u - 2u * lag));  // bases lag .. lag + 31
+        const uint64_t d = s0 ^ sh;
+        hit |= __popcll((d | (d >> 1)) & 0x5555555555555555ull) <= 5;
+    }
+    return hit;
+}
+
+__global__ __launch_bounds__(256) void order_reads_kernel(const SplitArgs A) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= A.n) return;
+    const uint64_t o0 = A.offsets[r];
+    const uint64_t len = A.lens ? (uint64_t)A.lens[r] : A.offsets[r + 1] - o0;
+    uint32_t w = r;
+    if (len >> 32) w |= WORK_TOO_LONG;
+    else if (A.heavy_first && len >= 512u) {
+        const uint8_t *seq = A.bases + o0;
+        const uint32_t ln = (uint32_t)len;
+        if (window_periodic(seq + ln / 6u) || window_periodic(seq + ln / 2u) || window_periodic(seq + (ln / 6u) * 5u)) {
+            const uint32_t k = atomicAdd(&A.counters[WORK_NF], 1u);
+            if (k < WORK_FRONT_CAP) {
+                A.work[WORK_FRONT_CAP - 1u - k] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), ln, w);
+                w |= WORK_SKIP;
+            }
+        }
+    }
+    A.work[WORK_FRONT_CAP + r] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), (uint32_t)len, w);
+}
 
 __device__ __forceinline__ void list_region(const SplitArgs &A, uint64_t o0_rel, uint64_t len, uint32_t r, uint64_t &base, uint32_t &cap) {
     base = ((o0_rel * A.f16) >> 16) + (uint64_t)A.slack * r;
@@ -299,6 +361,13 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
     const uint64_t o_base = A.offsets[0];
     uint32_t n_fast = 0, n_general = 0, n_moved = 0;
     unsigned long long t_steps = 0, t_lookups = 0;
+#ifdef MQ_STAGGER  // experiment (profiles/NOTES.md): the waves of a SIMD start MQ_STAGGER x 8 k cycles apart instead of in the same stage
+    {
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        for (uint32_t i = (hw & 3u) * (uint32_t)(MQ_STAGGER); i; --i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 #ifdef MQ_STAGE_CLOCKS
     if (lane == 0)
         for (int i = 0; i < MQ_N_CLK; ++i) mq_clk_lds().acc[wv][i] = 0;
@@ -308,18 +377,42 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
     // phase, its offsets during the map phase -- two dependent memory round trips per read that no wave waits for.  (Requesting
     // the next read's first super-row across the map phase as well was measured at -3 %: a wave's loads return in order, so the
     // map phase's first wait -- an L2 round trip for the list -- then sits behind an HBM one.)
+#if MQ_LDS_PREFETCH  // (this experimental build takes the reads in their own order, from the caller's arrays)
     uint32_t r = 0;
     if (lane == 0) r = atomicAdd(&A.counters[0], 1u);
     r = rdfirst(r);
-#if MQ_LDS_PREFETCH
     uint32_t rn_v = 0;  // lane 0: the work item after r, taken one read ahead (the request goes out with the next read's first super-row)
     if (lane == 0) rn_v = atomicAdd(&A.counters[0], 1u);
-#endif
     uint64_t o0 = 0, len = 0;
     if (r < A.n) {
         o0 = A.offsets[r];
         len = A.lens ? (uint64_t)A.lens[r] : A.offsets[r + 1] - o0;
     }
+#else
+    // work items = order_reads_kernel's descriptors: the reads that go first, then all reads in their own order (those that went first marked)
+    const uint32_t nf = A.counters[WORK_NF] < WORK_FRONT_CAP ? A.counters[WORK_NF] : WORK_FRONT_CAP;
+    const uint4 *work = A.work + (WORK_FRONT_CAP - nf);
+    const uint32_t n_items = A.n + nf;
+    uint32_t r = 0xFFFFFFFFu;  // the read being worked on; none: the wave is done
+    uint64_t o0 = 0, len = 0;
+    // a work item taken with nothing to do meanwhile: a wave's first, and the one after an entry whose read went first (one in hundreds)
+    auto take_now = [&]() {
+        for (;;) {
+            uint32_t i = 0;
+            if (lane == 0) i = atomicAdd(&A.counters[0], 1u);
+            i = rdfirst(i);
+            r = 0xFFFFFFFFu;
+            if (i >= n_items) return;
+            const uint4 d = work[i];
+            if (d.w & WORK_SKIP) continue;
+            r = d.w & WORK_ID_MASK;
+            o0 = ((uint64_t)d.y << 32) | d.x;
+            len = (uint64_t)d.z | ((uint64_t)((d.w >> 30) & 1u) << 32);
+            return;
+        }
+    };
+    take_now();
+#endif
     APre pre;                // the current read's first super-row when pre_valid (MQ_LDS_PREFETCH: picked up from LDS at the end of the
     bool pre_valid = false;  // iteration before)
     while (r < A.n) {
@@ -395,13 +488,8 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
             }
         }
 #else
-        unsigned long long n_o0 = 0, n_o1 = 0;
-        uint32_t n_len = 0;
-        if (lane == 0 && rn < A.n) {  // vector loads by one lane: in flight through the map phase (scalar loads would be waited for at its first LDS wait)
-            n_o0 = A.offsets[rn];
-            if (A.lens) n_len = A.lens[rn];
-            else n_o1 = A.offsets[rn + 1];
-        }
+        uint4 nd = make_uint4(0u, 0u, 0u, 0u);
+        if (lane == 0 && rn < n_items) nd = work[rn];  // a vector load by one lane: in flight through the map phase (a scalar load would be waited for at its first LDS wait)
 #endif
         mq_hit h;
 #if MQ_LDS_LIST
@@ -444,8 +532,8 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
 #endif
         wave_sync();
         const uint32_t r_done = r;
-        r = rn;
 #if MQ_LDS_PREFETCH
+        r = rn;
         o0 = o0_n;
         len = len_n;
         rn_v = rnn_v;
@@ -467,10 +555,13 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         store_hit(A, r_done, h);
     }
 #else
-        o0 = rdlane64(n_o0, 0);
-        len = A.lens ? (uint64_t)rdfirst(n_len) : rdlane64(n_o1, 0) - o0;
-        asm volatile("" ::: "memory");  // the prefetched offsets are out of their registers before the result's store is issued
+        const uint32_t nw = rdfirst(nd.w);
+        o0 = ((uint64_t)rdfirst(nd.y) << 32) | rdfirst(nd.x);
+        len = (uint64_t)rdfirst(nd.z) | ((uint64_t)((nw >> 30) & 1u) << 32);
+        r = rn < n_items ? (nw & WORK_ID_MASK) : 0xFFFFFFFFu;
+        asm volatile("" ::: "memory");  // the prefetched descriptor is out of its registers before the result's store is issued
         store_hit(A, r_done, h);
+        if (rn < n_items && (nw & WORK_SKIP)) take_now();  // that read went first
         if (TIMING && lane == 0) {
             const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_read0;
             A.mz_count[r_done] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;

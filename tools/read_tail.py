@@ -64,6 +64,14 @@ def main():
     for i in order:
         print("  %9d %6.1fx %6d %5d  st %d score %4d  at %7.1f us  %s:%d%s" % (cyc[i], c[i] / np.median(c), lens_r[i], hits["n_kminmers"][i], hits["status"][i], hits["score"][i],
                                                                            (int(start[i]) - t0) / 100.0, names[int(reads["ctg"][i])], int(reads["start"][i]), "-" if reads["strand"][i] else "+"))
+    # what a read costs by when it was taken up: the launch's start (every wave in the same stage), its steady state, its end
+    t_us = (start.astype(np.int64) - t0) / 100.0
+    edges = [0, 25, 100, 200, 400, 800, 1600, 2400, 3200, 3600, 3700, 3800, 3900, 4000, 4200, 1e9]
+    print("mean cycles per read by the time it was taken up [us]:")
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        m = (t_us >= lo) & (t_us < hi)
+        if m.any():
+            print("  [%6.0f, %6.0f)  %7d reads  mean %8.0f  median %8.0f" % (lo, min(hi, 99999), int(m.sum()), c[m].mean(), np.median(c[m])))
     print("last read finished %.1f us after the first was taken up; the median wave's last read finished at about %.1f us" % (rel_end.max(), np.median(np.sort(rel_end)[-4096:])))
 
 
