@@ -31,8 +31,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=196608,
-                    help="reads per step per GPU (a launch carries ~0.2 ms of start-up + tail, so small batches under-report)")
+    ap.add_argument("--reads", type=int, default=1572864,
+                    help="reads per step per GPU: 1,572,864 HiFi reads = 37 Gbases = 12x of the 30x of BASELINE config 3, resident in HBM (a launch "
+                         "carries 0.15-0.3 ms of start-up + tail -- its waves start in step and finish one read apart -- which is 7 %% of a "
+                         "196,608-read launch and 1 %% of this one: the line's `smaller_batches` gives the rates of 49,152 / 196,608 / 786,432 reads)")
     ap.add_argument("--genome-scale", type=float, default=1.0, help="1.0 = CHM13-like 3.117 Gbp")
     ap.add_argument("--seed", type=int, default=2013)
     ap.add_argument("--repeat-frac", type=float, default=0.05, help="fraction of the genome overwritten by copied 1-20 kb segments "
@@ -545,6 +547,25 @@ def main():
         kern_ms = [a.elapsed_time(b) for a, b in ev]
     avg_kern_s = float(np.mean(kern_ms)) / 1e3
 
+    # the same kernel on the first m reads of the batch: what a launch's fixed cost (start-up + tail) does to smaller batches
+    smaller = {}
+    if not strong:
+        for m in (49152, 196608, 786432):
+            if m < n:
+                tb = int(offs[m])
+                for _ in range(2):
+                    ix.map_batch_device(d_bases.data_ptr(), d_offs.data_ptr(), m, tb, d_out.data_ptr(), stream.cuda_stream)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(10):
+                    ix.map_batch_device(d_bases.data_ptr(), d_offs.data_ptr(), m, tb, d_out.data_ptr(), stream.cuda_stream)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                ms_m = e0.elapsed_time(e1) / 10
+                smaller[str(m)] = {"gbases_s": round(tb / ms_m / 1e6, 1), "ms_per_launch": round(ms_m, 4)}
+        if smaller:  # the whole batch once more: d_out holds the step's results again
+            ix.map_batch_device(d_bases.data_ptr(), d_offs.data_ptr(), n, total_bases, d_out.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
     hits = np.frombuffer(d_out.cpu().numpy().tobytes(), dtype=mq.hit_dtype)
     launch_order = dict(zip(("reads_flagged", "reads_first"), ix.last_map_order()))  # order_reads_kernel: reads taken up first
     if os.environ.get("MQ_BENCH_DUMP_HITS"):  # test hook: this rank's hits (strong scaling: of its shard of the one read set)
@@ -722,9 +743,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_e2e:
         import tempfile
         e2e = {}
-        gb, h_e2e = measure_host_buffers(mq, ix, reads)
+        n_hb = min(n, 393216)  # (page-locking the whole step batch would take longer than the leg)
+        gb, h_e2e = measure_host_buffers(mq, ix, dict(bases=reads["bases"][:int(offs[n_hb])], offsets=offs[:n_hb + 1]))
         e2e["host_buffers_gbases_s"] = round(gb, 2)
-        e2e["host_buffers_hits_identical"] = bool(np.array_equal(h_e2e.view(np.uint8), hits.view(np.uint8)))
+        e2e["host_buffers_reads"] = n_hb
+        e2e["host_buffers_hits_identical"] = bool(np.array_equal(h_e2e.view(np.uint8), hits[:n_hb].view(np.uint8)))
         e2e["host_buffers_note"] = "page-locked reads -> mq_ctx_submit/wait on 3 stream slots, 16,384-read sub-batches -> hits in host memory; PCIe-bound at 1 B/base"
         base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
         kargs = ["-k", str(args.k), "-l", str(args.l), "-d", repr(args.density)]
@@ -812,6 +835,7 @@ def main():
             "overflow_reads": n_over,
             "kminmers_per_step": n_kmm,
             "launch_order": launch_order,
+            "smaller_batches": smaller or None,
             "setup_s": {"genome": round(t_genome, 1), "genome_upload": round(t_upload, 2), "gpu_index": round(t_index, 3), "reads": round(t_reads, 1)},
             "index_build": index_build,
             "q60": n_q60,
