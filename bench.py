@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--e2e-fastq-reads", type=int, default=786432,
                     help="reads of the FASTQ + -k 7 leg (BASELINE config 4's shape, experiments/table1.sh:50-55): 786,432 reads = 18.5 Gbases; 0 = skip")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
+    ap.add_argument("--no-smaller-batches", action="store_true", help="skip the `smaller_batches` launches (profiling runs: a profiler's per-kernel "
+                    "averages then cover launches of the step batch only)")
     ap.add_argument("--no-configs", action="store_true", help="skip the kernel-only legs of the other configurations (human-like, maize-like, -k 7)")
     ap.add_argument("--config-reads", type=int, default=0, help="reads per step of the kernel-only legs (0 = --reads)")
     ap.add_argument("--config-sample-reads", type=int, default=8192, help="reads of each leg that the C oracle maps for the column-by-column check")
@@ -549,7 +551,7 @@ def main():
 
     # the same kernel on the first m reads of the batch: what a launch's fixed cost (start-up + tail) does to smaller batches
     smaller = {}
-    if not strong:
+    if not strong and not args.no_smaller_batches:
         for m in (49152, 196608, 786432):
             if m < n:
                 tb = int(offs[m])

@@ -13,7 +13,7 @@ for grp in \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
   "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" ${PMC_EXTRA:-} ; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pass$i" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-e2e --no-configs --steps 3 --warmup 1 "$@" > "$OUT/pass$i.json" 2> "$OUT/pass$i.err" < /dev/null
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/pass$i" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-e2e --no-configs --no-smaller-batches --steps 3 --warmup 1 "$@" > "$OUT/pass$i.json" 2> "$OUT/pass$i.err" < /dev/null
   echo "pass $i ($grp): rc=$?"
 done
 python3 - "$OUT" <<'PY'

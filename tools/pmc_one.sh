@@ -3,7 +3,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$1; CNT=$2; shift 2
 mkdir -p "$OUT"; cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$OUT/p" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-e2e --no-configs --steps 3 --warmup 1 "$@" > "$OUT/bench.json" 2> "$OUT/err.txt"
+timeout 300 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$OUT/p" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-e2e --no-configs --no-smaller-batches --steps 3 --warmup 1 "$@" > "$OUT/bench.json" 2> "$OUT/err.txt"
 python3 - "$OUT" <<'PY'
 import sys, glob, csv, collections
 agg = collections.defaultdict(lambda: [0.0, 0])

@@ -11,7 +11,7 @@ TAG=${1:-prof}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 $ROOT/bench.py --no-cpu-baseline --no-e2e --no-configs --steps 10 --warmup 2 > $OUT/bench_stats.json 2> $OUT/bench_stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 $ROOT/bench.py --no-cpu-baseline --no-e2e --no-configs --no-smaller-batches --steps 10 --warmup 2 > $OUT/bench_stats.json 2> $OUT/bench_stats.err
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 cd $ROOT
 rm -rf $ROOT/gpurun_out/traffic
