@@ -18,7 +18,7 @@
  *   - The caller owns every buffer it passes; the library owns device memory behind mq_index.
  *   - The compute path is HIP only.  There is no CPU fallback: without a usable GPU every compute entry
  *     point fails with MQ_ENODEVICE.
- *   - Limits (checked, MQ_EINVAL otherwise): 1 <= l <= 64, 1 <= k <= 32, sequence length < 2^32.
+ *   - Limits (checked, MQ_EINVAL otherwise): 1 <= l <= 64, 1 <= k <= 32, sequence length < 2^32, fewer than 2^30 reads per batch.
  */
 #ifndef MAPQUIK_HIP_H
 #define MAPQUIK_HIP_H
