@@ -204,10 +204,13 @@ struct NoOp {
 };
 // lds_h / lds_p: the whole list (cnt entries) already in LDS -- then nothing is staged; nullptr: the list is at `base` in device memory.
 // list_done(): called exactly once, when the staged HASHES (S.h) are no longer needed: after the tuple hashes of the list's last chunk.
-template <int CH, bool TIMING, class F = NoOp, bool VAR = true>
+// probes_done(): called exactly once, when the read's last probe has been resolved (nothing of the map phase is in flight any more): in front of
+// the chain stage, or where the chain stage would be for a read without Matches.
+template <int CH, bool TIMING, class F = NoOp, bool VAR = true, class F2 = NoOp>
 __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, MatchRec *scratch, uint32_t r, uint64_t len, uint32_t cnt,
                                          uint64_t base, unsigned long long &t_steps, unsigned long long &t_lookups, mq_hit &h,
-                                         const unsigned long long *lds_h = nullptr, const uint32_t *lds_p = nullptr, const F &list_done = F()) {
+                                         const unsigned long long *lds_h = nullptr, const uint32_t *lds_p = nullptr, const F &list_done = F(),
+                                         const F2 &probes_done = F2()) {
     const uint32_t lane = lane_id();
     const DevParams &P = A.P;
     h.status = MQ_HIT_UNMAPPED;
@@ -215,6 +218,7 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
     uint32_t n_kmm = 0;
     if (cnt == LIST_OVERFLOW) {
         h.status = MQ_HIT_OVERFLOW;  // the list fits neither its region nor the pool: nothing was computed for this read
+        probes_done();
     } else if (cnt >= P.k) {
         mq_kminmer *d = nullptr;
         uint32_t dcap = 0;
@@ -278,6 +282,7 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing was staged: whatever list_done() wants to find in LDS has landed
             list_done();
         }
+        probes_done();
         if (sink.n_matches > 0 && sink.n_matches <= MAP_LDS_RECS && sink.n_matches <= (uint32_t)CH) {
             // all of the read's records are in LDS: lane i takes record i, and the chain stage -- one chunk -- reads no Match record
             wave_sync();
@@ -306,6 +311,7 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         list_done();
+        probes_done();
     }
     h.n_kminmers = n_kmm;
     mq_clk(9);
@@ -325,6 +331,9 @@ constexpr int MAP_WAVES = MQ_MAP_WAVES;
 // and the LDS-direct loads' waits cost the map phase 3.9 k (profiles/NOTES.md).
 #ifndef MQ_LDS_PREFETCH
 #define MQ_LDS_PREFETCH 0
+#endif
+#ifndef MQ_NEXT_READ_PREFETCH
+#define MQ_NEXT_READ_PREFETCH 0
 #endif
 static_assert(!(MQ_LDS_PREFETCH && MQ_LDS_LIST), "MQ_LDS_PREFETCH lands in the staged list's area");
 
@@ -528,7 +537,25 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         };
         map_read<CH, TIMING>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h, nullptr, nullptr, request_next);
 #else
+#if MQ_NEXT_READ_PREFETCH
+        // the next read's first super-row is requested when this read's probes are done: its HBM round trip (9 k cycles of a read's 130 k in
+        // front of stage A, which nothing preceded) runs beside the chain stage.  The descriptor has landed: every load issued after it was
+        // waited for.  (`pre` is assigned on both sides: carried conditionally it would stay alive across the whole map phase.)
+        bool pre_next = false;
+        auto request_next = [&]() {
+            const uint32_t w_ = rdfirst(nd.w), l_ = rdfirst(nd.z);
+            pre_next = rn < n_items && !(w_ & (WORK_SKIP | WORK_TOO_LONG)) && l_ >= 16u && l_ >= P.l + P.k - 1u && !A.force_general;
+            if (pre_next) {
+                stage_a_request(A.bases + (((uint64_t)rdfirst(nd.y) << 32) | rdfirst(nd.x)), l_, 0, pre);
+            } else {
+                pre.nx0 = pre.nx1 = pre.nx2 = pre.nx3 = make_uint4(0u, 0u, 0u, 0u);
+            }
+        };
+        map_read<CH, TIMING, NoOp, VAR>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h, nullptr, nullptr, NoOp(), request_next);
+        pre_valid = pre_next;
+#else
         map_read<CH, TIMING, NoOp, VAR>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h);
+#endif
 #endif
         wave_sync();
         const uint32_t r_done = r;
@@ -561,7 +588,10 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         r = rn < n_items ? (nw & WORK_ID_MASK) : 0xFFFFFFFFu;
         asm volatile("" ::: "memory");  // the prefetched descriptor is out of its registers before the result's store is issued
         store_hit(A, r_done, h);
-        if (rn < n_items && (nw & WORK_SKIP)) take_now();  // that read went first
+        if (rn < n_items && (nw & WORK_SKIP)) {  // that read went first
+            take_now();
+            pre_valid = false;
+        }
         if (TIMING && lane == 0) {
             const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_read0;
             A.mz_count[r_done] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
