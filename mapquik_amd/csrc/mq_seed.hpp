@@ -55,7 +55,7 @@ static_assert(SD_BLOCKS <= 256, "block_of holds block numbers in a byte");
 // workgroup-shared look-up tables (built once per workgroup)
 struct SeedTables {
     uint4 rot[32 * 16];  // index s*16 + (out | in<<2), s = 0..31 : {ror(A,s) lo,hi ; rol(B,s) lo,hi} with the roll terms
-                         //   A = rol(h(out),l)^h(in), B = ror(hc(out),1)^rol(hc(in),l-1); rotation by s+32 = the same entry, halves swapped
+                         //   A = rol(h(out),l)^h(in), B = ror(hc(out),1)^rol(hc(in),l-1); rotation by s+32 = the same entry, halves swapped (32-bit hashes: {ror32(A,s), rol32(B,s)} twice)
     uint4 rem[64];       // index c0 | c1<<2 | c2<<4 : the last l mod 4 Horner steps at once (same form as quad, l mod 4 codes; entry 0 unused when l mod 4 = 0)
     uint4 quad[256];     // index c0 | c1<<2 | c2<<4 | c3<<6 : four Horner steps at once, {F4 lo,hi ; R4 lo,hi} with
                          //   F4 = rol(h(c0),3)^rol(h(c1),2)^rol(h(c2),1)^h(c3),  R4 = ror(X0,3)^ror(X1,2)^ror(X2,1)^X3,  X = rol(hc(c),l-1)
@@ -104,7 +104,8 @@ __device__ __forceinline__ void build_seed_tables(SeedTables &T, uint32_t l, boo
         const uint32_t sft = i >> 4, o = i & 3u, in = (i >> 2) & 3u;
         const uint64_t f = rotr64(rotl64(seed_of(o), l) ^ seed_of(in), sft);
         const uint64_t r = rotl64(rotr64(seed_of(o ^ 2u), 1) ^ rotl64(seed_of(in ^ 2u), l - 1u), sft);
-        T.rot[i] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
+        // (32-bit hashes, seeding variant 4: both halves of f and of r are the 32-bit term; stage_b_block32 reads {f, r} as ONE 8-byte entry)
+        T.rot[i] = h32 ? make_uint4((uint32_t)f, (uint32_t)r, (uint32_t)f, (uint32_t)r) : make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)r, (uint32_t)(r >> 32));
     }
     for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) {
         uint64_t f = 0, r = 0;
@@ -625,6 +626,130 @@ __device__ __forceinline__ void seed_stage_b(const SeedTables &T, SeedLds &S, co
     }
 }
 
+// Stage B of seeding variant 4 (MQ_SEEDVAR_HASH32): ntHash on 32-bit words.  The tables hold the 64-bit form of the duplicated low seed
+// halves (dup(x) = x | x << 32: rol64 of dup = dup of rol32), whose halves ARE the 32-bit roll terms: build_seed_tables stores an entry as
+// {ror32(A32, s), rol32(B32, s)} twice; the rotating frame has period 32 (PH = block number mod 2), a step keeps one word per strand: 2 v_alignbit (F = rol32(G, t),
+// R = ror32(H, t)), v_min, v_cmp ... 2 v_xor ... v_addc and the SDWA table offset: 8 VALU + 1 LDS where the 64-bit frame takes 10 + 1.
+// Same flags as seed_stage_b on the duplicated words (dup(a) <= dup(b) <=> a <= b), which the variant ran on before.
+template <int PH, bool LIM_CHECK>
+__device__ __forceinline__ uint32_t stage_b_block32(const SeedTables &T, uint32_t &g, uint32_t &h, uint2 (&tv)[4], uint32_t xe, uint32_t xo, uint32_t xe_n,
+                                                    uint32_t xo_n, uint32_t bhi, uint32_t lim) {
+    auto off16 = [](uint32_t xe_, uint32_t xo_, uint32_t s) -> uint32_t {  // as in stage_b_block: byte offset of entry (out | in<<2) of step s
+        const uint32_t x = (s & 1u) ? xo_ : xe_, m = s >> 1;
+        uint32_t r;
+        if (m & 1u) {
+            switch (m >> 1) {
+                case 0: r = x & 0xF0u; break;
+                case 1: asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(x), "s"(0xF0u)); break;
+                case 2: asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(x), "s"(0xF0u)); break;
+                default: asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(x), "s"(0xF0u)); break;
+            }
+        } else {
+            switch (m >> 1) {
+                case 0: asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(x), "s"(4u)); break;
+                case 1: asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(x), "s"(4u)); break;
+                case 2: asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(x), "s"(4u)); break;
+                default: asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(x), "s"(4u)); break;
+            }
+        }
+        return r;
+    };
+    auto rot_at = [&T](uint32_t s4, uint32_t off) {  // the entry's first half: one ds_read_b64, the rotation in its immediate offset
+        return *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(&T.rot[s4 * 16u]) + off);
+    };
+    uint32_t fbits = 0;  // step t of the block ends up at bit 15 - t
+#pragma unroll
+    for (uint32_t t = 0; t < 16; ++t) {
+        if (!LIM_CHECK || t < lim) {
+            const uint32_t TT = 16u * (uint32_t)PH + t;  // step number mod 32 (compile-time after unrolling)
+            const uint32_t fh = TT == 0 ? g : __builtin_amdgcn_alignbit(g, g, 32u - TT);  // F = rol32(G, TT)
+            const uint32_t rh = TT == 0 ? h : __builtin_amdgcn_alignbit(h, h, TT);        // R = ror32(H, TT)
+            const uint32_t mhi = fh < rh ? fh : rh;
+            const uint2 e = tv[t & 3u];
+            asm("v_cmp_ge_u32_e32 vcc, %6, %5\n\tv_xor_b32 %0, %0, %3\n\tv_xor_b32 %1, %1, %4\n\tv_addc_co_u32_e32 %2, vcc, %2, %2, vcc"
+                : "+v"(g), "+v"(h), "+v"(fbits) : "v"(e.x), "v"(e.y), "v"(mhi), "s"(bhi) : "vcc");
+            const uint32_t s4 = (TT + 5u) & 31u;  // the look-up of step t + 4 (rotation (TT + 5) mod 32), in flight while the next steps run
+            tv[t & 3u] = (t + 4u < 16u) ? rot_at(s4, off16(xe, xo, t + 4u)) : rot_at(s4, off16(xe_n, xo_n, t + 4u - 16u));
+        }
+    }
+    if (LIM_CHECK) fbits <<= 16u - lim;
+    return fbits;
+}
+
+__device__ __forceinline__ void seed_stage_b32(const SeedTables &T, SeedLds &S, const DevParams &P, uint32_t w_eff) {
+    const uint32_t lane = lane_id();
+    const uint32_t l = P.l;
+    const uint32_t lc = (w_eff + 63u) >> 6;
+    const uint32_t s0 = lane * lc;
+    const uint32_t bhi = (uint32_t)(P.bound >> 32);  // = the 32-bit bound (P.bound is its duplicate)
+    if (s0 < w_eff) {
+        const Hash2 h0 = window_hash(T, S, l, s0);  // duplicated words: either half is the 32-bit hash
+        uint32_t g = h0.flo, h = h0.rlo;
+        auto mk_xe = [](uint32_t ow, uint32_t iw) { return (ow & 0x33333333u) | ((iw & 0x33333333u) << 2); };
+        auto mk_xo = [](uint32_t ow, uint32_t iw) { return ((ow >> 2) & 0x33333333u) | (iw & 0xCCCCCCCCu); };
+        auto nib = [](uint32_t xe, uint32_t xo, uint32_t s) { return (((s & 1u) ? xo : xe) >> (4u * (s >> 1))) & 0xFu; };
+        const uint32_t o_dw = s0 >> 4, o_sh = 2u * (s0 & 15u);
+        const uint32_t i_dw = (s0 + l) >> 4, i_sh = 2u * ((s0 + l) & 15u);
+        uint32_t prev_o = S.codes[o_dw], prev_i = S.codes[i_dw];
+        uint32_t xe, xo;
+        {
+            const uint32_t no = S.codes[o_dw + 1u], ni = S.codes[i_dw + 1u];
+            const uint32_t ow = __builtin_amdgcn_alignbit(no, prev_o, o_sh), iw = __builtin_amdgcn_alignbit(ni, prev_i, i_sh);
+            prev_o = no;
+            prev_i = ni;
+            xe = mk_xe(ow, iw);
+            xo = mk_xo(ow, iw);
+        }
+        uint2 tv[4];
+#pragma unroll
+        for (uint32_t s = 0; s < 4; ++s) {
+            const uint4 e = T.rot[(s + 1u) * 16u + nib(xe, xo, s)];
+            tv[s] = make_uint2(e.x, e.y);
+        }
+        const uint32_t nb = (lc + 15u) >> 4;
+        auto next_x = [&](uint32_t b, uint32_t &xe_n, uint32_t &xo_n) {
+            const uint32_t no = S.codes[o_dw + b + 2u], ni = S.codes[i_dw + b + 2u];
+            const uint32_t ow = __builtin_amdgcn_alignbit(no, prev_o, o_sh), iw = __builtin_amdgcn_alignbit(ni, prev_i, i_sh);
+            prev_o = no;
+            prev_i = ni;
+            xe_n = mk_xe(ow, iw);
+            xo_n = mk_xo(ow, iw);
+        };
+        auto put = [&](uint32_t w_at, uint32_t v) { S.flagw[w_at * 64u + lane] = v; };
+        uint32_t blk = 0;
+        for (const uint32_t full = (lc >> 5) << 1; blk < full; blk += 2u) {  // whole 32-step groups: the frame's two phases back to back, one flag word
+            uint32_t xe1, xo1, xe2, xo2;
+            next_x(blk, xe1, xo1);
+            const uint32_t b0 = stage_b_block32<0, false>(T, g, h, tv, xe, xo, xe1, xo1, bhi, 16u);
+            next_x(blk + 1u, xe2, xo2);
+            const uint32_t b1 = stage_b_block32<1, false>(T, g, h, tv, xe1, xo1, xe2, xo2, bhi, 16u);
+            put(blk >> 1, (__brev(b0) >> 16) | (__brev(b1) & 0xFFFF0000u));  // bit t <=> step t
+            xe = xe2;
+            xo = xo2;
+        }
+        uint32_t word = 0;  // the last, incomplete group: up to two blocks, the last of them possibly partial
+        for (; blk < nb; ++blk) {
+            uint32_t xe_n, xo_n;
+            next_x(blk, xe_n, xo_n);
+            const uint32_t lim = lc - 16u * blk;
+            uint32_t fbits;
+            if (lim >= 16u) {
+                fbits = (blk & 1u) ? stage_b_block32<1, false>(T, g, h, tv, xe, xo, xe_n, xo_n, bhi, 16u) : stage_b_block32<0, false>(T, g, h, tv, xe, xo, xe_n, xo_n, bhi, 16u);
+            } else {
+                fbits = (blk & 1u) ? stage_b_block32<1, true>(T, g, h, tv, xe, xo, xe_n, xo_n, bhi, lim) : stage_b_block32<0, true>(T, g, h, tv, xe, xo, xe_n, xo_n, bhi, lim);
+            }
+            if (blk & 1u) {
+                put(blk >> 1, word | (__brev(fbits) & 0xFFFF0000u));
+            } else {
+                word = __brev(fbits) >> 16;
+            }
+            xe = xe_n;
+            xo = xo_n;
+        }
+        if (nb & 1u) put(nb >> 1, word);
+    }
+}
+
 // ------------------------------------------------------------------ stage R
 // r-th run head (0-based) of a 64-base block with head mask m
 __device__ __forceinline__ uint32_t select_bit64(unsigned long long m, uint32_t r) {
@@ -840,7 +965,8 @@ __device__ __forceinline__ uint32_t seed_sequence_fast_to(const uint8_t *__restr
         const bool more = raw_end < len;
         if (STOP != 1 && n_codes >= P.l) {
             const uint32_t w_eff = n_codes - P.l + 1u;
-            seed_stage_b(T, S, P, w_eff);
+            if (var_h32<VAR>(P)) seed_stage_b32(T, S, P, w_eff);  // seeding variant 4: one word per strand
+            else seed_stage_b(T, S, P, w_eff);
             mq_clk(1);
             if (STOP != 2) {
                 bool inexact = false;
