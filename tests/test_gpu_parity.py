@@ -617,8 +617,10 @@ def test_fuzz_params_and_sequences(mq, oracle, simlib):
         variant = 0
         if it % 3 == 2:
             variant = int(rng.choice([1, 2, 4, 8, 16, 32, 12, 24, 28, 63]))
-            if l < 2:
-                variant &= ~8
+        if os.environ.get("MQ_FUZZ_VARIANT"):  # a campaign on one variant's code paths (e.g. 4: stage B on two dwords)
+            variant = int(os.environ["MQ_FUZZ_VARIANT"])
+        if l < 2:
+            variant &= ~8
         oracle.lib().mqo_set_variant(variant)
         try:
             ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads2, ps, variant)
