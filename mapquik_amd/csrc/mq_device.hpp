@@ -183,6 +183,19 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
     return x;
 }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return rdlane(wave_incl_scan_u32(v), 63); }
+// the same scan with XOR (the general seeder's prefix of rotated seeds), on the two halves of a 64-bit word
+__device__ __forceinline__ uint32_t wave_incl_xor_scan_u32(uint32_t x) {
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return x;
+}
+__device__ __forceinline__ uint64_t wave_incl_xor_scan_u64(uint64_t v) {
+    return ((uint64_t)wave_incl_xor_scan_u32((uint32_t)(v >> 32)) << 32) | wave_incl_xor_scan_u32((uint32_t)v);
+}
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
     auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
     x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));
@@ -406,14 +419,8 @@ __device__ __forceinline__ void seed_segment(const uint8_t *__restrict__ seq, ui
         const uint32_t code = valid ? (uint32_t)S.ring_code[idx & (RING - 1)] : 4u;
         uint64_t tf = rotr64(nt_seed(code, h32), lane);
         uint64_t tr = rotl64(nt_seed(comp_code(code), h32), lane);
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint64_t of = shfl_up64(tf, d), orr = shfl_up64(tr, d);
-            if (lane >= (uint32_t)d) {
-                tf ^= of;
-                tr ^= orr;
-            }
-        }
+        tf = wave_incl_xor_scan_u64(tf);  // DPP row shifts and broadcasts (as ds_bpermute steps each of the six was an LDS round trip)
+        tr = wave_incl_xor_scan_u64(tr);
         tf ^= carryF;
         tr ^= carryR;
         const uint64_t of = shfl64(src_cur ? tf : prevF, (int)from);
@@ -440,10 +447,16 @@ __device__ __forceinline__ void seed_segment(const uint8_t *__restrict__ seq, ui
         sink.on_minimizers(S, mz_count);
     };
 
+    // the bytes of the two blocks after the current one are on their way while it is processed (loaded where they are used, every one of the
+    // loop's iterations opened with a memory round trip: 375 of them for a 24-kb read, most of what such a read cost)
+    uint32_t nb1 = a + lane < len ? (uint32_t)seq[a + lane] : 0u;
+    uint32_t nb2 = a + 64u + lane < len ? (uint32_t)seq[a + 64u + lane] : 0u;
     for (uint64_t pos = a;; pos += 64) {
         const uint64_t i = pos + lane;
         const bool inr = i < len;
-        uint32_t bt = inr ? (uint32_t)seq[i] : 0u;
+        uint32_t bt = nb1;
+        nb1 = nb2;
+        nb2 = i + 128u < len ? (uint32_t)seq[i + 128u] : 0u;
         if (P.fold && bt - 'a' < 26u) bt -= 32u;
         uint32_t pb = (uint32_t)__shfl_up((int)bt, 1, 64);
         if (lane == 0) pb = prev_byte;
