@@ -458,8 +458,8 @@ __device__ __forceinline__ void seed_segment(const uint8_t *__restrict__ seq, ui
         nb1 = nb2;
         nb2 = i + 128u < len ? (uint32_t)seq[i + 128u] : 0u;
         if (P.fold && bt - 'a' < 26u) bt -= 32u;
-        uint32_t pb = (uint32_t)__shfl_up((int)bt, 1, 64);
-        if (lane == 0) pb = prev_byte;
+        // the byte in front of every lane's: a DPP wave shift (lane 0 keeps `old` = the previous block's last byte)
+        const uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp((int)prev_byte, (int)bt, 0x138, 0xf, 0xf, false);  // wave_shr:1
         const bool head = inr && (!P.use_hpc || bt != pb);
         const uint64_t hm = __ballot(head);
         if (head) {
