@@ -58,7 +58,7 @@ struct SplitArgs {
 // Which reads go first: those that look like a short-period tandem array.  A read inside an array of period p < l has p distinct l-mers;
 // when one of them passes the density test the read lists a minimizer every p bases -- thousands instead of ~350 -- and costs its wave 10-40
 // times the ordinary read (profiles/r05_read_tail.txt).  Taken up in the last third of a launch such a read IS the launch's tail (every
-// other wave has left); taken up first it costs nothing but its own work.  The test (three windows of 48 bases at 1/6, 3/6, 5/6 of the read:
+// other wave has left); taken up first it costs nothing but its own work.  The test (three windows of 48 bases near 1/6, 3/6, 5/6 of the read:
 // some lag 1..16 matches in >= 27 of 32 positions) costs ~800 instructions per READ against map_kernel's ~13,000 per read per WAVE;
 // it flags 0.1-0.3 % of the reads of a human-like batch, among them every read with > 10 x the median minimizer count and 21 of 23
 // with > 5 x (tools/heavy_study.py).  The order changes nothing but the order: results are stored by read number.
@@ -96,9 +96,11 @@ __global__ __launch_bounds__(256) void order_reads_kernel(const SplitArgs A) {
     uint32_t w = r;
     if (len >> 32) w |= WORK_TOO_LONG;
     else if (A.heavy_first && len >= 512u) {
-        const uint8_t *seq = A.bases + o0;
+        // (a window starts at a multiple of 64 bytes of the batch: its 48 bytes come from one 64-byte sector -- the pass is bound by the sectors it touches)
         const uint32_t ln = (uint32_t)len;
-        if (window_periodic(seq + ln / 6u) || window_periodic(seq + ln / 2u) || window_periodic(seq + (ln / 6u) * 5u)) {
+        auto win = [&](uint32_t at) { return A.bases + ((o0 + at) & ~(uint64_t)63); };  // ln >= 512: at >= 85, the window lies inside the read
+        const bool p1 = window_periodic(win(ln / 6u)), p2 = window_periodic(win(ln / 2u)), p3 = window_periodic(win((ln / 6u) * 5u));  // (no short cut: the three windows' loads are in flight together)
+        if (p1 | p2 | p3) {
             const uint32_t k = atomicAdd(&A.counters[WORK_NF], 1u);
             if (k < WORK_FRONT_CAP) {
                 A.work[WORK_FRONT_CAP - 1u - k] = make_uint4((uint32_t)o0, (uint32_t)(o0 >> 32), ln, w);

@@ -31,7 +31,7 @@ def _flagged(bases, offs):
         if ln < 512:
             out.append(False)
             continue
-        out.append(any(_periodic(bases[o + at:o + at + 48]) for at in (ln // 6, ln // 2, (ln // 6) * 5)))
+        out.append(any(_periodic(bases[w:w + 48]) for w in (((o + at) // 64) * 64 for at in (ln // 6, ln // 2, (ln // 6) * 5))))  # windows start at multiples of 64 bytes of the batch
     return np.array(out)
 
 
