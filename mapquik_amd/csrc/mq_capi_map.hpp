@@ -65,6 +65,16 @@ static int launch_map(mq_ctx *c, const uint8_t *d_bases, const uint64_t *d_offse
         else if (idx->chain_chunk == 4) hipLaunchKernelGGL((map_kernel<4, false>), dim3(grid), blk, 0, st, A);
         else hipLaunchKernelGGL((map_kernel<64, false>), dim3(grid), blk, 0, st, A);
         HIPCHK(hipGetLastError());
+        // the reads the fast seeder declined (queue length on the device: map_kernel's grid, its waves leave at once when there are none)
+        const uint32_t gd = grid;
+        if (idx->dp.variant) {
+            if (o.instrumented) hipLaunchKernelGGL((map_declined_kernel<64, true, true>), dim3(gd), blk, 0, st, A);
+            else if (idx->chain_chunk == 4) hipLaunchKernelGGL((map_declined_kernel<4, false, true>), dim3(gd), blk, 0, st, A);
+            else hipLaunchKernelGGL((map_declined_kernel<64, false, true>), dim3(gd), blk, 0, st, A);
+        } else if (o.instrumented) hipLaunchKernelGGL((map_declined_kernel<64, true>), dim3(gd), blk, 0, st, A);
+        else if (idx->chain_chunk == 4) hipLaunchKernelGGL((map_declined_kernel<4, false>), dim3(gd), blk, 0, st, A);
+        else hipLaunchKernelGGL((map_declined_kernel<64, false>), dim3(gd), blk, 0, st, A);
+        HIPCHK(hipGetLastError());
     } else {
         const uint32_t gs = std::min<uint32_t>(idx->grid_seed, (n + SEED_WAVES - 1) / SEED_WAVES);
         const char *ss = getenv("MQ_SEED_STOP");  // diagnostic: stage attribution by truncation (results are NOT valid)

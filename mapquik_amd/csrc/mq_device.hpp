@@ -395,9 +395,58 @@ __device__ __forceinline__ bool probe_table(const Bucket *__restrict__ table, ui
 // ------------------------------------------------------------------ streaming seeder
 // Emits, in order, every minimizer whose l-mer starts at a homopolymer-run head with raw index in [a, b).
 // Sink interface: void on_minimizers(WaveLds&, uint32_t &mz_count)  (called after each block, wave-uniform)
+// 16 bytes at `at` of a sequence of len bytes (those at or behind len read as 0); n = how many of them are inside
+__device__ __forceinline__ uint4 load16_tail(const uint8_t *__restrict__ seq, uint64_t len, uint64_t at, uint32_t &n) {
+    typedef uint4 __attribute__((aligned(1))) uint4_u;
+    if (at + 16u <= len) {
+        n = 16u;
+        return *reinterpret_cast<const uint4_u *>(seq + at);
+    }
+    n = at < len ? (uint32_t)(len - at) : 0u;
+    uint64_t lo = 0, hi = 0;  // (the sequence's last piece only; no array: a dynamically indexed one lives in scratch memory)
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint64_t b = seq[at + j];
+        if (j < 8u) lo |= b << (8u * j);
+        else hi |= b << (8u * (j - 8u));
+    }
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+// first position >= from whose byte differs from v (compared as the general seeder compares: a-z as A-Z when folding), or len; 4 KB a step
+__device__ __forceinline__ uint64_t next_byte_differing(const uint8_t *__restrict__ seq, uint64_t len, uint64_t from, uint32_t v, bool fold) {
+    const uint32_t lane = lane_id();
+    const uint32_t m8 = (fold && v - 'A' < 26u) ? 0xDFu : 0xFFu;  // v is what a byte folds TO: a letter matches its lower case too
+    const uint32_t mm = m8 * 0x01010101u, vv = (v & 0xFFu) * 0x01010101u;
+    if (v > 0xFFu) return from;  // no byte at all (the sequence's start)
+    for (uint64_t p = from; p < len; p += 4096u) {
+        const uint64_t at = p + 64u * lane;
+        uint32_t first = 64u;  // index of the lane's first differing byte
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            uint32_t n;
+            const uint4 q = load16_tail(seq, len, at + 16u * (uint32_t)j, n);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int i = 3; i >= 0; --i) {
+                const uint32_t d = (w[i] & mm) ^ vv;
+                if (d) {
+                    const uint32_t k = 16u * (uint32_t)j + 4u * (uint32_t)i + ((uint32_t)__ffs((int)d) - 1u) / 8u;
+                    if (k < 16u * (uint32_t)j + n) first = k;  // (bytes behind len read as 0: not a difference)
+                }
+            }
+        }
+        const uint64_t m = __ballot(first < 64u);
+        if (m) {
+            const int l0 = __ffsll((long long)m) - 1;
+            return p + 64u * (uint32_t)l0 + rdlane(first, l0);
+        }
+    }
+    return len;
+}
+// min_last > 0: only windows whose LAST compressed base lies at or behind raw position min_last (seed_read_hybrid: the windows that lie
+// wholly in front of it were listed by the fast seeder)
 template <bool VAR = true, class Sink>
 __device__ __forceinline__ void seed_segment(const uint8_t *__restrict__ seq, uint64_t len, uint64_t a, uint64_t b,
-                                             const DevParams &P, WaveLds &S, Sink &sink, uint32_t &mz_count) {
+                                             const DevParams &P, WaveLds &S, Sink &sink, uint32_t &mz_count, uint64_t min_last = 0) {
     const uint32_t lane = lane_id();
     const uint32_t l = P.l;
     if (a >= len || a >= b) return;
@@ -429,7 +478,8 @@ __device__ __forceinline__ void seed_segment(const uint8_t *__restrict__ seq, ui
         const uint64_t rh = rotr64(tr ^ orr, rot_r);
         const uint64_t h = fh < rh ? fh : rh;
         const uint32_t j = idx - (l - 1u);  // HPC index of the window's first base
-        const bool sel = valid && idx >= l - 1u && j < s_elig && h <= P.bound && !var_keep_none<VAR>(P);
+        const bool sel = valid && idx >= l - 1u && j < s_elig && h <= P.bound && !var_keep_none<VAR>(P) &&
+                         (min_last == 0 || (uint64_t)S.ring_pos[idx & (RING - 1)] >= min_last);
         const uint64_t sm = __ballot(sel);
         if (sel) {
             const uint32_t o = mz_count + mbcnt64(sm);
@@ -447,16 +497,19 @@ __device__ __forceinline__ void seed_segment(const uint8_t *__restrict__ seq, ui
         sink.on_minimizers(S, mz_count);
     };
 
-    // the bytes of the two blocks after the current one are on their way while it is processed (loaded where they are used, every one of the
+    // the bytes of the AHEAD blocks after the current one are on their way while it is processed (loaded where they are used, every one of the
     // loop's iterations opened with a memory round trip: 375 of them for a 24-kb read, most of what such a read cost)
-    uint32_t nb1 = a + lane < len ? (uint32_t)seq[a + lane] : 0u;
-    uint32_t nb2 = a + 64u + lane < len ? (uint32_t)seq[a + 64u + lane] : 0u;
+    constexpr int AHEAD = 8;  // blocks in flight: two covered a third of the latency a wave sees with the chip busy
+    uint32_t nb[AHEAD];
+#pragma unroll
+    for (int j = 0; j < AHEAD; ++j) nb[j] = a + 64u * (uint32_t)j + lane < len ? (uint32_t)seq[a + 64u * (uint32_t)j + lane] : 0u;
     for (uint64_t pos = a;; pos += 64) {
         const uint64_t i = pos + lane;
         const bool inr = i < len;
-        uint32_t bt = nb1;
-        nb1 = nb2;
-        nb2 = i + 128u < len ? (uint32_t)seq[i + 128u] : 0u;
+        uint32_t bt = nb[0];
+#pragma unroll
+        for (int j = 0; j + 1 < AHEAD; ++j) nb[j] = nb[j + 1];
+        nb[AHEAD - 1] = i + 64u * AHEAD < len ? (uint32_t)seq[i + 64u * AHEAD] : 0u;
         if (P.fold && bt - 'a' < 26u) bt -= 32u;
         // the byte in front of every lane's: a DPP wave shift (lane 0 keeps `old` = the previous block's last byte)
         const uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp((int)prev_byte, (int)bt, 0x138, 0xf, 0xf, false);  // wave_shr:1
@@ -475,6 +528,19 @@ __device__ __forceinline__ void seed_segment(const uint8_t *__restrict__ seq, ui
         if (hbase - hproc >= 64u) {
             process_block(64u);
             hproc += 64u;
+        }
+        if (P.use_hpc && hm == 0ull && inm == ~0ull && __ballot(nb[0] != prev_byte || nb[1] != prev_byte) == 0ull && pos + 192u <= len && !(P.fold && prev_byte - 'A' < 26u)) {
+            // 192 bytes that all repeat the byte in front of them (a gap of the reference: tens of thousands of N; a long homopolymer run): jump to
+            // the block that holds the next different byte -- nothing in between is a run head.  (Only behind three such blocks: a READ from a
+            // gap carries the simulator's or the sequencer's errors every ~100 bytes, and the scan costs more than the two blocks it would skip.
+            // nb1 / nb2 are raw bytes: with folding a letter's two cases would have to be told apart -- left to the ordinary walk)
+            const uint64_t q = next_byte_differing(seq, len, pos + 64u, prev_byte, P.fold != 0);
+            const uint64_t skip = ((q - (pos + 64u)) >> 6) << 6;
+            if (skip) {
+                pos += skip;
+#pragma unroll
+                for (int j = 0; j < AHEAD; ++j) nb[j] = pos + 64u * (uint32_t)(j + 1) + lane < len ? (uint32_t)seq[pos + 64u * (uint32_t)(j + 1) + lane] : 0u;
+            }
         }
         const bool end_of_seq = pos + 64 >= len;
         // behind b: done once the last eligible window is complete -- or at once when no run head lies in [a, b) at all (a segment inside

@@ -167,6 +167,165 @@ __device__ __forceinline__ uint32_t seed_read_general(const SplitArgs &A, WaveLd
     return cnt;
 }
 
+// ------------------------------------------------------------------- reads the fast seeder declined: stretch by stretch
+// The fast seeder takes sequences of A C G T; a read with anything else (a run of N from a gap of the reference it was drawn from) went through
+// the general streaming seeder whole, at 8-13 x the cost.  seed_read_hybrid cuts such a read: every stretch of >= HYB_MIN_CLEAN bytes (whole
+// 64-byte blocks) of A C G T is seeded by the fast seeder as a sequence of its own (a VIEW: positions shifted, the byte in front of it known) -- that lists exactly the
+// windows that lie wholly inside the stretch -- and the general seeder lists the rest: the windows that start between two stretches, and those
+// that start in the last l - 1 run heads of a stretch and reach past its end (seed_segment's min_last filter drops the ones the fast seeder
+// listed).  Same list as the general seeder's over the whole read (tests: MQ_FORCE_GENERAL=1 takes that one).
+constexpr uint32_t HYB_MIN_CLEAN = 2048;
+// bit i: the 64-byte block at p + 64 i (p a multiple of 64) lies inside the sequence and holds only A C G T (a c g t too when folding); 4 KB a call
+__device__ __forceinline__ uint64_t clean_blocks(const uint8_t *__restrict__ seq, uint64_t len, uint64_t p, bool fold) {
+    const uint64_t at = p + 64u * lane_id();
+    bool ok = false;
+    if (at + 64u <= len) {
+        const uint32_t fm = fold ? 0xDFDFDFDFu : 0xFFFFFFFFu;
+        uint4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const uint4_unaligned *>(seq + at + 16 * j);
+        uint32_t all = 0x80808080u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t x = w[i] & fm;
+                uint32_t is = 0;  // 0x80 in every byte that is A, C, G or T: exact zero-byte masks of x ^ letter
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint32_t y = x ^ (t == 0 ? 0x41414141u : t == 1 ? 0x43434343u : t == 2 ? 0x47474747u : 0x54545454u);
+                    is |= ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
+                }
+                all &= is;
+            }
+        }
+        ok = all == 0x80808080u;
+    }
+    return __ballot(ok);
+}
+// the first run of at least HYB_MIN_CLEAN / 64 consecutive clean blocks at or behind `from` (a multiple of 64): [s, d), both multiples of 64; false: none.
+// One pass over the bytes between `from` and d, however the other bytes are spread.
+__device__ __forceinline__ bool next_clean_stretch(const uint8_t *__restrict__ seq, uint64_t len, uint64_t from, bool fold, uint64_t &s, uint64_t &d) {
+    constexpr uint64_t NONE = ~(uint64_t)0;
+    uint64_t run_s = NONE;
+    for (uint64_t p = from; p < len; p += 4096u) {
+        const uint64_t m = clean_blocks(seq, len, p, fold);
+        uint32_t bit = 0;
+        while (bit < 64u) {
+            if (run_s == NONE) {
+                const uint64_t rest = m >> bit;
+                if (!rest) break;
+                bit += (uint32_t)__ffsll((long long)rest) - 1u;
+                run_s = p + 64u * bit;
+            }
+            const uint64_t rest0 = ~(m >> bit);  // (the bits shifted in from above read as "not clean": a run never passes bit 63 here)
+            const uint32_t z = (uint32_t)__ffsll((long long)rest0) - 1u;
+            if (bit + z >= 64u) break;  // the run goes on into the next 4 KB
+            const uint64_t run_e = p + 64u * (bit + z);
+            if (run_e - run_s >= HYB_MIN_CLEAN) {
+                s = run_s;
+                d = run_e;
+                return true;
+            }
+            run_s = NONE;
+            bit += z;
+        }
+    }
+    if (run_s != NONE) {  // a run up to the sequence's last whole block
+        const uint64_t run_e = len & ~(uint64_t)63;
+        if (run_e > run_s && run_e - run_s >= HYB_MIN_CLEAN) {
+            s = run_s;
+            d = run_e;
+            return true;
+        }
+    }
+    return false;
+}
+// a0 in [lo, d] such that [a0, d) holds at least `need` run heads (or a0 = lo): where the general seeder has to start for the windows that reach d
+__device__ __forceinline__ uint64_t heads_back(const uint8_t *__restrict__ seq, uint64_t lo, uint64_t d, uint32_t need, const DevParams &P) {
+    const uint32_t lane = lane_id();
+    uint64_t a0 = d;
+    uint32_t heads = 0;
+    while (a0 > lo && heads < need) {
+        const uint32_t step = a0 - lo < 64u ? (uint32_t)(a0 - lo) : 64u;
+        a0 -= step;
+        bool head = false;
+        if (lane < step) {
+            const uint64_t i = a0 + lane;
+            uint32_t b = seq[i], pb = i > 0 ? (uint32_t)seq[i - 1] : 0x100u;
+            if (P.fold && b - 'a' < 26u) b -= 32u;
+            if (P.fold && pb - 'a' < 26u) pb -= 32u;
+            head = !P.use_hpc || b != pb;
+        }
+        heads += (uint32_t)__popcll(__ballot(head));
+    }
+    return a0;
+}
+template <bool VAR = true>
+__device__ __forceinline__ uint32_t seed_read_hybrid(const SplitArgs &A, const SeedTables &T, SeedLds &SF, WaveLds &SG, const uint8_t *seq, uint64_t len,
+                                                     uint64_t &base, uint32_t cap, uint32_t &n_moved) {
+    const DevParams &P = A.P;
+    auto pass = [&](uint64_t base_, uint32_t cap_) -> uint32_t {
+        uint32_t n_out = 0;
+        auto general = [&](uint64_t a, uint64_t b, uint64_t min_last) {
+            wave_sync();
+            SoaListSink sink(A.mz_hash + base_ + n_out, A.mz_pos + base_ + n_out, (VAR && A.mz_last) ? A.mz_last + base_ + n_out : nullptr, cap_ > n_out ? cap_ - n_out : 0u);
+            uint32_t mzc = 0;
+            seed_segment<VAR>(seq, len, a, b, P, SG, sink, mzc, min_last);
+            n_out += sink.written;
+            wave_sync();
+        };
+        if (A.force_general || len < 16u || (len >> 32)) {  // the test hook; the scanner's precondition; beyond the fast seeder's range
+            general(0, len, 0);
+            return n_out;
+        }
+        uint64_t seg_a = 0, seg_min_last = 0;  // the open general segment: windows that start at or behind seg_a (and end at or behind seg_min_last)
+        uint64_t pos = 0, s = 0, d = 0;
+        while (pos < len && next_clean_stretch(seq, len, pos, P.fold != 0, s, d)) {  // [s, d): whole 64-byte blocks of A C G T, at least HYB_MIN_CLEAN bytes
+            pos = d;
+            if (d - s > 0xFFFFFF00ull) continue;
+            if (s > seg_a) general(seg_a, s, seg_min_last);  // the windows that start in front of the stretch
+            APre pre;
+            SeedView V;
+            V.first_prev = 4u;
+            if (s > 0) {  // the byte in front of the stretch as the seeder's 2-bit code (the stretch may begin inside a run: its first base is then no run head)
+                uint32_t b = seq[s - 1];
+                if (P.fold && b - 'a' < 26u) b -= 32u;
+                V.first_prev = b == 'A' ? 0u : b == 'C' ? 1u : b == 'T' ? 2u : b == 'G' ? 3u : 4u;
+            }
+            V.elig_end = (uint32_t)(((d - s) + 127u) & ~(uint64_t)63);
+            V.pos_add = (uint32_t)s;
+            V.more_after = 0u;
+            const uint32_t left = cap_ > n_out ? cap_ - n_out : 0u;
+            const uint32_t c = seed_sequence_fast<0, true, VAR>(seq + s, (uint32_t)(d - s), P, T, SF, A.mz_hash + base_ + n_out, A.mz_pos + base_ + n_out, left, pre, false, V,
+                                                                A.mz_last ? A.mz_last + base_ + n_out : nullptr);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_sync();
+            if (c == SD_NOT_FAST) {  // (a candidate on the bound: the general seeder's test is exact) the stretch joins the general segment
+                seg_a = s;
+                seg_min_last = 0;
+            } else {
+                n_out += c;
+                seg_a = heads_back(seq, s, d, P.l - 1u, P);
+                seg_min_last = d;
+            }
+        }
+        if (seg_a < len && seg_min_last < len) general(seg_a, len, seg_min_last);
+        return n_out;
+    };
+    uint32_t cnt = pass(base, cap);
+    if (cnt > cap) {  // denser than its region: once more, into an exact-size pool region
+        if (pool_take(A, cnt, base)) {
+            pass(base, cnt);
+            n_moved++;
+        } else {
+            cnt = LIST_OVERFLOW;
+        }
+    }
+    return cnt;
+}
+
 // 6: a 24-kb HiFi read lists ~350 minimizers = 5.4 lane-batches, so six cover four reads in five in one chunk; 7 (rounds 3-4) covered
 // nearly all at two more key + four more payload registers across probe_all: 1255-1257 against 1249-1250 Gbases/s (round 5, same box); 8
 // does not fit 128 registers at all (169)
@@ -472,8 +631,15 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
 #endif
             if (cnt == SD_NOT_FAST) {
                 n_general++;
+#if MQ_LDS_PREFETCH || MQ_LDS_LIST
                 wave_sync();
                 cnt = seed_read_general<VAR>(A, S.general, A.bases + o0, len, base, cap, n_moved);
+#else
+                // a byte other than A C G T (or a candidate on the bound): the read is queued for map_declined_kernel, which seeds it stretch
+                // by stretch and maps it (what is stored for it here -- an unmapped record -- is overwritten there)
+                if (lane == 0) A.queue[atomicAdd(&A.counters[2], 1u)] = r;
+                cnt = 0;
+#endif
                 mq_clk(10);
             } else {
                 n_fast++;
@@ -612,6 +778,63 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
 #ifdef MQ_STAGE_CLOCKS
         for (int i = 0; i < MQ_N_CLK; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(A.counters + 16) + i, mq_clk_lds().acc[wv][i]);
 #endif
+    }
+}
+
+// The reads map_kernel queued (the fast seeder declined them): seeded stretch by stretch (seed_read_hybrid), mapped, stored.  Launched behind
+// map_kernel in every launch sequence; its waves leave at once when the queue is empty.
+template <int CH, bool TIMING = false, bool VAR = false>
+__global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_declined_kernel(const SplitArgs A) {
+    const uint32_t nq = A.counters[2];
+    if (nq == 0) return;
+    __shared__ struct {
+        SeedTables T;
+        MapWaveLds SS[MAP_WAVES];
+    } W;
+    build_seed_tables(W.T, A.P.l, var_h32<VAR>(A.P));
+    __syncthreads();
+    const uint32_t lane = lane_id();
+    const uint32_t wv = rdfirst(threadIdx.x >> 6);
+    MapWaveLds &S = W.SS[wv];
+    const size_t wave_gid = (size_t)blockIdx.x * MAP_WAVES + wv;
+    MatchRec *scratch = A.scratch_all + wave_gid * A.cap_matches;
+    const uint64_t o_base = A.offsets[0];
+    uint32_t n_moved = 0;
+    unsigned long long t_steps = 0, t_lookups = 0;
+    for (;;) {
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(&A.counters[3], 1u);
+        i = rdfirst(i);
+        if (i >= nq) break;
+        const uint32_t r = A.queue[i];
+        const unsigned long long t_read0 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long t_real0 = TIMING ? __builtin_amdgcn_s_memrealtime() : 0ull;
+        const uint64_t o0 = A.offsets[r];
+        const uint64_t len = A.lens ? (uint64_t)A.lens[r] : A.offsets[r + 1] - o0;
+        uint64_t base;
+        uint32_t cap;
+        list_region(A, o0 - o_base, len, r, base, cap);
+        const uint32_t cnt = seed_read_hybrid<VAR>(A, W.T, S.seed, S.general, A.bases + o0, len, base, cap, n_moved);
+        const unsigned long long t_seeded = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have reached L2
+        wave_sync();
+        mq_hit h;
+        map_read<CH, TIMING, NoOp, VAR>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h);
+        wave_sync();
+        store_hit(A, r, h);
+        if (TIMING && lane == 0) {  // mq_last_read_cycles: this read's cycles here (seeding in the high half of the start word's place: see tools/read_tail.py)
+            const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_read0;
+            A.mz_count[r] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
+            A.mz_base[r] = t_real0;
+            (void)t_seeded;
+        }
+    }
+    if (lane == 0) {
+        if (n_moved) atomicAdd(&A.counters[6], n_moved);
+        if (TIMING) {
+            atomicAdd(&A.stats64[0], t_steps);
+            atomicAdd(&A.stats64[1], t_lookups);
+        }
     }
 }
 

@@ -19,15 +19,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=196608)
     ap.add_argument("--genome-scale", type=float, default=1.0)
-    ap.add_argument("--genome-preset", choices=("planted-repeats", "human-like"), default="planted-repeats")
+    ap.add_argument("--genome-preset", choices=("planted-repeats", "human-like", "maize-like"), default="planted-repeats")
     ap.add_argument("--seeding-variant", type=int, default=0)
     a = ap.parse_args()
     import torch
     import mapquik_amd as mq
     from tools import sim
     dev = torch.device("cuda", 0)
-    lens = [max(40, int(x * a.genome_scale)) for x in sim.CHM13_LIKE]
-    kw = sim.HUMAN_LIKE if a.genome_preset == "human-like" else dict(repeat_frac=0.05, tandem_frac=0.01, div=0.01)
+    lens = [max(40, int(x * a.genome_scale)) for x in (sim.MAIZE_LIKE if a.genome_preset == "maize-like" else sim.CHM13_LIKE)]
+    kw = (sim.HUMAN_LIKE if a.genome_preset == "human-like" else
+          dict(family_frac=1.9, n_families=400, family_div=(0.005, 0.025), tandem_frac=0.02, n_runs=300) if a.genome_preset == "maize-like" else
+          dict(repeat_frac=0.05, tandem_frac=0.01, div=0.01))
     g, off, names = sim.make_genome(lens, seed=2013, threads=16, **kw)
     ix = mq.Index(mq.Params(seeding_variant=a.seeding_variant), device=0)
     for r in range(len(lens)):
@@ -62,8 +64,14 @@ def main():
     lens_r = (offs[1:] - offs[:-1]).astype(np.int64)
     print("the 25 most expensive reads (cycles, x median, bases, k-min-mers, status, score, taken up at [us], true origin):")
     for i in order:
-        print("  %9d %6.1fx %6d %5d  st %d score %4d  at %7.1f us  %s:%d%s" % (cyc[i], c[i] / np.median(c), lens_r[i], hits["n_kminmers"][i], hits["status"][i], hits["score"][i],
-                                                                           (int(start[i]) - t0) / 100.0, names[int(reads["ctg"][i])], int(reads["start"][i]), "-" if reads["strand"][i] else "+"))
+        rb = reads["bases"][int(offs[i]):int(offs[i + 1])]
+        print("  %9d %6.1fx %6d %5d  st %d score %4d  at %7.1f us  %s:%d%s  other bytes %d" % (cyc[i], c[i] / np.median(c), lens_r[i], hits["n_kminmers"][i], hits["status"][i], hits["score"][i],
+                                                                           (int(start[i]) - t0) / 100.0, names[int(reads["ctg"][i])], int(reads["start"][i]), "-" if reads["strand"][i] else "+",
+                                                                           int((~np.isin(rb, np.frombuffer(b"ACGT", dtype=np.uint8))).sum())))
+    nn = np.array([int((~np.isin(reads["bases"][int(offs[i]):int(offs[i + 1])], np.frombuffer(b"ACGT", dtype=np.uint8))).sum()) for i in np.nonzero(c > 3 * np.median(c))[0]])
+    dirty = np.nonzero(c > 3 * np.median(c))[0][nn > 0]
+    if dirty.size:
+        print("reads with other bytes among those > 3x the median: %d; their cycles: mean %.0f median %.0f; other bytes per read: median %d" % (dirty.size, c[dirty].mean(), np.median(c[dirty]), int(np.median(nn[nn > 0]))))
     # what a read costs by when it was taken up: the launch's start (every wave in the same stage), its steady state, its end
     t_us = (start.astype(np.int64) - t0) / 100.0
     edges = [0, 25, 100, 200, 400, 800, 1600, 2400, 3200, 3600, 3700, 3800, 3900, 4000, 4200, 1e9]
