@@ -565,12 +565,19 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
     const uint32_t n_items = A.n + nf;
     uint32_t r = 0xFFFFFFFFu;  // the read being worked on; none: the wave is done
     uint64_t o0 = 0, len = 0;
+    // A wave's first two work items are its own (item w and item n_waves + w of wave w): taken from the counter, the launch opened with two atomics
+    // per wave on ONE address at the same instant -- 8,192 of them are served in ~65 us, and the wave served last starts that much later
+    // (tools/launch_fixed_cost.py, tools/stage_clocks.py --reads 4096).  The counter hands out the items from 2 n_waves on.
+    const uint32_t n_waves = gridDim.x * (uint32_t)MAP_WAVES;
     // a work item taken with nothing to do meanwhile: a wave's first, and the one after an entry whose read went first (one in hundreds)
-    auto take_now = [&]() {
+    auto take_now = [&](uint32_t own) {  // own: the wave's own item, or 0xFFFFFFFF: from the counter
         for (;;) {
-            uint32_t i = 0;
-            if (lane == 0) i = atomicAdd(&A.counters[0], 1u);
-            i = rdfirst(i);
+            uint32_t i = own;
+            if (own == 0xFFFFFFFFu) {
+                if (lane == 0) i = atomicAdd(&A.counters[0], 1u);
+                i = rdfirst(i) + 2u * n_waves;
+            }
+            own = 0xFFFFFFFFu;
             r = 0xFFFFFFFFu;
             if (i >= n_items) return;
             const uint4 d = work[i];
@@ -581,7 +588,8 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
             return;
         }
     };
-    take_now();
+    take_now((uint32_t)wave_gid);
+    bool second_own = true;  // the item after the first is the wave's own too
 #endif
     APre pre;                // the current read's first super-row when pre_valid (MQ_LDS_PREFETCH: picked up from LDS at the end of the
     bool pre_valid = false;  // iteration before)
@@ -590,8 +598,12 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         const unsigned long long t_read0 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
         const unsigned long long t_real0 = TIMING ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #if !MQ_LDS_PREFETCH
-        uint32_t rn_v = 0;
-        if (lane == 0) rn_v = atomicAdd(&A.counters[0], 1u);
+        uint32_t rn_v = n_waves + (uint32_t)wave_gid;
+        if (!second_own) {
+            if (lane == 0) rn_v = atomicAdd(&A.counters[0], 1u);
+            rn_v += 2u * n_waves;
+        }
+        second_own = false;
 #endif
         uint32_t cnt = 0;
         uint64_t base = 0;
@@ -757,7 +769,7 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         asm volatile("" ::: "memory");  // the prefetched descriptor is out of its registers before the result's store is issued
         store_hit(A, r_done, h);
         if (rn < n_items && (nw & WORK_SKIP)) {  // that read went first
-            take_now();
+            take_now(0xFFFFFFFFu);
             pre_valid = false;
         }
         if (TIMING && lane == 0) {
