@@ -569,15 +569,22 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
     // per wave on ONE address at the same instant -- 8,192 of them are served in ~65 us, and the wave served last starts that much later
     // (tools/launch_fixed_cost.py, tools/stage_clocks.py --reads 4096).  The counter hands out the items from 2 n_waves on.
     const uint32_t n_waves = gridDim.x * (uint32_t)MAP_WAVES;
+    uint32_t own1 = (uint32_t)wave_gid, own2 = n_waves + (uint32_t)wave_gid;  // 0xFFFFFFFF once taken
     // a work item taken with nothing to do meanwhile: a wave's first, and the one after an entry whose read went first (one in hundreds)
-    auto take_now = [&](uint32_t own) {  // own: the wave's own item, or 0xFFFFFFFF: from the counter
+    auto take_now = [&]() {
         for (;;) {
-            uint32_t i = own;
-            if (own == 0xFFFFFFFFu) {
+            uint32_t i;
+            if (own1 != 0xFFFFFFFFu) {
+                i = own1;
+                own1 = 0xFFFFFFFFu;
+            } else if (own2 != 0xFFFFFFFFu) {  // (the first was an entry whose read went first: the wave's second item is still its own)
+                i = own2;
+                own2 = 0xFFFFFFFFu;
+            } else {
+                i = 0;
                 if (lane == 0) i = atomicAdd(&A.counters[0], 1u);
                 i = rdfirst(i) + 2u * n_waves;
             }
-            own = 0xFFFFFFFFu;
             r = 0xFFFFFFFFu;
             if (i >= n_items) return;
             const uint4 d = work[i];
@@ -588,8 +595,7 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
             return;
         }
     };
-    take_now((uint32_t)wave_gid);
-    bool second_own = true;  // the item after the first is the wave's own too
+    take_now();
 #endif
     APre pre;                // the current read's first super-row when pre_valid (MQ_LDS_PREFETCH: picked up from LDS at the end of the
     bool pre_valid = false;  // iteration before)
@@ -598,12 +604,12 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         const unsigned long long t_read0 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
         const unsigned long long t_real0 = TIMING ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #if !MQ_LDS_PREFETCH
-        uint32_t rn_v = n_waves + (uint32_t)wave_gid;
-        if (!second_own) {
+        uint32_t rn_v = own2;
+        if (own2 == 0xFFFFFFFFu) {
             if (lane == 0) rn_v = atomicAdd(&A.counters[0], 1u);
             rn_v += 2u * n_waves;
         }
-        second_own = false;
+        own2 = 0xFFFFFFFFu;
 #endif
         uint32_t cnt = 0;
         uint64_t base = 0;
@@ -769,7 +775,7 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         asm volatile("" ::: "memory");  // the prefetched descriptor is out of its registers before the result's store is issued
         store_hit(A, r_done, h);
         if (rn < n_items && (nw & WORK_SKIP)) {  // that read went first
-            take_now(0xFFFFFFFFu);
+            take_now();
             pre_valid = false;
         }
         if (TIMING && lane == 0) {
