@@ -150,12 +150,13 @@ def files_on(path):
     return "/dev/shm (tmpfs: memory, no block device)" if p.startswith("/dev/shm") else "%s (temporary directory, files read once before the timed run: page cache)" % os.path.dirname(p)
 
 
-def measure_file_to_paf(ref, reads, n_reads, threads, workdir, fastq=False, extra_args=(), compress=None, env=None, more_threads=()):
+def measure_file_to_paf(ref, reads, n_reads, threads, workdir, fastq=False, extra_args=(), compress=None, env=None, more_threads=(), prefetch_run=True):
     """End to end through the native driver (mapquik_amd/lib/mapquik): reference FASTA + reads file on disk -> <prefix>.paf.
-    fastq: the reads as a FASTQ file; compress="gz": as a plain gzip stream.  Three runs: one to bring the files into the page cache,
-    the driver's default = the strict run (nothing of the reads is touched before the index is ready; also reported under the
-    no_prefetch_* keys of earlier rounds) and one with MQ_DRIVER_PREFETCH=1 (the read feeder starts while the reference is
-    indexed).  Rates over the driver's own 'Mapped query sequences' phase."""
+    fastq: the reads as a FASTQ file; compress="gz": as a plain gzip stream.  One run to bring the files into the page cache, then the
+    driver's default = the strict run (nothing of the reads is touched before the index is ready; also reported under the
+    no_prefetch_* keys of earlier rounds) THREE times -- the leg's numbers are the run with the median map phase, min / max beside
+    them (a single shot on a shared box is not a measurement) -- and one run with MQ_DRIVER_PREFETCH=1 (the read feeder starts while
+    the reference is indexed).  Rates over the driver's own 'Mapped query sequences' phase."""
     import re
     import subprocess
     from mapquik_amd import build as B
@@ -189,22 +190,31 @@ def measure_file_to_paf(ref, reads, n_reads, threads, workdir, fastq=False, extr
         t_idx = float(mi.group(1)) * unit.get(mi.group(2), 1.0) if mi else float("nan")
         return t_map, t_idx, wall
 
+    def median_of(env, threads=threads, reps=3):
+        """`reps` runs of the driver: the run with the median map phase, and min / max of the map-phase rate and of the job's wall time"""
+        rs = sorted((run(env, threads=threads) for _ in range(reps)), key=lambda r: r[0])
+        t_map, t_idx, wall = rs[len(rs) // 2]
+        return t_map, t_idx, wall, dict(runs=reps, gbases_s_min=round(bases / rs[-1][0] / 1e9, 3), gbases_s_max=round(bases / rs[0][0] / 1e9, 3),
+                                        driver_wall_s_min=round(min(r[2] for r in rs), 2), driver_wall_s_max=round(max(r[2] for r in rs), 2))
+
     try:
         run({})  # first run: files enter the page cache
-        t_map, t_idx, wall = run({})
+        t_map, t_idx, wall, spread = median_of({})
         out.update(gbases_s=round(bases / t_map / 1e9, 3), map_phase_s=round(t_map, 4), index_phase_s=round(t_idx, 3), driver_wall_s=round(wall, 2),
-                   whole_job_gbases_s=round(bases / wall / 1e9, 3))
+                   whole_job_gbases_s=round(bases / wall / 1e9, 3), spread=spread,
+                   note="median of %d runs of the driver (the run with the median map phase); spread = min / max over the runs" % spread["runs"])
         out.update(no_prefetch_gbases_s=out["gbases_s"], no_prefetch_map_phase_s=out["map_phase_s"], no_prefetch_index_phase_s=out["index_phase_s"],
                    no_prefetch_driver_wall_s=out["driver_wall_s"])
-        t_map2, t_idx2, wall2 = run({"MQ_DRIVER_PREFETCH": "1"})
-        out.update(prefetch_gbases_s=round(bases / t_map2 / 1e9, 3), prefetch_map_phase_s=round(t_map2, 4), prefetch_index_phase_s=round(t_idx2, 3),
-                   prefetch_driver_wall_s=round(wall2, 2))
+        if prefetch_run:
+            t_map2, t_idx2, wall2 = run({"MQ_DRIVER_PREFETCH": "1"})
+            out.update(prefetch_gbases_s=round(bases / t_map2 / 1e9, 3), prefetch_map_phase_s=round(t_map2, 4), prefetch_index_phase_s=round(t_idx2, 3),
+                       prefetch_driver_wall_s=round(wall2, 2))
         with open(prefix + ".paf", "rb") as f:
             out["paf_lines"] = sum(1 for _ in f)
-        for t in more_threads:  # the same file at other thread counts (strict run)
-            tm, ti, w = run({}, threads=t)
+        for t in more_threads:  # the same file at other thread counts (strict run), medians too
+            tm, ti, w, sp = median_of({}, threads=t)
             out["at_%d_threads" % t] = dict(gbases_s=round(bases / tm / 1e9, 3), map_phase_s=round(tm, 4), index_phase_s=round(ti, 3), driver_wall_s=round(w, 2),
-                                            whole_job_gbases_s=round(bases / w / 1e9, 3))
+                                            whole_job_gbases_s=round(bases / w / 1e9, 3), spread=sp)
     finally:
         for fn in (rd, prefix + ".paf"):
             try:
@@ -260,61 +270,237 @@ def build_index_device(mq, torch, dev, local_rank, P, genome, ctg_off, ctg_names
     return ix, per_ref, n_unique, t_up, t_build
 
 
-def oracle_sample_check(mq, O, genome, ctg_off, ctg_names, po, ncpu, reads, hits, ns):
-    """The first ns reads through the C oracle (index built with all granted threads): are status and every numeric PAF column
-    of the GPU's hits the oracle's?  Returns (identical, oracle unique k-min-mers)."""
-    ox = O.Index()
-    ox.build_mt(genome, ctg_off, ctg_names, po, ncpu)
-    offs = reads["offsets"]
-    ns = min(ns, offs.size - 1)
-    want = ox.map_batch(reads["bases"][:int(offs[ns])], offs[:ns + 1], po, threads=ncpu)
+def columns_equal(mq, hits, want):
+    """status and every numeric PAF column of the GPU's hits against the oracle's records of the same reads"""
     m = want["mapped"] != 0
-    same = bool(np.array_equal(hits["status"][:ns] == 1, m)) and all(
-        np.array_equal(mq.hit_column(hits[:ns], a)[m], want[a][m].astype(np.uint64))
+    return bool(np.array_equal(hits["status"] == 1, m)) and all(
+        np.array_equal(mq.hit_column(hits, a)[m], want[a][m].astype(np.uint64))
         for a in ("ref_id", "rc", "mapq", "q_start", "q_end", "r_start", "r_end", "score"))
-    uniq = int(ox.count())
-    del ox
-    return same, uniq
 
 
-def kernel_leg(mq, sim, O, torch, dev, local_rank, P, po, genome, ctg_off, ctg_names, reads, steps, warmup, ncpu, sample_reads, workload):
+def oracle_sample_check(mq, O, genome, ctg_off, ctg_names, po, ncpu, B, hits, ns, variant=0):
+    """The batch's first ns reads and its strided sample through the C oracle (index built with all granted threads, the oracle switched
+    to the leg's seeding variant): are status and every numeric PAF column of the GPU's hits the oracle's?
+    Returns (identical, oracle unique k-min-mers, reads compared)."""
+    O.lib().mqo_set_variant(variant)
+    try:
+        ox = O.Index()
+        ox.build_mt(genome, ctg_off, ctg_names, po, ncpu)
+        ns = min(ns, B.keep_first)
+        rd = host_reads(B, ns)
+        same = columns_equal(mq, hits[:ns], ox.map_batch(rd["bases"], rd["offsets"], po, threads=ncpu))
+        n_cmp = ns
+        idx = B.strided_idx[B.strided_idx < hits.size]  # (a leg on the batch's first reads only: the strided reads among them)
+        if idx.size:
+            so = B.strided_offsets[:idx.size + 1]
+            same = same and columns_equal(mq, hits[idx], ox.map_batch(B.strided_bases[:int(so[-1])], so, po, threads=ncpu))
+            n_cmp += int(idx.size)
+        uniq = int(ox.count())
+        del ox
+    finally:
+        O.lib().mqo_set_variant(0)
+    return same, uniq, n_cmp
+
+
+def poison(d_out):
+    """0xFF in every byte of the result buffer: a read whose record no wave writes keeps status 0xFFFFFFFF -- not 0 = 'unmapped'."""
+    d_out.fill_(0xFF)
+
+
+def records_written(torch, d_out, n):
+    """How many of the n result records carry a status a wave wrote (0 unmapped, 1 mapped, 2 overflow): n, or a read was lost."""
+    st = d_out.view(torch.int32).view(n, -1)[:, 0]
+    return int(((st >= 0) & (st <= 2)).sum().item())
+
+
+def kernel_leg(mq, sim, O, torch, dev, local_rank, P, po, genome, ctg_off, ctg_names, B, steps, warmup, ncpu, sample_reads, workload, n_reads=None, variant=0):
     """One kernel-only leg of another configuration: index on the GPU, the batch resident in HBM, `steps` timed launches of
-    map_kernel, mapeval counts over the batch, the oracle's columns on a sample."""
+    map_kernel on a poisoned result buffer, mapeval counts over the batch, the oracle's columns on a sample."""
     ix, _, n_unique, _, t_build = build_index_device(mq, torch, dev, local_rank, P, genome, ctg_off, ctg_names)
-    offs = reads["offsets"]
-    n, total_bases = offs.size - 1, int(offs[-1])
-    d_bases = torch.from_numpy(reads["bases"]).to(dev)
-    d_offs = torch.from_numpy(offs.astype(np.int64)).to(dev)
-    d_out = torch.zeros(n * mq.hit_dtype.itemsize, dtype=torch.uint8, device=dev)
+    n = B.n if n_reads is None else min(n_reads, B.n)
+    offs = B.offsets[:n + 1]
+    total_bases = int(offs[-1])
+    d_out = torch.empty(n * mq.hit_dtype.itemsize, dtype=torch.uint8, device=dev)
+    poison(d_out)
     ix.reserve(n, total_bases)
     stream = torch.cuda.current_stream(dev)
     for _ in range(warmup):
-        ix.map_batch_device(d_bases.data_ptr(), d_offs.data_ptr(), n, total_bases, d_out.data_ptr(), stream.cuda_stream)
+        ix.map_batch_device(B.d_bases.data_ptr(), B.d_offs.data_ptr(), n, total_bases, d_out.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(steps):
-        ix.map_batch_device(d_bases.data_ptr(), d_offs.data_ptr(), n, total_bases, d_out.data_ptr(), stream.cuda_stream)
+        ix.map_batch_device(B.d_bases.data_ptr(), B.d_offs.data_ptr(), n, total_bases, d_out.data_ptr(), stream.cuda_stream)
     e1.record(stream)
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
+    n_written = records_written(torch, d_out, n)
     hits = np.frombuffer(d_out.cpu().numpy().tobytes(), dtype=mq.hit_dtype)
-    truth = {k: v for k, v in reads.items() if k not in ("bases", "offsets")}
+    truth = {k: v[:n] for k, v in B.truth.items()}
     pafs = {"mapped": (hits["status"] == 1).astype(np.uint32)}
     for a_ in ("ref_id", "rc", "mapq", "r_start", "r_end"):
         pafs[a_] = hits[a_]
     n_m, n_q60, n_q60_wrong = sim.mapeval(truth, pafs)
     n_fast, n_general = ix.last_map_path_counts()
     n_flagged, n_first = ix.last_map_order()
-    same, ouniq = oracle_sample_check(mq, O, genome, ctg_off, ctg_names, po, ncpu, reads, hits, sample_reads)
+    same, ouniq, n_cmp = oracle_sample_check(mq, O, genome, ctg_off, ctg_names, po, ncpu, B, hits, min(sample_reads, n), variant=variant)
     st = ix.stats()
     ix.close()
-    del d_bases, d_offs, d_out
+    del d_out
     return dict(workload=workload, value=round(total_bases / (ms * 1e-3) / 1e9, 3), unit="Gbases/s", ms_per_launch=round(ms, 4), steps=steps,
-                reads_per_step=n, bases_per_step=total_bases, kminmers_per_step=int(hits["n_kminmers"].astype(np.int64).sum()),
+                reads_per_step=n, bases_per_step=total_bases, records_written=n_written, kminmers_per_step=int(hits["n_kminmers"].astype(np.int64).sum()),
                 mapped_frac=round(n_m / max(n, 1), 4), q60=n_q60, q60_wrong=n_q60_wrong, overflow_reads=int((hits["status"] == 2).sum()), reads_first=n_first,
                 general_path_reads=int(n_general), index_unique_kminmers=int(n_unique), index_keys=int(st["n_keys"]), index_build_s=round(t_build, 3),
-                paf_columns_identical_to_oracle=same, oracle_sample_reads=min(sample_reads, n), unique_kminmers_equal_oracle=bool(ouniq == n_unique))
+                paf_columns_identical_to_oracle=same, oracle_sample_reads=n_cmp, unique_kminmers_equal_oracle=bool(ouniq == n_unique), seeding_variant=variant)
+
+
+class Batch:
+    """A batch of reads resident in HBM: device tensors (bases, offsets), the host's offsets and truth columns, and the first
+    `keep_first` reads (plus every `keep_stride`-th read) in host memory for the CPU-side checks and the file legs."""
+    pass
+
+
+def load_batch(torch, dev, sim, genome, ctg_off, n_reads, seed, threads, keep_first=0, keep_stride=0, stride_from=0, slice_reads=32768):
+    """tools/sim.py's reads [0, n_reads) of `seed`, synthesised slice by slice (<= 0.9 GB of page-locked work buffer, two of them) and
+    copied straight into the device batch while the next slice is made: no 39-GB capacity layout and no 37-GB host copy per rank
+    (the batch a rank maps exists only in HBM).  Same reads, byte for byte, as sim.make_reads(genome, ctg_off, n_reads, seed)."""
+    ctg_off = np.ascontiguousarray(ctg_off, dtype=np.uint64)
+    caps = np.zeros(n_reads + 1, dtype=np.uint64)
+    sim.lib().mqsim_read_caps(ctg_off.ctypes.data, ctg_off.size - 1, n_reads, 24000.0, 2300.0, 100, 25000, seed, caps.ctypes.data)
+    d_buf = torch.empty(int(caps[-1]) + 64, dtype=torch.uint8, device=dev)  # an upper bound (template + room for insertions); the batch is a view of it
+    del caps
+    pinned = {}
+
+    def alloc(nbytes):
+        t = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        a = t.numpy()
+        pinned[a.ctypes.data] = t
+        return a
+
+    offsets = np.zeros(n_reads + 1, dtype=np.uint64)
+    truth = dict(ctg=np.zeros(n_reads, dtype=np.uint32), start=np.zeros(n_reads, dtype=np.uint64), end=np.zeros(n_reads, dtype=np.uint64),
+                 strand=np.zeros(n_reads, dtype=np.uint8))
+    head, strided, strided_idx = [], [], []
+    copy_stream = torch.cuda.Stream(device=dev)
+    done = [None, None]
+    at = 0
+    for k, (r0, r1, b, o, t) in enumerate(sim.read_slices(genome, ctg_off, n_reads, seed=seed, slice_reads=slice_reads, threads=threads, buffers=alloc)):
+        src = pinned[b.ctypes.data][:b.size]
+        with torch.cuda.stream(copy_stream):
+            d_buf[at:at + b.size].copy_(src, non_blocking=True)
+            done[k & 1] = torch.cuda.Event()
+            done[k & 1].record(copy_stream)
+        offsets[r0 + 1:r1 + 1] = o[1:] + np.uint64(at)
+        for key in truth:
+            truth[key][r0:r1] = t[key]
+        if r0 < keep_first:
+            m = min(r1, keep_first) - r0
+            head.append(b[:int(o[m])].copy())
+        if keep_stride:
+            for r in range(-(-r0 // keep_stride) * keep_stride, r1, keep_stride):
+                if r >= stride_from:
+                    strided.append(b[int(o[r - r0]):int(o[r - r0 + 1])].copy())
+                    strided_idx.append(r)
+        at += b.size
+        if done[(k + 1) & 1] is not None:
+            done[(k + 1) & 1].synchronize()  # the other work buffer (the next slice's) has left for the device
+    copy_stream.synchronize()
+    B = Batch()
+    B.n, B.total_bases = n_reads, at
+    B.d_buf = d_buf
+    B.d_bases = d_buf[:at]
+    B.offsets = offsets
+    B.d_offs = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    B.truth = truth
+    B.keep_first = min(keep_first, n_reads)
+    B.head_bases = np.concatenate(head) if head else np.zeros(0, dtype=np.uint8)
+    B.strided_idx = np.asarray(strided_idx, dtype=np.int64)
+    B.strided_bases = np.concatenate(strided) if strided else np.zeros(0, dtype=np.uint8)
+    B.strided_offsets = np.zeros(len(strided) + 1, dtype=np.uint64)
+    if strided:
+        B.strided_offsets[1:] = np.cumsum([x.size for x in strided])
+    return B
+
+
+def batch_from_host(torch, dev, reads, keep_first=None):
+    """A batch whose reads exist in host memory (real reads from a file; a strong-scaling shard): uploaded whole."""
+    B = Batch()
+    offs = reads["offsets"]
+    B.n, B.total_bases = offs.size - 1, int(offs[-1])
+    B.d_buf = B.d_bases = torch.from_numpy(reads["bases"]).to(dev)
+    B.offsets = offs
+    B.d_offs = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    B.truth = {k: v for k, v in reads.items() if k not in ("bases", "offsets")}
+    B.keep_first = B.n if keep_first is None else min(keep_first, B.n)
+    B.head_bases = reads["bases"][:int(offs[B.keep_first])]
+    B.strided_idx = np.zeros(0, dtype=np.int64)
+    B.strided_bases = np.zeros(0, dtype=np.uint8)
+    B.strided_offsets = np.zeros(1, dtype=np.uint64)
+    return B
+
+
+def host_reads(B, m):
+    """The batch's first m reads as host arrays (m <= B.keep_first)."""
+    assert m <= B.keep_first, "bench.py keeps only the first %d reads of a batch in host memory (asked for %d)" % (B.keep_first, m)
+    d = {k: v[:m] for k, v in B.truth.items()}
+    d["offsets"] = B.offsets[:m + 1]
+    d["bases"] = B.head_bases[:int(B.offsets[m])]
+    return d
+
+
+def peak_rss_gb():
+    import resource
+    return round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0, 2)  # ru_maxrss is in KB on Linux
+
+
+def shared_genome(make, dist, world, rank, tag):
+    """The synthetic genome once per node: rank 0 synthesises it (with every granted thread) into /dev/shm, the other ranks map the
+    file (copy-on-write pages: shared until written, and nobody writes) -- not 3.1 GB and a synthesis per rank."""
+    if world == 1:
+        return make()
+    path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp",
+                        "mq_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), tag))
+    if rank == 0:
+        g, off, names = make()
+        np.save(path + ".g.tmp.npy", g)
+        os.replace(path + ".g.tmp.npy", path + ".g.npy")
+        np.save(path + ".off.npy", off)
+        del g
+    dist.barrier()
+    off = np.load(path + ".off.npy")
+    g = np.load(path + ".g.npy", mmap_mode="c")
+    names = ["chr%d" % (i + 1) for i in range(off.size - 1)]
+    dist.barrier()
+    if rank == 0:  # every rank has the file mapped: the name can go (the pages live as long as the mappings)
+        for sfx in (".g.npy", ".off.npy"):
+            try:
+                os.remove(path + sfx)
+            except OSError:
+                pass
+    return g, off, names
+
+
+def fresh_table_alloc_ms(nbytes, reps=3):
+    """What allocating and clearing `nbytes` of FRESH device memory costs: hipMalloc + hipMemset + synchronize + hipFree straight on
+    the HIP runtime (torch's caching allocator hands back recycled blocks in a few ms or fresh ones in half a second, at its own
+    discretion: not a measurement).  Median, min, max over `reps`."""
+    import ctypes as C
+    h = C.CDLL("libamdhip64.so")
+    h.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    h.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    h.hipFree.argtypes = [C.c_void_p]
+    ts = []
+    for _ in range(reps):
+        p = C.c_void_p()
+        h.hipDeviceSynchronize()
+        t0 = time.perf_counter()
+        if h.hipMalloc(C.byref(p), nbytes) != 0:
+            raise MemoryError("hipMalloc(%d)" % nbytes)
+        h.hipMemset(p, 0, nbytes)
+        h.hipDeviceSynchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+        h.hipFree(p)
+    return float(np.median(ts)), min(ts), max(ts)
 
 
 def fake_ranks():
@@ -346,6 +532,7 @@ def launch_ranks(n_gpus):
 
 
 def main():
+    t_start = time.time()
     args = parse()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -411,15 +598,15 @@ def main():
     ix0 = mq.Index(P, device=local_rank)
     ix0.reserve_table(expected_kminmers(sum(lens), P))
 
-    # ---- genome (same on every rank: the index is replicated)
+    # ---- genome (same on every rank: the index is replicated; synthesised once per node)
     if real_ref:
         genome, ctg_off, ctg_names = real
         del real
     elif args.genome_preset == "human-like":
-        genome, ctg_off, ctg_names = sim.make_genome(lens, seed=args.seed, threads=threads, **sim.HUMAN_LIKE)
+        genome, ctg_off, ctg_names = shared_genome(lambda: sim.make_genome(lens, seed=args.seed, threads=ncpu, **sim.HUMAN_LIKE), dist, world, rank, "g")
     else:
-        genome, ctg_off, ctg_names = sim.make_genome(lens, seed=args.seed, threads=threads, repeat_frac=args.repeat_frac,
-                                                     tandem_frac=args.tandem_frac, div=args.repeat_div)
+        genome, ctg_off, ctg_names = shared_genome(lambda: sim.make_genome(lens, seed=args.seed, threads=ncpu, repeat_frac=args.repeat_frac,
+                                                                          tandem_frac=args.tandem_frac, div=args.repeat_div), dist, world, rank, "g")
     t_genome = time.time() - t0
 
     # ---- index on this rank's GPU (Index::add_with_mer + into_read_only on device), from device-resident contigs
@@ -436,39 +623,32 @@ def main():
                             "is not in it" % (len(lens), st["table_bytes"] / 1e9, t_upload))
 
     # what the table's allocation + clear costs by itself (the build above overlaps it with genome synthesis, which a real run does not
-    # have): the same number of bytes allocated and zeroed once more, timed alone
-    try:
-        torch.cuda.synchronize()
-        ta0 = time.perf_counter()
-        scratch_tbl = torch.zeros(int(st["table_bytes"]), dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize()
-        t_tbl = time.perf_counter() - ta0
-        del scratch_tbl
-        torch.cuda.empty_cache()
-        index_build["table_alloc_and_clear_ms"] = round(t_tbl * 1e3, 2)
-        index_build["ms_with_table_allocation"] = round((t_index + t_tbl) * 1e3, 2)
-        index_build["table_note"] = ("%.1f GB allocated and zeroed by itself right after the build (torch.zeros + synchronize): what a run that cannot hide the "
-                                     "table's allocation behind other work adds to `ms`" % (st["table_bytes"] / 1e9))
-    except Exception as ex:  # noqa: BLE001
-        index_build["table_alloc_and_clear_ms"] = None
-        index_build["table_note"] = repr(ex)[:200]
+    # have): the same number of bytes of FRESH device memory (hipMalloc + hipMemset + synchronize on the HIP runtime, not torch's caching
+    # allocator), timed alone, three times
+    if rank == 0 and world == 1:
+        try:
+            torch.cuda.synchronize()
+            t_med, t_lo, t_hi = fresh_table_alloc_ms(int(st["table_bytes"]))
+            index_build["table_alloc_and_clear_ms"] = round(t_med, 2)
+            index_build["table_alloc_and_clear_ms_min_max"] = [round(t_lo, 2), round(t_hi, 2)]
+            index_build["ms_with_table_allocation"] = round(t_index * 1e3 + t_med, 2)
+            index_build["table_note"] = ("%.1f GB of fresh device memory: hipMalloc + hipMemset + hipDeviceSynchronize straight on the HIP runtime, median of 3 "
+                                         "(min, max beside it): what a run that cannot hide the table's allocation behind other work adds to `ms`" % (st["table_bytes"] / 1e9))
+        except Exception as ex:  # noqa: BLE001
+            index_build["table_alloc_and_clear_ms"] = None
+            index_build["table_note"] = repr(ex)[:200]
 
     # ---- this rank's batch of reads, resident in HBM
     t0 = time.time()
     strong = args.scaling == "strong"
-    if strong and not args.reads_fastx:  # the same read set on every rank; this rank's contiguous shard of it
-        from mapquik_amd.shard import shard_bounds
-        full = sim.make_reads(genome, ctg_off, args.reads, seed=args.seed + 1000, threads=threads)
-        lo, hi = shard_bounds(args.reads, world, rank)
-        fo = full["offsets"]
-        reads = {k: v[lo:hi] for k, v in full.items() if k not in ("bases", "offsets")}
-        reads["bases"] = full["bases"][int(fo[lo]):int(fo[hi])]
-        reads["offsets"] = (fo[lo:hi + 1] - fo[lo]).astype(np.uint64)
-        del full
-    elif args.reads_fastx:
-        reads = None
-    else:
-        reads = sim.make_reads(genome, ctg_off, args.reads, seed=args.seed + 1000 + rank, threads=threads)
+    solo = rank == 0 and world == 1
+    # reads kept in host memory as well: what the CPU baseline, the oracle checks and the file legs read (N = 1 only); every 32nd read of
+    # the rest for the strided oracle check.  A rank of a multi-GPU run keeps nothing: its batch exists in HBM only.
+    keep_first = 0
+    if solo:
+        keep_first = max(args.cpu_sample_reads or 49152, args.config_sample_reads if not args.no_configs else 0)
+        if not args.no_e2e:
+            keep_first = max(keep_first, 393216, args.e2e_file_reads, args.e2e_fastq_reads)
     read_names = None
     have_truth = True
     if args.reads_fastx:  # real reads: weak scaling = every rank its own slice of the file; strong = one slice dealt to the ranks
@@ -484,19 +664,34 @@ def main():
         read_names = rr.pop("names")
         truth_ = realdata.truth_from_names(read_names, ctg_names)  # pbsim2fq names carry it; real reads do not
         have_truth = truth_ is not None
-        reads = dict(rr, **(truth_ or {}))
-    offs = reads["offsets"]
-    n = offs.size - 1
-    total_bases = int(offs[-1])
-    max_len = int((offs[1:] - offs[:-1]).max())
-    d_bases = torch.from_numpy(reads["bases"]).to(dev)
-    d_offs = torch.from_numpy(offs.astype(np.int64)).to(dev)
-    d_out = torch.zeros(n * mq.hit_dtype.itemsize, dtype=torch.uint8, device=dev)
+        B = batch_from_host(torch, dev, dict(rr, **(truth_ or {})))
+        del rr
+    elif strong:  # the same read set on every rank; this rank's contiguous shard of it, in host memory (it is mapped from there)
+        from mapquik_amd.shard import shard_bounds
+        lo, hi = shard_bounds(args.reads, world, rank)
+        parts, po_, tr_ = [], [np.zeros(1, dtype=np.uint64)], {}
+        for r0, r1, b, o, t in sim.read_slices(genome, ctg_off, hi - lo, seed=args.seed + 1000, first_read=lo, threads=threads):
+            parts.append(b.copy())
+            po_.append(o[1:] + po_[-1][-1])
+            for k_, v_ in t.items():
+                tr_.setdefault(k_, []).append(v_)
+        B = batch_from_host(torch, dev, dict(bases=np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8), offsets=np.concatenate(po_),
+                                             **{k_: np.concatenate(v_) for k_, v_ in tr_.items()}))
+        del parts
+    else:
+        B = load_batch(torch, dev, sim, genome, ctg_off, args.reads, args.seed + 1000 + rank, threads, keep_first=keep_first,
+                       keep_stride=32 if solo else 0, stride_from=min(args.cpu_sample_reads or 49152, args.config_sample_reads))
+    offs = B.offsets
+    n = B.n
+    total_bases = B.total_bases
+    d_bases, d_offs = B.d_bases, B.d_offs
+    d_out = torch.empty(n * mq.hit_dtype.itemsize, dtype=torch.uint8, device=dev)
+    poison(d_out)  # a record no wave writes stays 0xFF..: counted below (`records_written`), never mistaken for an unmapped read
     t_reads = time.time() - t0
     ix.reserve(n, total_bases)
     stream = torch.cuda.current_stream(dev)
 
-    pipe = HostPipeline(mq, ix, reads) if strong else None
+    pipe = HostPipeline(mq, ix, dict(bases=B.head_bases, offsets=offs)) if strong else None
 
     def step():
         if strong:
@@ -507,6 +702,8 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    t_first_step = time.time() - t_start
+    rss_setup = peak_rss_gb()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -529,13 +726,16 @@ def main():
         tb = torch.tensor([float(total_bases), float(n)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         all_bases, all_reads = float(tb[0].item()), float(tb[1].item())
-        mine = torch.tensor([elapsed_local, float(total_bases)], dtype=torch.float64, device=red_dev)
+        mine = torch.tensor([elapsed_local, float(total_bases), t_first_step, rss_setup], dtype=torch.float64, device=red_dev)
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
         per_rank = [round(float(g[1].item()) * args.steps / float(g[0].item()) / 1e9, 3) for g in gathered]
+        per_rank_setup = [round(float(g[2].item()), 1) for g in gathered]
+        per_rank_rss = [round(float(g[3].item()), 2) for g in gathered]
     else:
         all_bases, all_reads = float(total_bases), float(n)
         per_rank = None
+        per_rank_setup, per_rank_rss = [round(t_first_step, 1)], [rss_setup]
     if strong:  # the kernel's own launch time for the roofline: one resident launch of this rank's shard, outside the timed region
         pipe.close()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -548,6 +748,11 @@ def main():
     else:
         kern_ms = [a.elapsed_time(b) for a, b in ev]
     avg_kern_s = float(np.mean(kern_ms)) / 1e3
+    # every read of the batch has a record that a wave wrote (the buffer was poisoned before the warm-up)
+    n_written = records_written(torch, d_out, n)
+    if n_written != n:
+        raise SystemExit("bench.py: %d of %d result records were never written: reads were lost by the launch" % (n - n_written, n))
+    d_step = d_out.clone()  # the timed steps' results: compared below with the instrumented launch and the oracle
 
     # the same kernel on the first m reads of the batch: what a launch's fixed cost (start-up + tail) does to smaller batches
     smaller = {}
@@ -565,9 +770,13 @@ def main():
                 torch.cuda.synchronize()
                 ms_m = e0.elapsed_time(e1) / 10
                 smaller[str(m)] = {"gbases_s": round(tb / ms_m / 1e6, 1), "ms_per_launch": round(ms_m, 4)}
-        if smaller:  # the whole batch once more: d_out holds the step's results again
+        if smaller:  # the whole batch once more, on a poisoned buffer again
+            poison(d_out)
             ix.map_batch_device(d_bases.data_ptr(), d_offs.data_ptr(), n, total_bases, d_out.data_ptr(), stream.cuda_stream)
             torch.cuda.synchronize()
+            assert torch.equal(d_out, d_step), "a launch of the same batch gave other results than the timed steps"
+    del d_out
+    d_out = d_step
     hits = np.frombuffer(d_out.cpu().numpy().tobytes(), dtype=mq.hit_dtype)
     launch_order = dict(zip(("reads_flagged", "reads_first"), ix.last_map_order()))  # order_reads_kernel: reads taken up first
     if os.environ.get("MQ_BENCH_DUMP_HITS"):  # test hook: this rank's hits (strong scaling: of its shard of the one read set)
@@ -575,15 +784,22 @@ def main():
     n_kmm = int(hits["n_kminmers"].astype(np.int64).sum())
     n_mapped = int((hits["status"] == 1).sum())
     n_over = int((hits["status"] == 2).sum())
+    # reads long enough for extract() (src/mers.rs:44) that listed k minimizers or more and still came back unmapped: what a lost read
+    # would look like had the buffer been cleared instead of poisoned -- reported so that two runs can be compared
+    rl = (offs[1:] - offs[:-1]).astype(np.int64)
+    n_unmapped_seeded = int(((hits["status"] == 0) & (rl >= args.l + args.k - 1) & (hits["n_kminmers"] >= 1)).sum())
 
     # ---- roofline of the dominant (only) kernel of a step: map_kernel
     # algorithmic bytes per launch = SURVEY.md 8(d): L*b_in + n_kmm*S_slot*p_bar + S_out per read, with b_in = 1 B (ASCII in
     # HBM), S_slot = 32 B, p_bar = mean probes per lookup MEASURED on this batch by one instrumented launch outside the timed
     # region, S_out = 40 B (+ 8 B offset)
-    d_out2 = torch.zeros_like(d_out)
+    d_out2 = torch.empty_like(d_out)
+    poison(d_out2)
     lookups, extra = ix.probe_stats(d_bases.data_ptr(), d_offs.data_ptr(), n, total_bases, d_out2.data_ptr())
     torch.cuda.synchronize()
-    assert torch.equal(d_out, d_out2), "instrumented launch disagrees with the timed one"
+    assert records_written(torch, d_out2, n) == n, "the instrumented launch left result records unwritten"
+    assert torch.equal(d_out, d_out2), "instrumented launch disagrees with the timed one"  # byte for byte: status, columns, n_kminmers of every read
+    del d_out2
     p_bar = 1.0 + extra / max(lookups, 1)
     alg_bytes = total_bases * 1 + n_kmm * st["slot_bytes"] * p_bar + n * (8 + 40)  # SURVEY 8(d)'s S_out = 40 B (the result record is 48 B since ABI 3)
     achieved = alg_bytes / avg_kern_s / 1e9
@@ -642,7 +858,7 @@ def main():
 
     # ---- accuracy on the whole batch (BASELINE metric: "Q60 mapeval parity"): paftools-mapeval-style counts
     if have_truth:
-        truth = {k: v for k, v in reads.items() if k not in ("bases", "offsets")}
+        truth = B.truth
         pafs = {"mapped": (hits["status"] == 1).astype(np.uint32)}
         for a_ in ("ref_id", "rc", "mapq", "r_start", "r_end"):
             pafs[a_] = hits[a_]
@@ -659,8 +875,8 @@ def main():
         ox = O.Index()
         ox.build_mt(genome, ctg_off, ctg_names, po, ncpu)
         t_cpu_index = time.time() - t0
-        ns = args.cpu_sample_reads or min(n, 49152)
-        sb = reads["bases"][:int(offs[ns])]
+        ns = min(args.cpu_sample_reads or 49152, n, B.keep_first)
+        sb = B.head_bases[:int(offs[ns])]
         so = offs[:ns + 1]
 
         def timed(nthreads, min_wall_s=5.0, min_passes=3):
@@ -678,16 +894,17 @@ def main():
         # all granted cores, and 10 threads (the reference's own benchmark setting, experiments/figure-k-l/get_mapstats.sh:6)
         t_cpu, t_lo, t_hi, reps, want = timed(ncpu)
         t10, t10_lo, t10_hi, reps10, _ = timed(10)
-        m = want["mapped"] != 0
-        same = bool(np.array_equal(hits["status"][:ns] == 1, m)) and all(
-            np.array_equal(mq.hit_column(hits[:ns], a)[m], want[a][m].astype(np.uint64))
-            for a in ("ref_id", "rc", "mapq", "q_start", "q_end", "r_start", "r_end", "score"))
+        same = columns_equal(mq, hits[:ns], want)
+        # and every 32nd read of the rest of the batch (a lost or misplaced result anywhere in the launch, not only among its first reads)
+        n_strided = int(B.strided_idx.size)
+        same_strided = columns_equal(mq, hits[B.strided_idx], ox.map_batch(B.strided_bases, B.strided_offsets, po, threads=ncpu)) if n_strided else None
         sb_bases = int(so[-1])
         cpu = dict(value=round(sb_bases / t_cpu / 1e9, 4), unit="Gbases/s", cores=ncpu, kind="port",
                    sample="first %d reads (%d bases) of the step batch, C oracle with %d pthreads (cgroup CPU quota of the box), median of %d "
                           "passes (%.1f s), index build (%.1f s) excluded" % (ns, sb_bases, ncpu, reps, t_cpu * reps, t_cpu_index),
                    passes=reps, spread=dict(best=round(sb_bases / t_lo / 1e9, 4), worst=round(sb_bases / t_hi / 1e9, 4)),
-                   seconds=round(t_cpu * reps, 2), paf_columns_identical_to_gpu=same, unique_kminmers_equal=bool(ox.count() == n_unique),
+                   seconds=round(t_cpu * reps, 2), paf_columns_identical_to_gpu=same, strided_sample_reads=n_strided,
+                   strided_sample_identical_to_gpu=same_strided, unique_kminmers_equal=bool(ox.count() == n_unique),
                    at_10_threads=dict(value=round(sb_bases / t10 / 1e9, 4), threads=10, passes=reps10,
                                       spread=dict(best=round(sb_bases / t10_lo / 1e9, 4), worst=round(sb_bases / t10_hi / 1e9, 4)),
                                       note="median; 10 pthreads on %d granted cores; mirrors --threads 10 of experiments/figure-k-l/get_mapstats.sh:6" % ncpu),
@@ -715,21 +932,33 @@ def main():
 
         def leg_k7():
             P7, po7 = mq.Params(k=7, l=31, density=0.01), O.params(k=7, l=31, density=0.01)
-            rd = reads if nr >= n else {k: (v[:nr] if k not in ("bases", "offsets") else v) for k, v in reads.items()}
-            if nr < n:
-                rd["offsets"] = offs[:nr + 1]
-                rd["bases"] = reads["bases"][:int(offs[nr])]
-            return kernel_leg(mq, sim, O, torch, dev, local_rank, P7, po7, genome, ctg_off, ctg_names, rd, lsteps, lwarm, ncpu, args.config_sample_reads,
-                              "the step batch's genome and reads at -k 7 -l 31 -d 0.01 (BASELINE config 4's parameters, experiments/table1.sh:50)")
+            return kernel_leg(mq, sim, O, torch, dev, local_rank, P7, po7, genome, ctg_off, ctg_names, B, lsteps, lwarm, ncpu, args.config_sample_reads,
+                              "the step batch's genome and reads at -k 7 -l 31 -d 0.01 (BASELINE config 4's parameters, experiments/table1.sh:50)", n_reads=nr)
+
+        def leg_variant(v):
+            # the third-party k-min-mer iterator's likeliest other readings (the crate's SIMD hash modes -- the
+            # reference's default HashMode::HpcSimd, src/mers.rs:22-23 -- may hash on 32 bits with an f32 bound): the step batch at seeding
+            # variant v, the oracle switched to the same variant for the column check
+            Pv = mq.Params(k=args.k, l=args.l, density=args.density, seeding_variant=v)
+            return kernel_leg(mq, sim, O, torch, dev, local_rank, Pv, O.params(k=args.k, l=args.l, density=args.density), genome, ctg_off, ctg_names, B, lsteps, lwarm,
+                              ncpu, args.config_sample_reads, "the step batch's genome and reads at seeding variant %d (%s), k=%d l=%d d=%g" % (
+                                  v, " + ".join(nm for bit, nm in ((1, "strict < on the bound"), (2, "f32 bound"), (4, "32-bit ntHash"), (8, "position = run end"),
+                                                                   (16, "end from the compressed window"), (32, "rev on <=")) if v & bit), args.k, args.l, args.density),
+                              n_reads=nr, variant=v)
 
         def leg_genome(lens_, kw, seed, workload):
             g, co, cn = sim.make_genome(lens_, seed=seed, threads=threads, **kw)
-            rd = sim.make_reads(g, co, nr, seed=seed + 1, threads=threads)
-            return kernel_leg(mq, sim, O, torch, dev, local_rank, P, O.params(k=args.k, l=args.l, density=args.density), g, co, cn, rd, lsteps, lwarm, ncpu,
-                              args.config_sample_reads, workload)
+            Bl = load_batch(torch, dev, sim, g, co, nr, seed + 1, threads, keep_first=min(args.config_sample_reads, nr), keep_stride=0)
+            try:
+                return kernel_leg(mq, sim, O, torch, dev, local_rank, P, O.params(k=args.k, l=args.l, density=args.density), g, co, cn, Bl, lsteps, lwarm, ncpu,
+                                  args.config_sample_reads, workload)
+            finally:
+                del Bl
 
         if args.k != 7:
             run_leg("k7", leg_k7)
+        for v in (4, 6):
+            run_leg("variant%d" % v, lambda v=v: leg_variant(v))
         if args.genome_preset != "human-like":
             run_leg("human_like", lambda: leg_genome(lens, sim.HUMAN_LIKE, args.seed + 31,
                                                      "CHM13-sized genome (scale %.3g) with tools/sim.py HUMAN_LIKE repeats (6%% satellite arrays at 99.8%% identity, 5%% segmental "
@@ -745,7 +974,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_e2e:
         import tempfile
         e2e = {}
-        n_hb = min(n, 393216)  # (page-locking the whole step batch would take longer than the leg)
+        n_hb = min(n, 393216, B.keep_first)  # (page-locking the whole step batch would take longer than the leg)
+        reads = host_reads(B, B.keep_first)  # the batch's first reads in host memory: what the file legs write out
         gb, h_e2e = measure_host_buffers(mq, ix, dict(bases=reads["bases"][:int(offs[n_hb])], offsets=offs[:n_hb + 1]))
         e2e["host_buffers_gbases_s"] = round(gb, 2)
         e2e["host_buffers_reads"] = n_hb
@@ -780,7 +1010,7 @@ def main():
             # reads as FASTA for the ratio
             if args.e2e_fastq_reads > 0:
                 try:
-                    big = reads if args.e2e_fastq_reads <= n else sim.make_reads(genome, ctg_off, args.e2e_fastq_reads, seed=args.seed + 5000, threads=threads)
+                    big = reads if args.e2e_fastq_reads <= B.keep_first else sim.make_reads(genome, ctg_off, args.e2e_fastq_reads, seed=args.seed + 5000, threads=threads)
                     k7 = ["-k", "7", "-l", "31", "-d", "0.01"]
                     # (the driver's lean reader: header + sequence lines read with one pread per record, qualities never read; the other reader --
                     # records found on the device, the whole file on the link -- is profiles/r05_fastq_readers.txt)
@@ -835,10 +1065,16 @@ def main():
             "per_rank_gbases_s": per_rank,
             "mapped_frac": round(n_mapped / max(n, 1), 4),
             "overflow_reads": n_over,
+            "records_written": n_written,
+            "unmapped_reads_with_kminmers": n_unmapped_seeded,
             "kminmers_per_step": n_kmm,
             "launch_order": launch_order,
             "smaller_batches": smaller or None,
-            "setup_s": {"genome": round(t_genome, 1), "genome_upload": round(t_upload, 2), "gpu_index": round(t_index, 3), "reads": round(t_reads, 1)},
+            "setup_s": {"genome": round(t_genome, 1), "genome_upload": round(t_upload, 2), "gpu_index": round(t_index, 3), "reads": round(t_reads, 1),
+                        "process_start_to_first_timed_step": round(t_first_step, 1)},
+            "per_rank_setup_s": per_rank_setup,
+            "per_rank_peak_rss_gb": per_rank_rss,
+            "peak_rss_gb_at_exit": peak_rss_gb(),
             "index_build": index_build,
             "q60": n_q60,
             "q60_wrong": n_q60_wrong,

@@ -19,6 +19,10 @@ int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general
  * how many of them were taken up first (n_first <= n_flagged: the front of the order holds 32,768). */
 int mq_last_map_order(mq_index *idx, uint32_t *n_flagged, uint32_t *n_first);
 
+/* How many persistent waves map_kernel employs for a launch of n_reads reads (its grid x 8): wave w's first two work items are items w
+ * and n_waves + w of the launch order, the atomic counter hands out the rest -- the tests place reads on exactly those borders. */
+int mq_map_launch_waves(mq_index *idx, uint32_t n_reads, uint32_t *n_waves);
+
 /* Measurement aid: one instrumented (slower, never timed) launch of the same batch that counts index lookups and the slots
  * visited beyond each lookup's home slot: mean probes per lookup = 1 + extra_steps / lookups (SURVEY 8d's p-bar). */
 int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases, mq_hit *d_out,

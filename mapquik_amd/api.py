@@ -35,7 +35,7 @@ EXPORTS = ["mq_index_set_table_factor", "mq_ctx_submit_fastx", "mq_index_get_par
            "mq_index_add_ref", "mq_index_add_ref_device", "mq_index_finalize", "mq_index_get_stats", "mq_index_ref_info",
            "mq_map_batch", "mq_map_batch_device", "mq_map_reserve", "mq_kminmers_batch", "mq_index_lookup", "mq_format_paf",
            "mq_last_map_ms", "mq_last_map_path_counts", "mq_last_map_order", "mq_host_alloc", "mq_host_free", "mq_index_save", "mq_index_load", "mq_index_clone", "mq_map_probe_stats",
-           "mq_ctx_new", "mq_ctx_free", "mq_ctx_map_batch", "mq_ctx_submit", "mq_ctx_submit_spans", "mq_ctx_wait", "mq_ctx_reserve", "mq_ctx_map_batch_device", "mq_ctx_last_map_ms", "mq_probe_rate", "mq_last_stage_clocks", "mq_last_read_cycles"]
+           "mq_ctx_new", "mq_ctx_free", "mq_ctx_map_batch", "mq_ctx_submit", "mq_ctx_submit_spans", "mq_ctx_wait", "mq_ctx_reserve", "mq_ctx_map_batch_device", "mq_ctx_last_map_ms", "mq_probe_rate", "mq_last_stage_clocks", "mq_last_read_cycles", "mq_map_launch_waves"]
 
 
 class MapquikError(RuntimeError):
@@ -112,9 +112,17 @@ def load_library(path=None):
     abi = L.mq_abi_version()
     if path is None and abi != MQ_ABI_VERSION:
         raise MapquikError("%s has ABI version %d, this binding is for %d: rebuild (python __graft_entry__.py)" % (p, abi, MQ_ABI_VERSION))
-    if abi >= 4 or hasattr(L, "mq_ctx_submit_fasta"):  # (an older build given by MQ_LIB / path for an A/B run may lack them)
+    # (an older build given by MQ_LIB / path for an A/B run may lack the newer symbols: each group under the guard of its own first symbol)
+    if hasattr(L, "mq_index_reserve"):
         L.mq_index_reserve.argtypes = [vp, u64]
-    if abi >= 4 and hasattr(L, "mq_index_stage_begin"):
+    if hasattr(L, "mq_ctx_submit_fasta"):  # ABI 3 on
+        L.mq_host_register.argtypes = [vp, C.c_size_t]
+        L.mq_host_unregister.argtypes = [vp]
+        L.mq_ctx_submit_fasta.argtypes = [vp, vp, u64, u64]
+        L.mq_ctx_wait_fasta.argtypes = [vp, C.POINTER(u32), C.POINTER(vp), C.POINTER(u32), C.POINTER(vp), C.POINTER(u32)]
+    if hasattr(L, "mq_ctx_submit_fastx"):
+        L.mq_ctx_submit_fastx.argtypes = [vp, vp, u64, u64, u32]
+    if hasattr(L, "mq_index_stage_begin"):  # ABI 4
         L.mq_index_set_table_factor.argtypes = [vp, u32]
         L.mq_index_get_params.argtypes = [vp, C.POINTER(Params)]
         L.mq_index_set_map_params.argtypes = [vp, u32, u32, u32, C.c_int]
@@ -123,12 +131,6 @@ def load_library(path=None):
         L.mq_index_stage_done.argtypes = [vp, u64, C.c_int]
         L.mq_index_add_ref_staged.restype = C.c_int64
         L.mq_index_add_ref_staged.argtypes = [vp, u32, C.c_char_p, u64, u64, u64]
-        L.mq_host_register.argtypes = [vp, C.c_size_t]
-        L.mq_host_unregister.argtypes = [vp]
-        L.mq_ctx_submit_fasta.argtypes = [vp, vp, u64, u64]
-        if hasattr(L, "mq_ctx_submit_fastx"):
-            L.mq_ctx_submit_fastx.argtypes = [vp, vp, u64, u64, u32]
-        L.mq_ctx_wait_fasta.argtypes = [vp, C.POINTER(u32), C.POINTER(vp), C.POINTER(u32), C.POINTER(vp), C.POINTER(u32)]
     L.mq_ctx_reserve.argtypes = [vp, u32, u64]
     L.mq_ctx_map_batch_device.argtypes = [vp, vp, vp, u32, u64, vp, vp]
     L.mq_ctx_last_map_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -141,6 +143,8 @@ def load_library(path=None):
     if hasattr(L, "mq_last_read_cycles"):
         L.mq_last_read_cycles.argtypes = [vp, u32, vp, vp]
     L.mq_map_probe_stats.argtypes = [vp, vp, vp, u32, u64, vp, C.POINTER(u64), C.POINTER(u64)]
+    if hasattr(L, "mq_map_launch_waves"):
+        L.mq_map_launch_waves.argtypes = [vp, u32, C.POINTER(u32)]
     L.mq_index_save.argtypes = [vp, C.c_char_p]
     L.mq_index_clone.restype = vp
     L.mq_index_clone.argtypes = [vp, C.c_int]
@@ -287,14 +291,18 @@ class Index:
         t = C.c_uint64()
         if self._L.mq_index_stage_piece(self._h, int(at), _p(s), s.size, C.byref(t)) != 0:
             raise _err(self._L, "mq_index_stage_piece")
-        self._staged = getattr(self, "_staged", [])
-        self._staged.append(s)  # the source stays alive until the index is finalized
+        self._staged = getattr(self, "_staged", {})
+        self._staged[t.value] = s  # the source stays alive until its copy is known to be done (stage_done) or the index is finalized
         return t.value
 
     def stage_done(self, ticket, wait=True):
         r = self._L.mq_index_stage_done(self._h, int(ticket), 1 if wait else 0)
         if r < 0:
             raise _err(self._L, "mq_index_stage_done")
+        if r:  # copies complete in order: every source up to this ticket can go
+            st = getattr(self, "_staged", {})
+            for t in [t for t in st if t <= int(ticket)]:
+                del st[t]
         return bool(r)
 
     def add_ref_staged(self, ref_idx, name, at, length, after_ticket=None):
@@ -315,6 +323,7 @@ class Index:
         n = self._L.mq_index_finalize(self._h)
         if n < 0:
             raise _err(self._L, "mq_index_finalize")
+        self._staged = {}  # every staged piece has been indexed: the sources can go
         return n
 
     def stats(self):
@@ -388,6 +397,13 @@ class Index:
         if self._L.mq_last_map_path_counts(self._h, C.byref(a), C.byref(b)) != 0:
             raise _err(self._L, "mq_last_map_path_counts")
         return a.value, b.value
+
+    def launch_waves(self, n_reads):
+        """Persistent waves map_kernel employs for a launch of n_reads reads (wave w owns work items w and n_waves + w)."""
+        a = C.c_uint32()
+        if self._L.mq_map_launch_waves(self._h, int(n_reads), C.byref(a)) != 0:
+            raise _err(self._L, "mq_map_launch_waves")
+        return a.value
 
     def last_map_order(self):
         """(reads the ordering pass of the last launch took for short-period tandem arrays, reads it put first)."""

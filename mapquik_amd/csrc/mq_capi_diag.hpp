@@ -115,6 +115,20 @@ int mq_last_map_order(mq_index *idx, uint32_t *n_flagged, uint32_t *n_first) try
     return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
+int mq_map_launch_waves(mq_index *idx, uint32_t n_reads, uint32_t *n_waves) try {
+    if (!idx || !n_waves) return set_err(MQ_EINVAL, "bad arguments");
+    int rc = use_device(idx);
+    if (rc) return rc;
+    if ((rc = ensure_geometry(idx))) return rc;
+    const uint32_t grid = std::min<uint32_t>(idx->grid_fused, (n_reads + MAP_WAVES - 1) / MAP_WAVES);  // launch_map's grid
+    *n_waves = grid * (uint32_t)MAP_WAVES;
+    return MQ_OK;
+} catch (const std::bad_alloc &) {
+    return set_err(MQ_ENOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+}
+
 int mq_map_probe_stats(mq_index *idx, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n, uint64_t total_bases, mq_hit *d_out,
                        uint64_t *lookups, uint64_t *extra_steps) try {
     if (!idx || !lookups || !extra_steps) return set_err(MQ_EINVAL, "bad arguments");

@@ -22,12 +22,6 @@ mq_index *mq_index_new(const mq_params *params, int device) try {
         set_err(MQ_EINVAL, "seeding variant 8 (position = end of the homopolymer run) needs l >= 2: the run's end is read off the window's second base");
         return nullptr;
     }
-#if MQ_LDS_LIST || MQ_LDS_PREFETCH
-    if (variant & MQ_SEEDVAR_END_COMPRESSED) {
-        set_err(MQ_EINVAL, "seeding variant 16 is not available in this experimental build (MQ_LDS_LIST / MQ_LDS_PREFETCH)");
-        return nullptr;
-    }
-#endif
     const bool init_timing = getenv("MQ_DRIVER_TIMING") != nullptr;  // diagnostic (stderr): where the first index's start-up time goes
     const auto ti0 = std::chrono::steady_clock::now();
     auto stamp = [&](const char *what) {
@@ -245,8 +239,14 @@ int mq_index_stage_begin(mq_index *idx, uint64_t total_bytes) try {
     std::lock_guard<std::mutex> lk(idx->stg_mu);
     if (idx->stg_buf) return set_err(MQ_ESTATE, "mq_index_stage_begin: one staging buffer per index");
     HIPCHK(hipMalloc((void **)&idx->stg_buf, total_bytes + 64));
+    const hipError_t es = hipStreamCreateWithFlags(&idx->stg_stream, hipStreamNonBlocking);
+    if (es != hipSuccess) {  // no buffer without its stream: a later mq_index_stage_piece must not find one
+        (void)hipFree(idx->stg_buf);
+        idx->stg_buf = nullptr;
+        idx->stg_stream = nullptr;
+        return set_err(MQ_EHIP, std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(es));
+    }
     idx->stg_bytes = total_bytes;
-    HIPCHK(hipStreamCreateWithFlags(&idx->stg_stream, hipStreamNonBlocking));
     return MQ_OK;
 } catch (const std::bad_alloc &) {
     return set_err(MQ_ENOMEM, "out of host memory");
@@ -262,10 +262,16 @@ int mq_index_stage_piece(mq_index *idx, uint64_t at, const uint8_t *src, uint64_
     if (!idx->stg_buf) return set_err(MQ_ESTATE, "mq_index_stage_piece before mq_index_stage_begin");
     if (at > idx->stg_bytes || n > idx->stg_bytes - at) return set_err(MQ_EINVAL, "piece outside the staging buffer");
     if (n) HIPCHK(hipMemcpyAsync(idx->stg_buf + at, src, n, hipMemcpyHostToDevice, idx->stg_stream));
+    // ticket t <=> stg_events[t], a RECORDED event: the event joins the list only once its record has succeeded (a ticket that indexed an
+    // event never recorded would let a wait return at once and a record be indexed before its bytes arrive)
     hipEvent_t ev;
     HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    const hipError_t er = hipEventRecord(ev, idx->stg_stream);
+    if (er != hipSuccess) {
+        (void)hipEventDestroy(ev);
+        return set_err(MQ_EHIP, std::string("hipEventRecord: ") + hipGetErrorString(er));
+    }
     idx->stg_events.push_back(ev);
-    HIPCHK(hipEventRecord(ev, idx->stg_stream));
     *ticket = idx->stg_issued++;
     return MQ_OK;
 } catch (const std::bad_alloc &) {

@@ -267,7 +267,22 @@ static int ensure_geometry_once(mq_index *idx) {
         return MQ_OK;
     };
     int occ = 0, rc;
-    if ((rc = occ_of((const void *)map_kernel<64, false>, 64 * MAP_WAVES, occ))) return rc;
+    // the grid of a launch sequence = the workgroups that are RESIDENT together, for every instantiation launched on it: wave w's first two
+    // work items are its own (items w and n_waves + w, among them the heavy reads that go first), so a workgroup that has to wait for a
+    // place would hold them back; the variants' instantiation and map_declined_kernel (more scratch) may fit fewer than map_kernel<64, false>
+    {
+        const void *fns[] = {(const void *)map_kernel<64, false, false>, (const void *)map_kernel<64, false, true>, (const void *)map_kernel<64, true, false>,
+                             (const void *)map_kernel<64, true, true>, (const void *)map_kernel<4, false, false>, (const void *)map_kernel<4, false, true>,
+                             (const void *)map_declined_kernel<64, false, false>, (const void *)map_declined_kernel<64, false, true>,
+                             (const void *)map_declined_kernel<64, true, false>, (const void *)map_declined_kernel<64, true, true>,
+                             (const void *)map_declined_kernel<4, false, false>, (const void *)map_declined_kernel<4, false, true>};
+        int occ_min = 8;
+        for (const void *fn : fns) {
+            if ((rc = occ_of(fn, 64 * MAP_WAVES, occ))) return rc;
+            occ_min = std::min(occ_min, occ);
+        }
+        occ = occ_min;
+    }
     idx->grid_fused = (uint32_t)(occ * idx->n_cu);
     if ((rc = occ_of((const void *)seed_reads_kernel<0>, 64 * SEED_WAVES, occ))) return rc;
     idx->grid_seed = (uint32_t)(occ * idx->n_cu);

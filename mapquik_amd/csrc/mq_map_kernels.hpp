@@ -335,24 +335,15 @@ __device__ __forceinline__ uint32_t seed_read_hybrid(const SplitArgs &A, const S
 constexpr int ML_NB = MQ_ML_NB;                              // lane-batches of 64 k-min-mers hashed and probed together
 constexpr uint32_t ML_LIST_CAP = 64 * ML_NB + MAX_L;   // minimizers staged in LDS at a time (64 * ML_NB + k - 1 used, k <= 32)
 static_assert(MAX_L >= 32, "k - 1 <= 31 entries of overlap between chunks");
-// MQ_LDS_LIST = n > 0: map_kernel keeps the first n minimizers of the read it is working on in LDS (mq_seed.hpp LdsThenGlobalList): the
-// list of an ordinary read is never written to device memory nor read back.  Needs the LDS of one 16-wave workgroup per CU with
-// two-super-row tiles (MQ_MAP_WAVES=16, MQ_SD_MAX_SR=2).
-#ifndef MQ_LDS_LIST
-#define MQ_LDS_LIST 0
-#endif
-constexpr uint32_t LDS_LIST_CAP = MQ_LDS_LIST;
-typedef LdsList<(LDS_LIST_CAP ? LDS_LIST_CAP : 1)> ReadListLds;
 struct MapListLds {
     unsigned long long h[ML_LIST_CAP];
     uint32_t p[ML_LIST_CAP];
     MatchRec rec[MAP_LDS_RECS];  // MapSink::lds_rec
-    uint32_t next_off[8];        // map_kernel: offsets (and length) of the wave's next read, fetched straight into LDS during the map phase
 };
 
 // map phase of read r: its list (cnt entries at base) -> mq_hit
 // the read's result is left in h (all lanes hold it); store_hit() writes it: the fused kernel does that after it has taken the
-// prefetched offsets of its next read out of their registers, so that this store's acknowledgement is nothing a wave waits for
+// prefetched descriptor of its next read out of its registers, so that this store's acknowledgement is nothing a wave waits for
 __device__ __forceinline__ void store_hit(const SplitArgs &A, uint32_t r, const mq_hit &h) {
     if (lane_id() == 0) {
         A.out[r] = h;
@@ -360,18 +351,9 @@ __device__ __forceinline__ void store_hit(const SplitArgs &A, uint32_t r, const 
     }
 }
 
-struct NoOp {
-    __device__ __forceinline__ void operator()() const {}
-};
-// lds_h / lds_p: the whole list (cnt entries) already in LDS -- then nothing is staged; nullptr: the list is at `base` in device memory.
-// list_done(): called exactly once, when the staged HASHES (S.h) are no longer needed: after the tuple hashes of the list's last chunk.
-// probes_done(): called exactly once, when the read's last probe has been resolved (nothing of the map phase is in flight any more): in front of
-// the chain stage, or where the chain stage would be for a read without Matches.
-template <int CH, bool TIMING, class F = NoOp, bool VAR = true, class F2 = NoOp>
+template <int CH, bool TIMING, bool VAR = true>
 __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, MatchRec *scratch, uint32_t r, uint64_t len, uint32_t cnt,
-                                         uint64_t base, unsigned long long &t_steps, unsigned long long &t_lookups, mq_hit &h,
-                                         const unsigned long long *lds_h = nullptr, const uint32_t *lds_p = nullptr, const F &list_done = F(),
-                                         const F2 &probes_done = F2()) {
+                                         uint64_t base, unsigned long long &t_steps, unsigned long long &t_lookups, mq_hit &h) {
     const uint32_t lane = lane_id();
     const DevParams &P = A.P;
     h.status = MQ_HIT_UNMAPPED;
@@ -379,7 +361,6 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
     uint32_t n_kmm = 0;
     if (cnt == LIST_OVERFLOW) {
         h.status = MQ_HIT_OVERFLOW;  // the list fits neither its region nor the pool: nothing was computed for this read
-        probes_done();
     } else if (cnt >= P.k) {
         mq_kminmer *d = nullptr;
         uint32_t dcap = 0;
@@ -391,12 +372,10 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
         const unsigned long long *lh = A.mz_hash + base;
         const uint32_t *lp = A.mz_pos + base;
         const uint32_t chunk = 64u * (uint32_t)ML_NB + P.k - 1u;
-        bool requested = false;
         for (uint32_t g = 0; g + P.k <= cnt;) {
             const uint32_t have = cnt - g < chunk ? cnt - g : chunk;
-            const bool last = g + have >= cnt;
-            if (!lds_h) {  // L2-served loads (the list may have been written by this very wave), ALL in flight before the first is stored: one L2
-               // round trip per chunk (a loop that loads and stores 64 entries at a time exposes one per 64 entries)
+            {  // L2-served loads (the list was written by this very wave), ALL in flight before the first is stored: one L2 round trip
+               // per chunk (a loop that loads and stores 64 entries at a time exposes one per 64 entries)
                 unsigned long long hv[ML_NB + 1];
                 uint32_t pv[ML_NB + 1];
 #pragma unroll
@@ -421,17 +400,13 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
             wave_sync();
             mq_clk(5);
             // seeding variant 16: the chunk's second positions take the place of its hashes once those are used up (S.h as dwords)
-            uint32_t *mzq = (VAR && A.mz_last && !lds_h) ? reinterpret_cast<uint32_t *>(S.h) : nullptr;
-            sink.template consume_list<ML_NB>(lds_h ? lds_h + g : S.h, lds_p ? lds_p + g : S.p, have, [&]() {
+            uint32_t *mzq = (VAR && A.mz_last) ? reinterpret_cast<uint32_t *>(S.h) : nullptr;
+            sink.template consume_list<ML_NB>(S.h, S.p, have, [&]() {
                 if (mzq) {
                     const uint32_t *lq = A.mz_last + base + g;
                     wave_sync();  // every lane's reads of the staged hashes are done
                     for (uint32_t i = lane; i < have; i += 64u) mzq[i] = ld_sc1_u32(lq + i);
                     wave_sync();
-                }
-                if (last && !requested) {
-                    requested = true;
-                    list_done();
                 }
             }, mzq);
             wave_sync();
@@ -439,11 +414,6 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
         }
         sink.finish_runs();
         n_kmm = sink.kmm_count;
-        if (!requested) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing was staged: whatever list_done() wants to find in LDS has landed
-            list_done();
-        }
-        probes_done();
         if (sink.n_matches > 0 && sink.n_matches <= MAP_LDS_RECS && sink.n_matches <= (uint32_t)CH) {
             // all of the read's records are in LDS: lane i takes record i, and the chain stage -- one chunk -- reads no Match record
             wave_sync();
@@ -469,10 +439,6 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
             t_steps += wave_sum_u32(sink.probe_steps);
             t_lookups += n_kmm;
         }
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        list_done();
-        probes_done();
     }
     h.n_kminmers = n_kmm;
     mq_clk(9);
@@ -485,20 +451,10 @@ __device__ __forceinline__ void map_read(const SplitArgs &A, MapListLds &S, Matc
 #define MQ_MAP_MIN_WAVES 4
 #endif
 constexpr int MAP_WAVES = MQ_MAP_WAVES;
-// 1 (experiment, off: measured -1.2 %): the first super-row of a wave's NEXT read is requested as soon as the current read's tuple hashes
-// are done, straight into the LDS area of the staged hashes (global_load_lds_dwordx4: no registers ride through the rest of the map
-// phase), together with the work-item atomic after it, and picked up from there at the end of the map phase; the next read's offsets come
-// the same way.  The seed phase then opens without a memory round trip (-3.2 k cycles of a read's 172 k), but the requests, the pick-up
-// and the LDS-direct loads' waits cost the map phase 3.9 k (profiles/NOTES.md).
-#ifndef MQ_LDS_PREFETCH
-#define MQ_LDS_PREFETCH 0
-#endif
-#ifndef MQ_NEXT_READ_PREFETCH
-#define MQ_NEXT_READ_PREFETCH 0
-#endif
-static_assert(!(MQ_LDS_PREFETCH && MQ_LDS_LIST), "MQ_LDS_PREFETCH lands in the staged list's area");
 
-// per-wave LDS of the fused kernel: the phases of one read follow each other, so they share the memory
+// per-wave LDS of the fused kernel: the phases of one read follow each other, so they share the memory.  (map_declined_kernel hands
+// `seed` AND `general` to seed_read_hybrid, which runs the two seeders in turn: neither may carry LDS state from one call to the next --
+// every seed_sequence_fast / seed_segment call starts from scratch and is fenced by wave_sync + vmcnt(0).)
 union MapWaveLds {
     SeedLds seed;
     WaveLds general;
@@ -508,15 +464,15 @@ union MapWaveLds {
 // CH: lanes per chunk in the chain stage (64 in production; 4 only in tests so that ordinary reads take the multi-chunk path)
 // VAR: built with the seeding variants (mq_params.flags bits 8..13); the launch for variant 0 -- the frozen reading, every timed launch --
 // uses the instantiation without them
+// (Experiments that lived here behind macros until round 5 -- the next read's first super-row prefetched into LDS, the read's minimizer
+// list kept in LDS, the prefetch issued when the probes are done, staggered wave starts: all measured at or below the product path --
+// are in git history, last at commit cc976e3; numbers in profiles/NOTES.md.)
 template <int CH, bool TIMING = false, bool VAR = false>
 __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(const SplitArgs A) {
     // one block of LDS with the tables FIRST: T.rot's entries are addressed through the 16-bit immediate offset of ds_read_b128
     __shared__ struct {
         SeedTables T;
         MapWaveLds SS[MAP_WAVES];
-#if MQ_LDS_LIST
-        ReadListLds LL[MAP_WAVES];
-#endif
     } W;
     SeedTables &T = W.T;
     MapWaveLds(&SS)[MAP_WAVES] = W.SS;
@@ -531,34 +487,15 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
     const uint64_t o_base = A.offsets[0];
     uint32_t n_fast = 0, n_general = 0, n_moved = 0;
     unsigned long long t_steps = 0, t_lookups = 0;
-#ifdef MQ_STAGGER  // experiment (profiles/NOTES.md): the waves of a SIMD start MQ_STAGGER x 8 k cycles apart instead of in the same stage
-    {
-        uint32_t hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        for (uint32_t i = (hw & 3u) * (uint32_t)(MQ_STAGGER); i; --i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
 #ifdef MQ_STAGE_CLOCKS
     if (lane == 0)
         for (int i = 0; i < MQ_N_CLK; ++i) mq_clk_lds().acc[wv][i] = 0;
     mq_clk(-1);
 #endif
     // The work item after the current one is fetched while the current one is processed: its index (one atomic) during the seed
-    // phase, its offsets during the map phase -- two dependent memory round trips per read that no wave waits for.  (Requesting
+    // phase, its descriptor during the map phase -- two dependent memory round trips per read that no wave waits for.  (Requesting
     // the next read's first super-row across the map phase as well was measured at -3 %: a wave's loads return in order, so the
     // map phase's first wait -- an L2 round trip for the list -- then sits behind an HBM one.)
-#if MQ_LDS_PREFETCH  // (this experimental build takes the reads in their own order, from the caller's arrays)
-    uint32_t r = 0;
-    if (lane == 0) r = atomicAdd(&A.counters[0], 1u);
-    r = rdfirst(r);
-    uint32_t rn_v = 0;  // lane 0: the work item after r, taken one read ahead (the request goes out with the next read's first super-row)
-    if (lane == 0) rn_v = atomicAdd(&A.counters[0], 1u);
-    uint64_t o0 = 0, len = 0;
-    if (r < A.n) {
-        o0 = A.offsets[r];
-        len = A.lens ? (uint64_t)A.lens[r] : A.offsets[r + 1] - o0;
-    }
-#else
     // work items = order_reads_kernel's descriptors: the reads that go first, then all reads in their own order (those that went first marked)
     const uint32_t nf = A.counters[WORK_NF] < WORK_FRONT_CAP ? A.counters[WORK_NF] : WORK_FRONT_CAP;
     const uint4 *work = A.work + (WORK_FRONT_CAP - nf);
@@ -596,24 +533,20 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         }
     };
     take_now();
-#endif
-    APre pre;                // the current read's first super-row when pre_valid (MQ_LDS_PREFETCH: picked up from LDS at the end of the
-    bool pre_valid = false;  // iteration before)
+    APre pre;  // the current read's first super-row (requested by seed_sequence_fast itself: nothing requests it ahead of the read)
     while (r < A.n) {
         // the instrumented launch (TIMING, never timed) also notes what every read cost its wave: mq_last_read_cycles
         const unsigned long long t_read0 = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
         const unsigned long long t_real0 = TIMING ? __builtin_amdgcn_s_memrealtime() : 0ull;
-#if !MQ_LDS_PREFETCH
+        // THE hand-over of work items (one place): the item after this read is the wave's own second item or comes from the counter
         uint32_t rn_v = own2;
         if (own2 == 0xFFFFFFFFu) {
             if (lane == 0) rn_v = atomicAdd(&A.counters[0], 1u);
             rn_v += 2u * n_waves;
         }
         own2 = 0xFFFFFFFFu;
-#endif
         uint32_t cnt = 0;
         uint64_t base = 0;
-        bool in_lds = false;  // the read's whole minimizer list is in W.LL[wv] (MQ_LDS_LIST builds)
         mq_clk(11);
         // extract(): len < l + k - 1 => None (src/mers.rs:44)
         if (len >> 32) {
@@ -621,170 +554,41 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_kernel(c
         } else if (len >= (uint64_t)P.l + P.k - 1u && !var_keep_none<VAR>(P)) {
             uint32_t cap;
             list_region(A, o0 - o_base, len, r, base, cap);
-#if MQ_LDS_LIST
-            cnt = SD_NOT_FAST;
-            if (!A.force_general) {
-                ReadListLds &L = W.LL[wv];
-                const LdsThenGlobalList<LDS_LIST_CAP> out = {L, {A.mz_hash + base, A.mz_pos + base, cap, nullptr}};
-                cnt = seed_sequence_fast_to<0, false, LdsThenGlobalList<LDS_LIST_CAP>>(A.bases + o0, (uint32_t)len, P, T, S.seed, out, pre, false);
-                if (cnt != SD_NOT_FAST) {
-                    if (cnt <= LDS_LIST_CAP) {
-                        in_lds = true;
-                    } else if (cnt <= cap) {  // a long read: the head of its list joins the rest in its region
-                        wave_sync();
-                        for (uint32_t i = lane; i < LDS_LIST_CAP; i += 64u) {
-                            A.mz_hash[base + i] = L.h[i];
-                            A.mz_pos[base + i] = L.p[i];
-                        }
-                    } else if (pool_take(A, cnt, base)) {  // denser than its region: once more, into an exact-size pool region
-                        seed_sequence_fast(A.bases + o0, (uint32_t)len, P, T, S.seed, A.mz_hash + base, A.mz_pos + base, cnt, pre, false);
-                        n_moved++;
-                    } else {
-                        cnt = LIST_OVERFLOW;
-                    }
-                }
-            }
-#else
-            cnt = A.force_general ? SD_NOT_FAST : seed_read_fast<0, VAR>(A, T, S.seed, A.bases + o0, (uint32_t)len, base, cap, n_moved, pre, pre_valid);
-#endif
+            cnt = A.force_general ? SD_NOT_FAST : seed_read_fast<0, VAR>(A, T, S.seed, A.bases + o0, (uint32_t)len, base, cap, n_moved, pre, false);
             if (cnt == SD_NOT_FAST) {
                 n_general++;
-#if MQ_LDS_PREFETCH || MQ_LDS_LIST
-                wave_sync();
-                cnt = seed_read_general<VAR>(A, S.general, A.bases + o0, len, base, cap, n_moved);
-#else
                 // a byte other than A C G T (or a candidate on the bound): the read is queued for map_declined_kernel, which seeds it stretch
                 // by stretch and maps it (what is stored for it here -- an unmapped record -- is overwritten there)
                 if (lane == 0) A.queue[atomicAdd(&A.counters[2], 1u)] = r;
                 cnt = 0;
-#endif
                 mq_clk(10);
             } else {
                 n_fast++;
             }
-            if (!in_lds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have reached L2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have reached L2
             wave_sync();
             mq_clk(4);
         }
         const uint32_t rn = rdfirst(rn_v);
-#if MQ_LDS_PREFETCH
-        // the next read's offsets: LDS-direct loads by lane 0 (no register waits through the map phase for them -- the map phase has none
-        // to spare: held in registers they were spilled, which takes the load's round trip first); they land while the list is staged
-        if (lane_id() == 0 && rn < A.n) {
-            typedef __attribute__((address_space(3))) void lds_void;
-            typedef const __attribute__((address_space(1))) void glb_void;
-            if (A.lens) {
-                const uint32_t *po = reinterpret_cast<const uint32_t *>(A.offsets + rn);
-                __builtin_amdgcn_global_load_lds((glb_void *)po, (lds_void *)&S.map.next_off[0], 4, 0, 0);
-                __builtin_amdgcn_global_load_lds((glb_void *)(po + 1), (lds_void *)&S.map.next_off[1], 4, 0, 0);
-                __builtin_amdgcn_global_load_lds((glb_void *)(A.lens + rn), (lds_void *)&S.map.next_off[4], 4, 0, 0);
-            } else {
-                __builtin_amdgcn_global_load_lds((glb_void *)(A.offsets + rn), (lds_void *)&S.map.next_off[0], 16, 0, 0);
-            }
-        }
-#else
         uint4 nd = make_uint4(0u, 0u, 0u, 0u);
         if (lane == 0 && rn < n_items) nd = work[rn];  // a vector load by one lane: in flight through the map phase (a scalar load would be waited for at its first LDS wait)
-#endif
         mq_hit h;
-#if MQ_LDS_LIST
-        map_read<CH, TIMING>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h, in_lds ? W.LL[wv].h : nullptr, in_lds ? W.LL[wv].p : nullptr);
-#elif MQ_LDS_PREFETCH
-        uint64_t o0_n = 0, len_n = 0;
-        uint32_t rnn_v = 0;
-        bool pre_in_lds = false;  // the next read's first super-row is on its way into S.map.h
-        auto request_next = [&]() {  // the staged list is done with: the next read's first super-row goes into its place
-            {  // (landed long ago: the list's staging waited for everything issued before it)
-                const uint4 v = *reinterpret_cast<const uint4 *>(&S.map.next_off[0]);
-                const uint32_t nl = S.map.next_off[4];
-                o0_n = ((uint64_t)rdfirst(v.y) << 32) | rdfirst(v.x);
-                len_n = A.lens ? (uint64_t)rdfirst(nl) : ((((uint64_t)rdfirst(v.w) << 32) | rdfirst(v.z)) - o0_n);
-            }
-            // the work item after the next: its atomic is as old as the requests below, so the pick-up's wait covers it and stage A
-            // never waits for anything but its own super-rows
-            if (lane == 0) rnn_v = atomicAdd(&A.counters[0], 1u);
-            // (32-bit tests: the compiler keeps 64-bit comparands in a spilled register pair, and a reload here waits for every probe)
-            const uint32_t ln_hi = (uint32_t)(len_n >> 32), ln_lo = (uint32_t)len_n;
-            pre_in_lds = rn < A.n && !A.force_general && ln_hi == 0u && ln_lo >= 16u && ln_lo >= P.l + P.k - 1u;  // seed_fast_eligible, extract()'s guard
-            if (pre_in_lds) {
-                const uint8_t *seq = A.bases + o0_n;
-                const uint32_t ln = (uint32_t)len_n;
-                typedef __attribute__((address_space(3))) void lds_void;
-                typedef const __attribute__((address_space(1))) void glb_void;
-                char *land = reinterpret_cast<char *>(S.map.h);
-                const uint32_t ln_id = lane_id();  // its own copy: a value the compiler carries around the read loop gets spilled
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) {  // piece j of every lane: the address load_piece() would use
-                    const uint32_t pos = ln_id * 64u + 16u * j;
-                    const uint32_t pp = pos < ln - 16u ? pos : ln - 16u;
-                    __builtin_amdgcn_global_load_lds((glb_void *)(seq + pp), (lds_void *)(land + 1024u * j), 16, 0, 0);
-                }
-            }
-        };
-        map_read<CH, TIMING>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h, nullptr, nullptr, request_next);
-#else
-#if MQ_NEXT_READ_PREFETCH
-        // the next read's first super-row is requested when this read's probes are done: its HBM round trip (9 k cycles of a read's 130 k in
-        // front of stage A, which nothing preceded) runs beside the chain stage.  The descriptor has landed: every load issued after it was
-        // waited for.  (`pre` is assigned on both sides: carried conditionally it would stay alive across the whole map phase.)
-        bool pre_next = false;
-        auto request_next = [&]() {
-            const uint32_t w_ = rdfirst(nd.w), l_ = rdfirst(nd.z);
-            pre_next = rn < n_items && !(w_ & (WORK_SKIP | WORK_TOO_LONG)) && l_ >= 16u && l_ >= P.l + P.k - 1u && !A.force_general;
-            if (pre_next) {
-                stage_a_request(A.bases + (((uint64_t)rdfirst(nd.y) << 32) | rdfirst(nd.x)), l_, 0, pre);
-            } else {
-                pre.nx0 = pre.nx1 = pre.nx2 = pre.nx3 = make_uint4(0u, 0u, 0u, 0u);
-            }
-        };
-        map_read<CH, TIMING, NoOp, VAR>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h, nullptr, nullptr, NoOp(), request_next);
-        pre_valid = pre_next;
-#else
-        map_read<CH, TIMING, NoOp, VAR>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h);
-#endif
-#endif
+        map_read<CH, TIMING, VAR>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h);
         wave_sync();
         const uint32_t r_done = r;
-#if MQ_LDS_PREFETCH
-        r = rn;
-        o0 = o0_n;
-        len = len_n;
-        rn_v = rnn_v;
-        // pick the next read's first super-row up BEFORE this read's result is stored: the wait then covers the four requests and the
-        // work-item atomic (all as old as the chain stage) and nothing younger
-        // (unconditionally: assigned only when the request went out, `pre` would keep its old contents alive across the whole map phase
-        // of the next read -- 16 registers the map phase does not have; what is read when nothing was requested is never used)
-        pre_valid = pre_in_lds;
-        {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            const uint4 *land = reinterpret_cast<const uint4 *>(S.map.h) + lane_id();
-            pre.nx0 = land[0];
-            pre.nx1 = land[64];
-            pre.nx2 = land[128];
-            pre.nx3 = land[192];
-            wave_sync();  // in registers before stage A clears its code stream (the same LDS)
-        }
-        store_hit(A, r_done, h);
-    }
-#else
         const uint32_t nw = rdfirst(nd.w);
         o0 = ((uint64_t)rdfirst(nd.y) << 32) | rdfirst(nd.x);
         len = (uint64_t)rdfirst(nd.z) | ((uint64_t)((nw >> 30) & 1u) << 32);
         r = rn < n_items ? (nw & WORK_ID_MASK) : 0xFFFFFFFFu;
         asm volatile("" ::: "memory");  // the prefetched descriptor is out of its registers before the result's store is issued
         store_hit(A, r_done, h);
-        if (rn < n_items && (nw & WORK_SKIP)) {  // that read went first
-            take_now();
-            pre_valid = false;
-        }
+        if (rn < n_items && (nw & WORK_SKIP)) take_now();  // that read went first
         if (TIMING && lane == 0) {
             const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_read0;
             A.mz_count[r_done] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
             A.mz_base[r_done] = t_real0;
         }
     }
-#endif
     if (lane == 0) {
         if (n_fast) atomicAdd(&A.counters[4], n_fast);
         if (n_general) atomicAdd(&A.counters[5], n_general);
@@ -837,7 +641,7 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_declined
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have reached L2
         wave_sync();
         mq_hit h;
-        map_read<CH, TIMING, NoOp, VAR>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h);
+        map_read<CH, TIMING, VAR>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h);
         wave_sync();
         store_hit(A, r, h);
         if (TIMING && lane == 0) {  // mq_last_read_cycles: this read's cycles here (seeding in the high half of the start word's place: see tools/read_tail.py)

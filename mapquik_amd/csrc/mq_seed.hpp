@@ -251,11 +251,7 @@ __device__ __forceinline__ bool seed_stage_a(const uint8_t *__restrict__ seq, ui
             bad |= (__builtin_amdgcn_perm(S0, S1, t0) ^ nx.x) | (__builtin_amdgcn_perm(S0, S1, t1) ^ nx.y) |
                    (__builtin_amdgcn_perm(S0, S1, t2) ^ nx.z) | (__builtin_amdgcn_perm(S0, S1, t3) ^ nx.w);
             p[j] = pack16(t0, t1, t2, t3);
-#ifdef MQ_EXPERIMENT_COALESCED  // WRONG RESULTS: timing experiment only (a wave's piece j = 1 KB contiguous)
-            nx = load_piece(seq, len, raw0 + (sr + 1u) * SD_SR_RAW + 1024u * j + 16u * lane);
-#else
             nx = load_piece(seq, len, pos + SD_SR_RAW + 16u * j);
-#endif
         };
         decode(nx0, 0);
         decode(nx1, 1);
@@ -499,7 +495,6 @@ __device__ __forceinline__ uint32_t stage_b_block(const SeedTables &T, uint32_t 
             // reads vcc right behind the one that wrote it; tools/valu_enc.hip, profiles/r04_valu_enc_stepb.txt: 30 -> 22 cycles per step).
             // The xors are plain v_xor_b32 in asm anyway: left to itself the SLP vectoriser pairs the words and, for the swapped halves,
             // first materialises the swap with two v_pk_mov_b32 per step.
-#ifndef MQ_SD_FLAG_PAIR_ADJACENT
             if (((TT + 1u) & 63u) < 32u) {
                 asm("v_cmp_ge_u32_e32 vcc, %10, %9\n\tv_xor_b32 %0, %0, %5\n\tv_xor_b32 %1, %1, %6\n\tv_xor_b32 %2, %2, %7\n\tv_xor_b32 %3, %3, %8\n\t"
                     "v_addc_co_u32_e32 %4, vcc, %4, %4, vcc"
@@ -509,16 +504,6 @@ __device__ __forceinline__ uint32_t stage_b_block(const SeedTables &T, uint32_t 
                     "v_addc_co_u32_e32 %4, vcc, %4, %4, vcc"
                     : "+v"(glo), "+v"(ghi), "+v"(hlo), "+v"(hhi), "+v"(fbits) : "v"(e.y), "v"(e.x), "v"(e.w), "v"(e.z), "v"(mhi), "s"(bhi) : "vcc");
             }
-#else
-            asm("v_cmp_ge_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(fbits) : "v"(mhi), "s"(bhi) : "vcc");
-            if (((TT + 1u) & 63u) < 32u) {
-                asm("v_xor_b32 %0, %0, %4\n\tv_xor_b32 %1, %1, %5\n\tv_xor_b32 %2, %2, %6\n\tv_xor_b32 %3, %3, %7"
-                    : "+v"(glo), "+v"(ghi), "+v"(hlo), "+v"(hhi) : "v"(e.x), "v"(e.y), "v"(e.z), "v"(e.w));
-            } else {  // rotation by s + 32: the stored entry with its halves swapped
-                asm("v_xor_b32 %0, %0, %4\n\tv_xor_b32 %1, %1, %5\n\tv_xor_b32 %2, %2, %6\n\tv_xor_b32 %3, %3, %7"
-                    : "+v"(glo), "+v"(ghi), "+v"(hlo), "+v"(hhi) : "v"(e.y), "v"(e.x), "v"(e.w), "v"(e.z));
-            }
-#endif
             // the look-up of step t + 4 (rotation (TT + 5) mod 64), in flight while the next steps run
             const uint32_t s4 = (TT + 5u) & 31u;
             tv[t & 3u] = (t + 4u < 16u) ? rot_at(s4, off16(xe, xo, t + 4u)) : rot_at(s4, off16(xe_n, xo_n, t + 4u - 16u));
@@ -813,32 +798,6 @@ struct GlobalList {  // a region of the minimizer buffers in device memory (entr
         }
     }
 };
-// The fused kernel: the first LCAP entries stay in the wave's LDS (map_kernel's map phase reads them there: an ordinary read's list
-// never visits device memory), entries beyond go to the read's region as before (the caller then copies the LDS part behind them).
-template <uint32_t LCAP>
-struct LdsList {
-    unsigned long long h[LCAP];
-    uint32_t p[LCAP];
-};
-template <uint32_t LCAP>
-struct LdsThenGlobalList {
-    LdsList<LCAP> &L;
-    GlobalList G;
-    __device__ __forceinline__ void put(uint32_t dest, uint64_t hv, uint32_t p, uint32_t lp) const {
-        // (this experimental build has no second position in LDS: mq_index_new refuses seeding variant 16 under MQ_LDS_LIST)
-        // typed LDS stores: left generic, the compiler folds the two branches into ONE flat store through a selected pointer -- which
-        // counts on both the LDS and the memory counter and costs every later LDS wait a memory round trip
-        typedef __attribute__((address_space(3))) unsigned long long lds_u64;
-        typedef __attribute__((address_space(3))) uint32_t lds_u32;
-        if (dest < LCAP) {
-            *(lds_u64 *)(&L.h[dest]) = hv;
-            *(lds_u32 *)(&L.p[dest]) = p;
-        } else {
-            G.put(dest, hv, p, lp);
-        }
-    }
-};
-
 // Lists the tile's candidates in position order (lane = candidate), resolves their raw positions and appends them to the
 // sequence's minimizer list.  Returns the number of minimizers appended; sets inexact when a candidate fails the exact
 // 64-bit test (the sequence then goes to the general path, whose test is exact by construction).

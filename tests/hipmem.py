@@ -14,6 +14,7 @@ def hip():
         h.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         h.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         h.hipFree.argtypes = [C.c_void_p]
+        h.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
         h.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         h.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
         h.hipStreamSynchronize.argtypes = [C.c_void_p]
@@ -51,6 +52,12 @@ class DevBuf:
             self.ptr = None
 
     __del__ = free
+
+
+def memset(buf, byte):
+    """every byte of a DevBuf set to `byte` (blocking)"""
+    assert hip().hipMemset(buf.ptr, int(byte), buf.nbytes) == 0
+    assert hip().hipDeviceSynchronize() == 0
 
 
 def device_sync():

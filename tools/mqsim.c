@@ -197,6 +197,7 @@ typedef struct {
     uint64_t *t_start, *t_end; /* 0-based start, exclusive end on the contig */
     uint8_t *t_strand;    /* 0 '+', 1 '-' */
     volatile uint32_t *next;
+    uint32_t r0;          /* the job's read i is read r0 + i of the seeded set (a slice of it: mqsim_reads_range) */
 } read_job;
 
 static inline double gauss(uint64_t *s) {
@@ -216,7 +217,7 @@ static inline uint8_t comp(uint8_t b) {
 
 /* template placement for read r (pure function of seed and r) */
 static void place(const read_job *j, uint32_t r, uint32_t *ctg, uint64_t *start, uint64_t *tlen, uint8_t *strand, uint64_t *state) {
-    uint64_t s = j->seed ^ (0x9E3779B97F4A7C15ULL * ((uint64_t)r + 1));
+    uint64_t s = j->seed ^ (0x9E3779B97F4A7C15ULL * ((uint64_t)j->r0 + (uint64_t)r + 1));
     splitmix64(&s);
     double L = j->len_mean + j->len_sd * gauss(&s);
     if (L < (double)j->len_min) L = (double)j->len_min;
@@ -313,7 +314,45 @@ void mqsim_reads(const uint8_t *genome, const uint64_t *ctg_off, uint32_t n_ctg,
                  uint64_t *t_start, uint64_t *t_end, uint8_t *t_strand) {
     volatile uint32_t next = 0;
     read_job j = {genome, ctg_off, n_ctg, n_reads, len_mean, len_sd, len_min, len_max, err, f_sub, f_ins, seed,
-                  bases, (uint64_t *)offsets, read_len, t_ctg, t_start, t_end, t_strand, &next};
+                  bases, (uint64_t *)offsets, read_len, t_ctg, t_start, t_end, t_strand, &next, 0};
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t th[256];
+    for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, read_worker, &j);
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+}
+
+/* The same two passes for reads [r0, r0 + n_reads) of the seeded set (a read is a pure function of seed and its number): bench.py
+ * synthesises a batch slice by slice straight into device memory instead of holding 39 GB of capacity layout + 37 GB of bases. */
+void mqsim_read_caps_range(const uint64_t *ctg_off, uint32_t n_ctg, uint32_t r0, uint32_t n_reads, double len_mean, double len_sd,
+                           uint64_t len_min, uint64_t len_max, uint64_t seed, uint64_t *offsets) {
+    read_job j;
+    memset(&j, 0, sizeof(j));
+    j.ctg_off = ctg_off;
+    j.n_ctg = n_ctg;
+    j.n_reads = n_reads;
+    j.len_mean = len_mean;
+    j.len_sd = len_sd;
+    j.len_min = len_min;
+    j.len_max = len_max;
+    j.seed = seed;
+    j.r0 = r0;
+    offsets[0] = 0;
+    for (uint32_t r = 0; r < n_reads; r++) {
+        uint32_t c;
+        uint64_t st, tl, s;
+        uint8_t strand;
+        place(&j, r, &c, &st, &tl, &strand, &s);
+        offsets[r + 1] = offsets[r] + tl + tl / 16 + 64;
+    }
+}
+void mqsim_reads_range(const uint8_t *genome, const uint64_t *ctg_off, uint32_t n_ctg, uint32_t r0, uint32_t n_reads, double len_mean,
+                       double len_sd, uint64_t len_min, uint64_t len_max, double err, double f_sub, double f_ins, uint64_t seed,
+                       int threads, uint8_t *bases, const uint64_t *offsets, uint64_t *read_len, uint32_t *t_ctg,
+                       uint64_t *t_start, uint64_t *t_end, uint8_t *t_strand) {
+    volatile uint32_t next = 0;
+    read_job j = {genome, ctg_off, n_ctg, n_reads, len_mean, len_sd, len_min, len_max, err, f_sub, f_ins, seed,
+                  bases, (uint64_t *)offsets, read_len, t_ctg, t_start, t_end, t_strand, &next, r0};
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;
     pthread_t th[256];

@@ -37,6 +37,8 @@ def lib():
         L.mqsim_read_caps.argtypes = [vp, u32, u32, dbl, dbl, u64, u64, u64, vp]
         L.mqsim_reads.argtypes = [vp, vp, u32, u32, dbl, dbl, u64, u64, dbl, dbl, dbl, u64, C.c_int, vp, vp, vp, vp, vp, vp, vp]
         L.mqsim_compact.argtypes = [vp, vp, vp, u32, vp, vp]
+        L.mqsim_read_caps_range.argtypes = [vp, u32, u32, u32, dbl, dbl, u64, u64, u64, vp]
+        L.mqsim_reads_range.argtypes = [vp, vp, u32, u32, u32, dbl, dbl, u64, u64, dbl, dbl, dbl, u64, C.c_int, vp, vp, vp, vp, vp, vp, vp]
         L.mqsim_write_fastx.restype = u64
         L.mqsim_write_fastx.argtypes = [C.c_char_p, vp, vp, u32, C.c_int, C.c_int]
         _lib = L
@@ -116,6 +118,40 @@ def make_reads(genome, ctg_off, n_reads, seed=1, len_mean=24000.0, len_sd=2300.0
     offsets = np.zeros(n_reads + 1, dtype=np.uint64)
     lib().mqsim_compact(_p(tmp), _p(caps), _p(rl), n_reads, _p(bases), _p(offsets))
     return dict(bases=bases, offsets=offsets, ctg=t_ctg, start=t_start, end=t_end, strand=t_strand)
+
+
+def read_slices(genome, ctg_off, n_reads, seed=1, slice_reads=65536, len_mean=24000.0, len_sd=2300.0, len_min=100, len_max=25000,
+                err=0.01, f_sub=0.10, f_ins=0.60, threads=8, buffers=None, first_read=0):
+    """The reads of make_reads(genome, ctg_off, n_reads, seed, ...) slice by slice (a read is a pure function of the seed and its number):
+    yields (r0, r1, bases, offsets, truth) per slice of <= slice_reads reads -- bases: the slice's reads back to back (a view of a work
+    buffer that the slice after the next reuses), offsets: r1 - r0 + 1 slice-local uint64, truth: dict(ctg, start, end, strand).
+    Host memory: two work buffers of one slice's capacity (65,536 HiFi reads: 1.7 GB each) instead of the batch twice over.
+    buffers: a callable nbytes -> uint8 array (e.g. page-locked memory) for the two work buffers.
+    first_read: the slices cover reads [first_read, first_read + n_reads) of the seeded set (r0, r1 count from first_read)."""
+    ctg_off = np.ascontiguousarray(ctg_off, dtype=np.uint64)
+    n_ctg = ctg_off.size - 1
+    alloc = buffers or (lambda nbytes: np.empty(nbytes, dtype=np.uint8))
+    cap_max = int(slice_reads * (len_max + len_max // 16 + 64))
+    work = [None, None]
+    for k, r0 in enumerate(range(0, n_reads, slice_reads)):
+        r1 = min(n_reads, r0 + slice_reads)
+        m = r1 - r0
+        caps = np.zeros(m + 1, dtype=np.uint64)
+        lib().mqsim_read_caps_range(_p(ctg_off), n_ctg, first_read + r0, m, len_mean, len_sd, len_min, len_max, seed, _p(caps))
+        if work[k & 1] is None:
+            work[k & 1] = alloc(cap_max)
+        tmp = work[k & 1]
+        assert int(caps[-1]) <= tmp.size
+        rl = np.zeros(m, dtype=np.uint64)
+        t_ctg = np.zeros(m, dtype=np.uint32)
+        t_start = np.zeros(m, dtype=np.uint64)
+        t_end = np.zeros(m, dtype=np.uint64)
+        t_strand = np.zeros(m, dtype=np.uint8)
+        lib().mqsim_reads_range(_p(genome), _p(ctg_off), n_ctg, first_read + r0, m, len_mean, len_sd, len_min, len_max, err, f_sub, f_ins,
+                                seed, threads, _p(tmp), _p(caps), _p(rl), _p(t_ctg), _p(t_start), _p(t_end), _p(t_strand))
+        offsets = np.zeros(m + 1, dtype=np.uint64)
+        lib().mqsim_compact(_p(tmp), _p(caps), _p(rl), m, _p(tmp), _p(offsets))  # in place: a read only ever moves towards the front (memmove)
+        yield r0, r1, tmp[:int(offsets[-1])], offsets, dict(ctg=t_ctg, start=t_start, end=t_end, strand=t_strand)
 
 
 def write_fastx(path, bases, offsets, n_reads, fastq=False, threads=8):
