@@ -41,10 +41,11 @@ def parse():
                     "(0.8 = maize-like stress: most k-min-mers are tombstoned, lookups miss, Matches are short)")
     ap.add_argument("--tandem-frac", type=float, default=0.01)
     ap.add_argument("--repeat-div", type=float, default=0.01, help="per-base divergence of the planted copies")
-    ap.add_argument("--genome-preset", choices=("planted-repeats", "human-like"), default="planted-repeats",
+    ap.add_argument("--genome-preset", choices=("planted-repeats", "human-like", "maize-like"), default="planted-repeats",
                     help="planted-repeats (default, the BASELINE stand-in of rounds 1-3): --repeat-frac / --tandem-frac / --repeat-div; human-like: "
                          "tools/sim.py HUMAN_LIKE (6 %% satellite arrays, 5 %% segmental duplications, young interspersed copies) -- reads from "
-                         "inside satellites and recent duplications do not map uniquely, as on a real genome")
+                         "inside satellites and recent duplications do not map uniquely, as on a real genome; maize-like: the maize-B73-shaped "
+                         "genome of the `configs.maize_like` leg (BASELINE config 5) as the step's workload")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default, the BASELINE metric): every rank maps its own HBM-resident batch of --reads reads; strong: ONE fixed "
                          "read set of --reads reads in host memory is dealt to the ranks (mapquik_amd.shard) and mapped through the "
@@ -313,7 +314,8 @@ def records_written(torch, d_out, n):
     return int(((st >= 0) & (st <= 2)).sum().item())
 
 
-def kernel_leg(mq, sim, O, torch, dev, local_rank, P, po, genome, ctg_off, ctg_names, B, steps, warmup, ncpu, sample_reads, workload, n_reads=None, variant=0):
+def kernel_leg(mq, sim, O, torch, dev, local_rank, P, po, genome, ctg_off, ctg_names, B, steps, warmup, ncpu, sample_reads, workload, n_reads=None, variant=0,
+               same_as=None):
     """One kernel-only leg of another configuration: index on the GPU, the batch resident in HBM, `steps` timed launches of
     map_kernel on a poisoned result buffer, mapeval counts over the batch, the oracle's columns on a sample."""
     ix, _, n_unique, _, t_build = build_index_device(mq, torch, dev, local_rank, P, genome, ctg_off, ctg_names)
@@ -347,7 +349,8 @@ def kernel_leg(mq, sim, O, torch, dev, local_rank, P, po, genome, ctg_off, ctg_n
     st = ix.stats()
     ix.close()
     del d_out
-    return dict(workload=workload, value=round(total_bases / (ms * 1e-3) / 1e9, 3), unit="Gbases/s", ms_per_launch=round(ms, 4), steps=steps,
+    extra = {} if same_as is None else {"hits_byte_identical_to_the_step": bool(hits.tobytes() == same_as[:n].tobytes())}
+    return dict(extra, workload=workload, value=round(total_bases / (ms * 1e-3) / 1e9, 3), unit="Gbases/s", ms_per_launch=round(ms, 4), steps=steps,
                 reads_per_step=n, bases_per_step=total_bases, records_written=n_written, kminmers_per_step=int(hits["n_kminmers"].astype(np.int64).sum()),
                 mapped_frac=round(n_m / max(n, 1), 4), q60=n_q60, q60_wrong=n_q60_wrong, overflow_reads=int((hits["status"] == 2).sum()), reads_first=n_first,
                 general_path_reads=int(n_general), index_unique_kminmers=int(n_unique), index_keys=int(st["n_keys"]), index_build_s=round(t_build, 3),
@@ -480,29 +483,6 @@ def shared_genome(make, dist, world, rank, tag):
     return g, off, names
 
 
-def fresh_table_alloc_ms(nbytes, reps=3):
-    """What allocating and clearing `nbytes` of FRESH device memory costs: hipMalloc + hipMemset + synchronize + hipFree straight on
-    the HIP runtime (torch's caching allocator hands back recycled blocks in a few ms or fresh ones in half a second, at its own
-    discretion: not a measurement).  Median, min, max over `reps`."""
-    import ctypes as C
-    h = C.CDLL("libamdhip64.so")
-    h.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-    h.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
-    h.hipFree.argtypes = [C.c_void_p]
-    ts = []
-    for _ in range(reps):
-        p = C.c_void_p()
-        h.hipDeviceSynchronize()
-        t0 = time.perf_counter()
-        if h.hipMalloc(C.byref(p), nbytes) != 0:
-            raise MemoryError("hipMalloc(%d)" % nbytes)
-        h.hipMemset(p, 0, nbytes)
-        h.hipDeviceSynchronize()
-        ts.append((time.perf_counter() - t0) * 1e3)
-        h.hipFree(p)
-    return float(np.median(ts)), min(ts), max(ts)
-
-
 def fake_ranks():
     """Test hook (tests/test_bench_ranks.py): MQ_BENCH_FAKE_RANKS=1 runs every rank on device 0 with the gloo backend and the two
     all-reduces on CPU tensors, so that the world > 1 branch executes on a one-GPU box."""
@@ -594,7 +574,9 @@ def main():
 
     t0 = time.time() if not real_ref else t0
     # ---- Index::new with its capacity (src/index.rs:78-83): the table is allocated and cleared in the background from here on
-    lens = [int(x) for x in (real[1][1:] - real[1][:-1])] if real_ref else [max(40, int(x * args.genome_scale)) for x in sim.CHM13_LIKE]
+    MAIZE_KW = dict(family_frac=1.9, n_families=400, family_div=(0.005, 0.025), tandem_frac=0.02, n_runs=300)
+    lens = ([int(x) for x in (real[1][1:] - real[1][:-1])] if real_ref else
+            [max(40, int(x * args.genome_scale)) for x in (sim.MAIZE_LIKE if args.genome_preset == "maize-like" else sim.CHM13_LIKE)])
     ix0 = mq.Index(P, device=local_rank)
     ix0.reserve_table(expected_kminmers(sum(lens), P))
 
@@ -602,6 +584,8 @@ def main():
     if real_ref:
         genome, ctg_off, ctg_names = real
         del real
+    elif args.genome_preset == "maize-like":
+        genome, ctg_off, ctg_names = shared_genome(lambda: sim.make_genome(lens, seed=args.seed, threads=ncpu, **MAIZE_KW), dist, world, rank, "g")
     elif args.genome_preset == "human-like":
         genome, ctg_off, ctg_names = shared_genome(lambda: sim.make_genome(lens, seed=args.seed, threads=ncpu, **sim.HUMAN_LIKE), dist, world, rank, "g")
     else:
@@ -622,21 +606,20 @@ def main():
                             "DashMap::with_capacity, src/index.rs:83; fresh device memory costs ~30 ms per GB here); the contigs' upload (%.2f s) "
                             "is not in it" % (len(lens), st["table_bytes"] / 1e9, t_upload))
 
-    # what the table's allocation + clear costs by itself (the build above overlaps it with genome synthesis, which a real run does not
-    # have): the same number of bytes of FRESH device memory (hipMalloc + hipMemset + synchronize on the HIP runtime, not torch's caching
-    # allocator), timed alone, three times
-    if rank == 0 and world == 1:
-        try:
-            torch.cuda.synchronize()
-            t_med, t_lo, t_hi = fresh_table_alloc_ms(int(st["table_bytes"]))
-            index_build["table_alloc_and_clear_ms"] = round(t_med, 2)
-            index_build["table_alloc_and_clear_ms_min_max"] = [round(t_lo, 2), round(t_hi, 2)]
-            index_build["ms_with_table_allocation"] = round(t_index * 1e3 + t_med, 2)
-            index_build["table_note"] = ("%.1f GB of fresh device memory: hipMalloc + hipMemset + hipDeviceSynchronize straight on the HIP runtime, median of 3 "
-                                         "(min, max beside it): what a run that cannot hide the table's allocation behind other work adds to `ms`" % (st["table_bytes"] / 1e9))
-        except Exception as ex:  # noqa: BLE001
-            index_build["table_alloc_and_clear_ms"] = None
-            index_build["table_note"] = repr(ex)[:200]
+    # what the table's allocation + clear cost: timed by the library around its own hipMalloc + memset + synchronize (the reservation's
+    # background thread, mq_index_reserve: this process's first large allocation, i.e. FRESH device memory -- a second allocation of
+    # the same size, by torch or by hipMalloc, gets recycled memory in 3-8 ms or fresh memory in 0.5 s at the runtime's discretion and
+    # measures nothing).  The build above overlaps it with genome synthesis, which a real run does not have.
+    try:
+        t_tbl = ix.table_alloc_ms()
+        index_build["table_alloc_and_clear_ms"] = round(t_tbl, 2)
+        index_build["ms_with_table_allocation"] = round(t_index * 1e3 + t_tbl, 2)
+        index_build["table_note"] = ("%.1f GB: the library's own clock around hipMalloc + hipMemsetAsync + synchronize of THIS index's table on "
+                                     "mq_index_reserve's thread (the process's first large allocation: fresh device memory); `ms` holds only what was left of "
+                                     "it to wait for" % (st["table_bytes"] / 1e9))
+    except Exception as ex:  # noqa: BLE001
+        index_build["table_alloc_and_clear_ms"] = None
+        index_build["table_note"] = repr(ex)[:200]
 
     # ---- this rank's batch of reads, resident in HBM
     t0 = time.time()
@@ -955,19 +938,28 @@ def main():
             finally:
                 del Bl
 
+        def leg_fast_kh():
+            # the opt-in cheap tuple hash (MQ_FLAG_FAST_KH): never the headline; the PAF depends on the tuple hash through equality only
+            # (src/index.rs:100-104,118-126), so the records must be the step's, byte for byte -- and the oracle's at its own bit 64
+            Pf = mq.Params(k=args.k, l=args.l, density=args.density, fast_kh=True)
+            return kernel_leg(mq, sim, O, torch, dev, local_rank, Pf, O.params(k=args.k, l=args.l, density=args.density), genome, ctg_off, ctg_names, B, lsteps, lwarm,
+                              ncpu, args.config_sample_reads, "the step batch's genome and reads with MQ_FLAG_FAST_KH (an add-rotate-xor tuple hash in SipHash-1-3's place: "
+                              "~80 instead of ~250 instructions per k-min-mer at k = 5); k=%d l=%d d=%g" % (args.k, args.l, args.density), n_reads=nr, variant=64, same_as=hits)
+
         if args.k != 7:
             run_leg("k7", leg_k7)
         for v in (4, 6):
             run_leg("variant%d" % v, lambda v=v: leg_variant(v))
+        run_leg("fast_kh", leg_fast_kh)
         if args.genome_preset != "human-like":
             run_leg("human_like", lambda: leg_genome(lens, sim.HUMAN_LIKE, args.seed + 31,
                                                      "CHM13-sized genome (scale %.3g) with tools/sim.py HUMAN_LIKE repeats (6%% satellite arrays at 99.8%% identity, 5%% segmental "
                                                      "duplications, young interspersed copies) x pbsim-like HiFi reads; k=%d l=%d d=%g" % (args.genome_scale, args.k, args.l, args.density)))
-        run_leg("maize_like", lambda: leg_genome([max(40, int(x * args.genome_scale)) for x in sim.MAIZE_LIKE],
-                                                 dict(family_frac=1.9, n_families=400, family_div=(0.005, 0.025), tandem_frac=0.02, n_runs=300), args.seed + 57,
-                                                 "maize-B73-shaped genome (10 contigs, 2.13 Gbp x scale %.3g), ~85%% of the bases in 400 transposon-like families "
-                                                 "(copies 1-5%% apart), 300 runs of N, x pbsim-like HiFi reads (BASELINE config 5, experiments/simulate_maize.sh:9); "
-                                                 "k=%d l=%d d=%g" % (args.genome_scale, args.k, args.l, args.density)))
+        if args.genome_preset != "maize-like":
+            run_leg("maize_like", lambda: leg_genome([max(40, int(x * args.genome_scale)) for x in sim.MAIZE_LIKE], MAIZE_KW, args.seed + 57,
+                                                     "maize-B73-shaped genome (10 contigs, 2.13 Gbp x scale %.3g), ~85%% of the bases in 400 transposon-like families "
+                                                     "(copies 1-5%% apart), 300 runs of N, x pbsim-like HiFi reads (BASELINE config 5, experiments/simulate_maize.sh:9); "
+                                                     "k=%d l=%d d=%g" % (args.genome_scale, args.k, args.l, args.density)))
 
     # ---- end to end (rank 0, N=1): host buffers -> hits through three stream slots, and FASTA files -> PAF through the native driver
     e2e = None
@@ -1026,7 +1018,7 @@ def main():
         value = all_bases * args.steps / elapsed / 1e9
         line = {
             "metric": ("Gbases/s mapped (%s, k=%d l=%d d=%g)" % ("real reference" + (" + real reads" if args.reads_fastx else ", simulated HiFi reads"), args.k, args.l, args.density))
-                      if real_ref else "Gbases/s mapped (sim CHM13v2-like HiFi, k=%d l=%d d=%g)" % (args.k, args.l, args.density),
+                      if real_ref else "Gbases/s mapped (sim %s HiFi, k=%d l=%d d=%g)" % ("maize-B73-like" if args.genome_preset == "maize-like" else "CHM13v2-like", args.k, args.l, args.density),
             "value": round(value, 3),
             "unit": "Gbases/s",
             "n_gpus": world,
@@ -1046,10 +1038,11 @@ def main():
                                                                              "" if have_truth else " (no truth in the read names: q60_wrong is null)"))
                                 if args.reads_fastx else "pbsim-like HiFi reads simulated from it (mean 24 kb, 1% error)", args.k, args.l, args.density))
                             if real_ref else
-                            "CHM13v2.0-like synthetic genome (25 contigs, %.3f Gbp, scale %.3g, %s) "
+                            "%s synthetic genome (%d contigs, %.3f Gbp, scale %.3g, %s) "
                             "x pbsim-like HiFi reads (mean 24 kb, 1%% error); k=%d l=%d d=%g HPC"
-                            % (sum(lens) / 1e9, args.genome_scale,
+                            % ("maize-B73v5-like" if args.genome_preset == "maize-like" else "CHM13v2.0-like", len(lens), sum(lens) / 1e9, args.genome_scale,
                                "human-like repeats: 6% satellite arrays, 5% segmental duplications, young interspersed copies" if args.genome_preset == "human-like"
+                               else "maize-B73-shaped: 10 contigs, ~85% of the bases in 400 transposon-like families, 300 runs of N" if args.genome_preset == "maize-like"
                                else "%g%% planted repeats + %g%% tandem arrays" % (100 * args.repeat_frac, 100 * args.tandem_frac),
                                args.k, args.l, args.density),
                 "seeding_variant": args.seeding_variant,

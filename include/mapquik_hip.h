@@ -54,6 +54,12 @@ typedef struct mq_params {
 /* The reference upper-cases every sequence before the seam (to_ascii_uppercase, src/closures.rs:63,106).  With this flag the
  * kernels treat a-z as A-Z themselves, so a feeder can hand over raw FASTX bytes without touching them. */
 #define MQ_FLAG_FOLD_CASE 1u
+/* Opt-in: a cheap k-min-mer tuple hash in place of the reference's SipHash-1-3 (Rust DefaultHasher over the tuple, src/index.rs:100-104 via
+ * the crate's KminmerHash).  The PAF depends on that hash only through EQUALITY (index hit / miss / duplicate, src/index.rs:118-126,
+ * src/match.rs:39-58), so the lines are the same; mq_kminmer.hash is then NOT the reference's value.  An add-rotate-xor chain on two 64-bit
+ * words (one step per minimizer, six to finish; the test suite's CPU checker has the same function).  The index and the reads must be hashed
+ * alike: the flag belongs to the seeding parameters (a saved index carries it).  Default off; never used for a headline number. */
+#define MQ_FLAG_FAST_KH 2u
 /* Seeding variants (flags bits 8..13; default 0 = the frozen reading of DESIGN.md section 2).  The k-min-mer iterator is a third-party
  * crate (rust-seq2kminmers, Cargo.toml:30, no pinned revision; call sites src/mers.rs:22-27,53) that this image cannot build, so
  * six of its decisions are switchable: tools/check_against_upstream.sh finds, on a machine with cargo, which combination reproduces

@@ -19,6 +19,10 @@ int mq_last_map_path_counts(mq_index *idx, uint32_t *n_fast, uint32_t *n_general
  * how many of them were taken up first (n_first <= n_flagged: the front of the order holds 32,768). */
 int mq_last_map_order(mq_index *idx, uint32_t *n_flagged, uint32_t *n_first);
 
+/* What allocating and clearing the finalized index's table took (hipMalloc + memset + synchronize; milliseconds), wherever it ran: on
+ * mq_index_reserve's background thread beside the reference phase, or inside mq_index_finalize.  0 for a loaded or cloned index. */
+int mq_index_table_alloc_ms(mq_index *idx, float *ms);
+
 /* How many persistent waves map_kernel employs for a launch of n_reads reads (its grid x 8): wave w's first two work items are items w
  * and n_waves + w of the launch order, the atomic counter hands out the rest -- the tests place reads on exactly those borders. */
 int mq_map_launch_waves(mq_index *idx, uint32_t n_reads, uint32_t *n_waves);

@@ -13,6 +13,7 @@ from . import build as _build
 
 MQ_HIT_UNMAPPED, MQ_HIT_MAPPED, MQ_HIT_OVERFLOW = 0, 1, 2
 MQ_FLAG_FOLD_CASE = 1
+MQ_FLAG_FAST_KH = 2
 MQ_FLAG_SEED_VARIANT_SHIFT = 8
 MQ_ABI_VERSION = 4  # include/mapquik_hip.h
 
@@ -35,7 +36,7 @@ EXPORTS = ["mq_index_set_table_factor", "mq_ctx_submit_fastx", "mq_index_get_par
            "mq_index_add_ref", "mq_index_add_ref_device", "mq_index_finalize", "mq_index_get_stats", "mq_index_ref_info",
            "mq_map_batch", "mq_map_batch_device", "mq_map_reserve", "mq_kminmers_batch", "mq_index_lookup", "mq_format_paf",
            "mq_last_map_ms", "mq_last_map_path_counts", "mq_last_map_order", "mq_host_alloc", "mq_host_free", "mq_index_save", "mq_index_load", "mq_index_clone", "mq_map_probe_stats",
-           "mq_ctx_new", "mq_ctx_free", "mq_ctx_map_batch", "mq_ctx_submit", "mq_ctx_submit_spans", "mq_ctx_wait", "mq_ctx_reserve", "mq_ctx_map_batch_device", "mq_ctx_last_map_ms", "mq_probe_rate", "mq_last_stage_clocks", "mq_last_read_cycles", "mq_map_launch_waves"]
+           "mq_ctx_new", "mq_ctx_free", "mq_ctx_map_batch", "mq_ctx_submit", "mq_ctx_submit_spans", "mq_ctx_wait", "mq_ctx_reserve", "mq_ctx_map_batch_device", "mq_ctx_last_map_ms", "mq_probe_rate", "mq_last_stage_clocks", "mq_last_read_cycles", "mq_map_launch_waves", "mq_index_table_alloc_ms"]
 
 
 class MapquikError(RuntimeError):
@@ -47,12 +48,17 @@ class Params(C.Structure):
     _fields_ = [("k", C.c_uint32), ("l", C.c_uint32), ("density", C.c_double), ("use_hpc", C.c_uint32), ("c", C.c_uint32),
                 ("s", C.c_uint32), ("g", C.c_uint32), ("flags", C.c_uint32)]
 
-    def __init__(self, k=5, l=31, density=0.01, use_hpc=True, c=4, s=11, g=2000, fold_case=False, seeding_variant=0):
-        """seeding_variant: MQ_SEEDVAR_* bits (include/mapquik_hip.h), 0 = the frozen reading of the third-party k-min-mer iterator."""
+    def __init__(self, k=5, l=31, density=0.01, use_hpc=True, c=4, s=11, g=2000, fold_case=False, seeding_variant=0, fast_kh=False):
+        """seeding_variant: MQ_SEEDVAR_* bits (include/mapquik_hip.h), 0 = the frozen reading of the third-party k-min-mer iterator.
+        fast_kh: MQ_FLAG_FAST_KH, the opt-in cheap tuple hash (same PAF; mq_kminmer.hash is then not the reference's value)."""
         if not 0 <= int(seeding_variant) < 64:
             raise ValueError("seeding_variant must be 0..63")
         super().__init__(k, l, density, 1 if use_hpc else 0, c, s, g,
-                         (MQ_FLAG_FOLD_CASE if fold_case else 0) | (int(seeding_variant) << MQ_FLAG_SEED_VARIANT_SHIFT))
+                         (MQ_FLAG_FOLD_CASE if fold_case else 0) | (MQ_FLAG_FAST_KH if fast_kh else 0) | (int(seeding_variant) << MQ_FLAG_SEED_VARIANT_SHIFT))
+
+    @property
+    def fast_kh(self):
+        return bool(self.flags & MQ_FLAG_FAST_KH)
 
     @property
     def seeding_variant(self):
@@ -145,6 +151,7 @@ def load_library(path=None):
     L.mq_map_probe_stats.argtypes = [vp, vp, vp, u32, u64, vp, C.POINTER(u64), C.POINTER(u64)]
     if hasattr(L, "mq_map_launch_waves"):
         L.mq_map_launch_waves.argtypes = [vp, u32, C.POINTER(u32)]
+        L.mq_index_table_alloc_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.mq_index_save.argtypes = [vp, C.c_char_p]
     L.mq_index_clone.restype = vp
     L.mq_index_clone.argtypes = [vp, C.c_int]
@@ -397,6 +404,13 @@ class Index:
         if self._L.mq_last_map_path_counts(self._h, C.byref(a), C.byref(b)) != 0:
             raise _err(self._L, "mq_last_map_path_counts")
         return a.value, b.value
+
+    def table_alloc_ms(self):
+        """What allocating + clearing this index's table took (on mq_index_reserve's thread or inside finalize), in ms."""
+        ms = C.c_float()
+        if self._L.mq_index_table_alloc_ms(self._h, C.byref(ms)) != 0:
+            raise _err(self._L, "mq_index_table_alloc_ms")
+        return ms.value
 
     def launch_waves(self, n_reads):
         """Persistent waves map_kernel employs for a launch of n_reads reads (wave w owns work items w and n_waves + w)."""

@@ -106,6 +106,9 @@ def build_parser():
     ap.add_argument("--seeding-variant", type=int, default=0, dest="seeding_variant",
                     help="reading of the k-min-mer iterator's unpinned decisions, bits 1 2 4 8 16 32 (include/mapquik_hip.h); 0 = the frozen "
                          "reading (extension; tools/check_against_upstream.sh finds the value that reproduces the crate)")
+    ap.add_argument("--fast-kh", action="store_true", dest="fast_kh",
+                    help="cheap k-min-mer tuple hash instead of SipHash-1-3 (MQ_FLAG_FAST_KH): the same PAF -- the hash acts through equality only, "
+                         "src/index.rs:118-126 -- with fewer instructions; KminmerHash.hash is then not the reference's value (extension)")
     ap.add_argument("--unmapped", action="store_true",
                     help="also write <prefix>.unmapped.out with the ids of reads that got no PAF line (extension; the reference "
                          "has this writer commented out, src/closures.rs:38-43; feeds a second pass with other parameters)")
@@ -166,8 +169,10 @@ def main(argv=None):
         print(ln)
     if opt.seeding_variant:
         print("Seeding variant %d (reading of rust-seq2kminmers other than the frozen one; include/mapquik_hip.h)." % opt.seeding_variant)
+    if opt.fast_kh:
+        print("Fast k-min-mer tuple hash (MQ_FLAG_FAST_KH): same PAF, KminmerHash.hash is not the reference's value.")
     params = api.Params(k=st["k"], l=st["l"], density=st["density"], use_hpc=st["use_hpc"], c=st["c"], s=st["s"], g=st["g"],
-                        seeding_variant=opt.seeding_variant)
+                        seeding_variant=opt.seeding_variant, fast_kh=opt.fast_kh)
     paf = open(st["prefix"] + ".paf", "w")  # src/closures.rs:32
     unm = open(st["prefix"] + ".unmapped.out", "w") if opt.unmapped else None
 
@@ -175,9 +180,11 @@ def main(argv=None):
     if opt.load_index:
         index = api.Index.load(opt.load_index, device=opt.device)
         fp = index.get_params()
-        if (fp.k, fp.l, fp.density, fp.use_hpc, fp.seeding_variant) != (params.k, params.l, params.density, params.use_hpc, params.seeding_variant):
-            raise SystemExit("%s was built with -k %d -l %d -d %s%s --seeding-variant %d: run with the same seeding parameters"
-                             % (opt.load_index, fp.k, fp.l, rust_float(fp.density), "" if fp.use_hpc else " --nohpc", fp.seeding_variant))
+        if (fp.k, fp.l, fp.density, fp.use_hpc, fp.seeding_variant, fp.fast_kh) != (params.k, params.l, params.density, params.use_hpc, params.seeding_variant,
+                                                                                     params.fast_kh):
+            raise SystemExit("%s was built with -k %d -l %d -d %s%s --seeding-variant %d%s: run with the same seeding parameters"
+                             % (opt.load_index, fp.k, fp.l, rust_float(fp.density), "" if fp.use_hpc else " --nohpc", fp.seeding_variant,
+                                " --fast-kh" if fp.fast_kh else ""))
         index.set_map_params(params.c, params.s, params.g, bool(params.flags & api.MQ_FLAG_FOLD_CASE))
         ist = index.stats()
         print("Loaded index %s: %d references, %d k-min-mers." % (opt.load_index, ist["n_refs"], ist["n_kminmers"]))

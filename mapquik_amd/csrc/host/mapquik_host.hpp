@@ -31,6 +31,7 @@ struct Params {
     bool a = false;
     bool fold_case = false;  // extension: the kernels treat a-z as A-Z (the reference upper-cases on the host, src/closures.rs:63,106)
     unsigned seeding_variant = 0;  // extension: MQ_SEEDVAR_* bits (include/mapquik_hip.h); 0 = the frozen reading of rust-seq2kminmers
+    bool fast_kh = false;    // extension: MQ_FLAG_FAST_KH, the cheap tuple hash (same PAF; KminmerHash.hash is then not the reference's value)
     size_t c = 4;
     size_t s = 11;
     size_t g = 2000;
@@ -45,7 +46,7 @@ struct Params {
         p.c = (uint32_t)c;
         p.s = (uint32_t)s;
         p.g = (uint32_t)g;
-        p.flags = (fold_case ? MQ_FLAG_FOLD_CASE : 0u) | MQ_FLAG_SEED_VARIANT(seeding_variant);
+        p.flags = (fold_case ? MQ_FLAG_FOLD_CASE : 0u) | (fast_kh ? MQ_FLAG_FAST_KH : 0u) | MQ_FLAG_SEED_VARIANT(seeding_variant);
         return p;
     }
 };

@@ -100,6 +100,7 @@ struct Opt {
     int device = 0;
     int gpus = 1;
     int seeding_variant = 0;  // MQ_SEEDVAR_* bits (include/mapquik_hip.h)
+    bool fast_kh = false;     // MQ_FLAG_FAST_KH
     bool last_pass = true;  // no second pass follows this one
     int table_factor = 2;  // table slots per inserted k-min-mer: this driver is bound by its host side (mq_index_set_table_factor)
     std::string save_index, load_index;  // --save-index / --index: the on-disk index (the reference has none and re-indexes on every run)
@@ -116,7 +117,7 @@ static void usage() {
          "        --parallelfastx\n        --unmapped      (extension) also write <prefix>.unmapped.out\n\nOPTIONS:\n"
          "    -b <b>\n    -c, --chain <chain>\n    -d, --density <density>\n    -g, --gap-diff <gap-diff>\n    -k <k>\n    -l <l>\n"
          "    -p, --prefix <prefix>\n    -q <q>\n        --reference <reference>\n    -s, --seed <seed>\n        --threads <threads>\n"
-         "        --device <n>    (extension) first HIP device ordinal\n        --gpus <n>      (extension) shard read batches over n GPUs, index replicated\n        --batch-bases <n> (extension) raw input bytes per chunk\n        --table-factor <n> (extension) index table slots per k-min-mer (default 2 here: a file-fed run is host-bound; the library's default for HBM-resident batches is 8)\n        --save-index <file> (extension) write the finalized index (occupied slots only) for later runs\n        --index <file>  (extension) map against a saved index instead of indexing --reference (same -k -l -d --nohpc as it was built with)\n        --seeding-variant <v> (extension) reading of the k-min-mer iterator's unpinned decisions, bits 1 2 4 8 16 32 (include/mapquik_hip.h); 0 = frozen\n        --second-pass <k2,l2,d2> (extension) map the unmapped reads again with these parameters: <prefix>-k2-l2-d2.{fa,paf,unmapped.out}\n\nARGS:\n    <reads>");
+         "        --device <n>    (extension) first HIP device ordinal\n        --gpus <n>      (extension) shard read batches over n GPUs, index replicated\n        --batch-bases <n> (extension) raw input bytes per chunk\n        --table-factor <n> (extension) index table slots per k-min-mer (default 2 here: a file-fed run is host-bound; the library's default for HBM-resident batches is 8)\n        --save-index <file> (extension) write the finalized index (occupied slots only) for later runs\n        --index <file>  (extension) map against a saved index instead of indexing --reference (same -k -l -d --nohpc as it was built with)\n        --seeding-variant <v> (extension) reading of the k-min-mer iterator's unpinned decisions, bits 1 2 4 8 16 32 (include/mapquik_hip.h); 0 = frozen\n        --fast-kh       (extension) cheap k-min-mer tuple hash instead of SipHash-1-3: same PAF (the hash acts through equality only), fewer instructions\n        --second-pass <k2,l2,d2> (extension) map the unmapped reads again with these parameters: <prefix>-k2-l2-d2.{fa,paf,unmapped.out}\n\nARGS:\n    <reads>");
 }
 
 // the last two lines of a run (src/main.rs:270-271)
@@ -277,11 +278,13 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
             if (mq_index_get_params(loaded->handle(), &fp) != MQ_OK) throw Error("mq_index_get_params: " + last_error());
             const mq_params want = P.to_abi();
             if (fp.k != want.k || fp.l != want.l || fp.density != want.density || fp.use_hpc != want.use_hpc ||
-                (fp.flags & MQ_FLAG_SEED_VARIANT_MASK) != (want.flags & MQ_FLAG_SEED_VARIANT_MASK)) {
-                char msg[512];
-                snprintf(msg, sizeof(msg), "%s was built with -k %u -l %u -d %s%s --seeding-variant %u: run with the same seeding parameters (this run: -k %u -l %u -d %s%s --seeding-variant %u)",
+                (fp.flags & (MQ_FLAG_SEED_VARIANT_MASK | MQ_FLAG_FAST_KH)) != (want.flags & (MQ_FLAG_SEED_VARIANT_MASK | MQ_FLAG_FAST_KH))) {
+                char msg[640];
+                snprintf(msg, sizeof(msg), "%s was built with -k %u -l %u -d %s%s --seeding-variant %u%s: run with the same seeding parameters (this run: -k %u -l %u -d %s%s --seeding-variant %u%s)",
                          o.load_index.c_str(), fp.k, fp.l, rust_float(fp.density).c_str(), fp.use_hpc ? "" : " --nohpc", (fp.flags & MQ_FLAG_SEED_VARIANT_MASK) >> MQ_FLAG_SEED_VARIANT_SHIFT,
-                         want.k, want.l, rust_float(want.density).c_str(), want.use_hpc ? "" : " --nohpc", (want.flags & MQ_FLAG_SEED_VARIANT_MASK) >> MQ_FLAG_SEED_VARIANT_SHIFT);
+                         (fp.flags & MQ_FLAG_FAST_KH) ? " --fast-kh" : "",
+                         want.k, want.l, rust_float(want.density).c_str(), want.use_hpc ? "" : " --nohpc", (want.flags & MQ_FLAG_SEED_VARIANT_MASK) >> MQ_FLAG_SEED_VARIANT_SHIFT,
+                         (want.flags & MQ_FLAG_FAST_KH) ? " --fast-kh" : "");
                 throw Error(msg);
             }
             // the chaining thresholds and the case folding are this run's (they act at mapping time only)
@@ -815,6 +818,7 @@ int main(int argc, char **argv) {
             o.seeding_variant = atoi(val());
             if (o.seeding_variant < 0 || o.seeding_variant > 63) { fprintf(stderr, "error: --seeding-variant wants 0..63 (bits 1 2 4 8 16 32)\n"); return 2; }
         }
+        else if (a == "--fast-kh") o.fast_kh = true;
         else if (a == "--second-pass") {
             o.second = val();
             char *e1 = nullptr, *e2 = nullptr;
@@ -856,6 +860,8 @@ int main(int argc, char **argv) {
     P.fold_case = true;  // raw FASTX bytes go to the GPU: the kernels do the reference's to_ascii_uppercase
     P.seeding_variant = (unsigned)o.seeding_variant;
     if (o.seeding_variant) printf("Seeding variant %d (reading of rust-seq2kminmers other than the frozen one; include/mapquik_hip.h).\n", o.seeding_variant);
+    P.fast_kh = o.fast_kh;
+    if (o.fast_kh) puts("Fast k-min-mer tuple hash (MQ_FLAG_FAST_KH): same PAF, KminmerHash.hash is not the reference's value.");
     if (P.use_hpc) puts(P.use_simd ? "Using HPC ntHash, with SIMD" : "Using HPC ntHash, scalar");
     else puts(P.use_simd ? "Using regular ntHash (not HPC), with SIMD" : "Using regular ntHash (not HPC), scalar");
 

@@ -167,8 +167,9 @@ __global__ void ref_kminmers_kernel(const unsigned long long *__restrict__ dense
         bool rev;
         auto get = [&](uint32_t j) { return (uint64_t)dense_hash[i + j]; };
         const bool re = var_rev_eq<true>(P);
-        const uint64_t key = P.k == 5u ? kminmer_hash_fixed<5>(get, rev, re) : P.k == 7u ? kminmer_hash_fixed<7>(get, rev, re) : P.k == 8u ? kminmer_hash_fixed<8>(get, rev, re)
-                                                                                                                       : kminmer_hash(P.k, get, rev, re);
+        const bool fk = P.fast_kh != 0;
+        const uint64_t key = P.k == 5u ? kminmer_hash_fixed<5>(get, rev, re, fk) : P.k == 7u ? kminmer_hash_fixed<7>(get, rev, re, fk)
+                             : P.k == 8u ? kminmer_hash_fixed<8>(get, rev, re, fk) : kminmer_hash(P.k, get, rev, re, fk);
         RefKmm r;
         r.hash = key;
         r.start = dense_pos[i];

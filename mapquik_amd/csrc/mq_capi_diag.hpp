@@ -115,6 +115,16 @@ int mq_last_map_order(mq_index *idx, uint32_t *n_flagged, uint32_t *n_first) try
     return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
 }
 
+int mq_index_table_alloc_ms(mq_index *idx, float *ms) try {
+    if (!idx || !ms) return set_err(MQ_EINVAL, "bad arguments");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (!idx->finalized) return set_err(MQ_ESTATE, "index not finalized");
+    *ms = (float)idx->table_alloc_ms;
+    return MQ_OK;
+} catch (const std::exception &e) {
+    return set_err(MQ_EINVAL, std::string("unexpected exception: ") + e.what());
+}
+
 int mq_map_launch_waves(mq_index *idx, uint32_t n_reads, uint32_t *n_waves) try {
     if (!idx || !n_waves) return set_err(MQ_EINVAL, "bad arguments");
     int rc = use_device(idx);

@@ -13,7 +13,7 @@ mq_index *mq_index_new(const mq_params *params, int device) try {
         set_err(MQ_EINVAL, "unsupported k/l: need 1 <= l <= 64 and 1 <= k <= 32");
         return nullptr;
     }
-    if (params->flags & ~(MQ_FLAG_FOLD_CASE | MQ_FLAG_SEED_VARIANT_MASK)) {
+    if (params->flags & ~(MQ_FLAG_FOLD_CASE | MQ_FLAG_FAST_KH | MQ_FLAG_SEED_VARIANT_MASK)) {
         set_err(MQ_EINVAL, "undefined bits in mq_params.flags");
         return nullptr;
     }
@@ -48,6 +48,7 @@ mq_index *mq_index_new(const mq_params *params, int device) try {
     idx->dp.s = params->s;
     idx->dp.g = params->g;
     idx->dp.fold = (params->flags & MQ_FLAG_FOLD_CASE) ? 1u : 0u;
+    idx->dp.fast_kh = (params->flags & MQ_FLAG_FAST_KH) ? 1u : 0u;
     const char *cc = getenv("MQ_CHAIN_CHUNK");
     if (cc && atoi(cc) == 4) idx->chain_chunk = 4;
     const char *fg = getenv("MQ_FORCE_GENERAL");
@@ -362,11 +363,13 @@ int mq_index_reserve(mq_index *idx, uint64_t expected_kminmers) try {
     idx->rsv_thread = std::thread([idx, nslots, device]() {
         hipError_t e = hipSetDevice(device);
         void *p = nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         if (e == hipSuccess) e = hipMalloc(&p, table_bytes_of(nslots));
         hipStream_t st = nullptr;
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);  // not the null stream: the build's kernels run there
         if (e == hipSuccess) e = hipMemsetAsync(p, 0, table_bytes_of(nslots), st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
+        idx->rsv_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (st) hipStreamDestroy(st);
         if (e != hipSuccess && p) {
             hipFree(p);
@@ -405,6 +408,7 @@ int64_t mq_index_finalize(mq_index *idx) try {
         idx->table = idx->rsv_table;
         idx->nslots = nslots;
         idx->rsv_table = nullptr;
+        idx->table_alloc_ms = idx->rsv_ms;
     } else {
         if (idx->rsv_table) {
             HIPCHK(hipFree(idx->rsv_table));  // the estimate was off: the table is allocated now, at the size the reference needs

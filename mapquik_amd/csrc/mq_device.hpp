@@ -28,7 +28,7 @@
 namespace mq {
 
 constexpr int WAVE = 64;
-constexpr int RING = 256;    // HPC ring entries kept per wave (>= 64 + 64 + l)
+constexpr int RING = 512;    // HPC ring entries kept per wave: l - 1 <= 63 behind the block being hashed + 63 waiting + one write group of the walk (<= 256)
 constexpr int MZ_CAP = 160;  // < (64 + k - 1) carried + 64 appended, k <= 32
 constexpr int MAX_K = 32;
 constexpr int MAX_L = 64;
@@ -48,6 +48,7 @@ struct DevParams {
     //   32     kminmer_hash: an undecided (palindromic) tuple counts as reversed
     uint32_t variant;
     uint32_t keep_none;  // 1: no l-mer passes the density test at all
+    uint32_t fast_kh;    // 1: MQ_FLAG_FAST_KH -- the tuple hash is kh_fast() instead of SipHash-1-3 (index and reads alike)
 };
 // VAR = false: code built for the frozen reading only -- the variant bits are not even looked at, so map_kernel's instantiation for
 // variant 0 (every timed launch) carries none of the variants' code or registers; every other kernel is built with VAR = true and
@@ -308,15 +309,52 @@ struct Sip13 {
     }
 };
 
+// MQ_FLAG_FAST_KH: the opt-in cheap tuple hash (include/mapquik_hip.h).  Two 64-bit words on 32-bit halves:
+//   x ^= m; x += y; y = rotl(y, 13) ^ x; x = rotl(x, 32)      per minimizer (8 instructions: the rotation by 32 is a renaming)
+//   x ^= 0xff; six more steps with rotations 17 21 13 16 17 21; result x ^ y       -- ~80 instructions for k = 5 against SipHash-1-3's ~250
+struct KhFast {
+    U2 x, y;
+    __device__ __forceinline__ void init(uint32_t k) {
+        x = u2_of(0x736f6d6570736575ULL ^ (uint64_t)k);
+        y = u2_of(0x646f72616e646f6dULL);
+    }
+    template <uint32_t R>
+    __device__ __forceinline__ void step() {
+        add_rotl_u2<R>(x, y);  // x += y; y = rotl(y, R)
+        y = xor_u2(y, x);
+        x = swap_u2(x);
+    }
+    __device__ __forceinline__ void word(U2 m) {
+        x = xor_u2(x, m);
+        step<13>();
+    }
+    __device__ __forceinline__ uint64_t finish() {
+        x.lo ^= 0xffu;
+        step<17>();
+        step<21>();
+        step<13>();
+        step<16>();
+        step<17>();
+        step<21>();
+        return u64_of(xor_u2(x, y));
+    }
+};
+
 // canonical orientation + tuple hash of k minimizer hashes read through `get(i)`, i = 0..k-1 (forward order)
 // rev_eq (variant 32): a tuple equal to its reverse counts as reversed (`<=` instead of `<`)
 template <class Get>
-__device__ __forceinline__ uint64_t kminmer_hash(uint32_t k, Get get, bool &rev, bool rev_eq = false) {
+__device__ __forceinline__ uint64_t kminmer_hash(uint32_t k, Get get, bool &rev, bool rev_eq = false, bool fast_kh = false) {
     rev = rev_eq;
     for (uint32_t i = 0; i < k; ++i) {
         uint64_t a = get(i), b = get(k - 1 - i);
         if (b < a) { rev = true; break; }
         if (b > a) { rev = false; break; }
+    }
+    if (fast_kh) {
+        KhFast f;
+        f.init(k);
+        for (uint32_t i = 0; i < k; ++i) f.word(u2_of(rev ? get(k - 1 - i) : get(i)));
+        return f.finish();
     }
     Sip13 h;
     h.init();
@@ -330,7 +368,7 @@ __device__ __forceinline__ uint64_t kminmer_hash(uint32_t k, Get get, bool &rev,
 // a reverse tuple is the forward one with its pairs (i, k-1-i) exchanged under a lane mask -- three bit operations a half-word.
 // (`r ? w[k-1-i] : w[i]` compiled to a select of the INDEX and a chain of k-1 compare/select pairs per word.)
 template <uint32_t K, class Get>
-__device__ __forceinline__ uint64_t kminmer_hash_fixed(Get get, bool &rev, bool rev_eq = false) {
+__device__ __forceinline__ uint64_t kminmer_hash_fixed(Get get, bool &rev, bool rev_eq = false, bool fast_kh = false) {
     uint64_t w[K];
 #pragma unroll
     for (uint32_t i = 0; i < K; ++i) w[i] = get(i);
@@ -353,6 +391,13 @@ __device__ __forceinline__ uint64_t kminmer_hash_fixed(Get get, bool &rev, bool 
         m[i].hi ^= dhi;
         m[K - 1u - i].lo ^= dlo;
         m[K - 1u - i].hi ^= dhi;
+    }
+    if (fast_kh) {  // (wave-uniform: mq_params.flags)
+        KhFast f;
+        f.init(K);
+#pragma unroll
+        for (uint32_t i = 0; i < K; ++i) f.word(m[i]);
+        return f.finish();
     }
     Sip13 h;
     h.template init_after<(uint64_t)K>();
@@ -497,55 +542,103 @@ __device__ __forceinline__ void seed_segment(const uint8_t *__restrict__ seq, ui
         sink.on_minimizers(S, mz_count);
     };
 
-    // the bytes of the AHEAD blocks after the current one are on their way while it is processed (loaded where they are used, every one of the
-    // loop's iterations opened with a memory round trip: 375 of them for a 24-kb read, most of what such a read cost)
-    constexpr int AHEAD = 8;  // blocks in flight: two covered a third of the latency a wave sees with the chip busy
-    uint32_t nb[AHEAD];
+    // The walk: 1 KB per step, 16 bytes per lane.  What it looks for are run heads (a byte that differs from the byte in front of it; every byte
+    // without HPC) -- the hashing above is per 64 HEADS, not per 64 bytes.  Sequences that come here are what the fast seeder declined: gaps of
+    // the reference (N by the ten thousand), reads drawn from inside one (N with a sequencing error every ~140 bytes: two heads per error), the
+    // neighbourhood of a stray byte in otherwise clean sequence.  A lane compares its 16 bytes with the same bytes shifted by one (SWAR,
+    // exact non-zero-byte mask), the heads' places in the ring come from one wave scan, and each lane writes its own heads, lowest first.
+    // (Round 5 walked 64 bytes per step, one per lane: 375 steps for a 24-kb read from inside a gap against 24, each with its ballots, its
+    // scalar bookkeeping and a memory round trip: such a read cost 4-5 x an ordinary read, 0.7 % of the maize-like batch.)
+    constexpr int AHEAD = 2;  // steps in flight behind the current one
+    auto load16 = [&](uint64_t at) -> uint4 {
+        uint32_t n;
+        return load16_tail(seq, len, at, n);
+    };
+    uint4 nb[AHEAD + 1];
 #pragma unroll
-    for (int j = 0; j < AHEAD; ++j) nb[j] = a + 64u * (uint32_t)j + lane < len ? (uint32_t)seq[a + 64u * (uint32_t)j + lane] : 0u;
-    for (uint64_t pos = a;; pos += 64) {
-        const uint64_t i = pos + lane;
-        const bool inr = i < len;
-        uint32_t bt = nb[0];
+    for (int j = 0; j <= AHEAD; ++j) nb[j] = load16(a + 1024u * (uint32_t)j + 16u * lane);
+    for (uint64_t pos = a;; pos += 1024) {
+        const uint64_t at = pos + 16u * lane;
+        uint4 v = nb[0];
 #pragma unroll
-        for (int j = 0; j + 1 < AHEAD; ++j) nb[j] = nb[j + 1];
-        nb[AHEAD - 1] = i + 64u * AHEAD < len ? (uint32_t)seq[i + 64u * AHEAD] : 0u;
-        if (P.fold && bt - 'a' < 26u) bt -= 32u;
-        // the byte in front of every lane's: a DPP wave shift (lane 0 keeps `old` = the previous block's last byte)
-        const uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp((int)prev_byte, (int)bt, 0x138, 0xf, 0xf, false);  // wave_shr:1
-        const bool head = inr && (!P.use_hpc || bt != pb);
-        const uint64_t hm = __ballot(head);
-        if (head) {
-            const uint32_t hi = (hbase + mbcnt64(hm)) & (RING - 1);
-            S.ring_code[hi] = (uint8_t)base_code(bt);
-            S.ring_pos[hi] = (uint32_t)i;
+        for (int j = 0; j < AHEAD; ++j) nb[j] = nb[j + 1];
+        nb[AHEAD] = load16(at + 1024u * (uint32_t)(AHEAD + 1));
+        const uint32_t nin = at < len ? (len - at < 16u ? (uint32_t)(len - at) : 16u) : 0u;  // bytes of this lane inside the sequence
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        if (P.fold) {  // a-z -> A-Z, byte-wise: 0x20 in every byte of 0x61..0x7A (no carry leaves a byte: the tests run on the low seven bits)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t t = w[i] & 0x7F7F7F7Fu;
+                w[i] ^= (((t + 0x1F1F1F1Fu) & ~(t + 0x05050505u) & ~w[i]) & 0x80808080u) >> 2;
+            }
         }
-        s_elig += (uint32_t)__popcll(hm & __ballot(i < b));
-        hbase += (uint32_t)__popcll(hm);
-        const uint64_t inm = __ballot(inr);
-        prev_byte = rdlane(bt, 63 - __clzll((long long)inm));
-        wave_sync();
-        if (hbase - hproc >= 64u) {
-            process_block(64u);
-            hproc += 64u;
+        // the byte in front of the lane's first: the previous lane's last (DPP wave_shr:1; lane 0 keeps `old` = the byte in front of the step)
+        const uint32_t pl = (uint32_t)__builtin_amdgcn_update_dpp((int)(prev_byte & 0xFFu), (int)(w[3] >> 24), 0x138, 0xf, 0xf, false);
+        uint32_t hm = 0xFFFFu;  // bit j: byte j is a run head
+        if (P.use_hpc) {
+            const uint32_t sh[4] = {(w[0] << 8) | pl, __builtin_amdgcn_alignbyte(w[1], w[0], 3), __builtin_amdgcn_alignbyte(w[2], w[1], 3),
+                                    __builtin_amdgcn_alignbyte(w[3], w[2], 3)};
+            hm = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t d = w[i] ^ sh[i];
+                const uint32_t nz = ((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u) >> 7;  // 1 in every byte that differs from the byte in front of it
+                hm |= ((nz * 0x01020408u) >> 24 & 0xFu) << (4 * i);                             // those four bits side by side (no two partial products meet)
+            }
+            if (prev_byte > 0xFFu && at == 0) hm |= 1u;  // the sequence's first byte has nothing in front of it: a head whatever it is
         }
-        if (P.use_hpc && hm == 0ull && inm == ~0ull && __ballot(nb[0] != prev_byte || nb[1] != prev_byte) == 0ull && pos + 192u <= len && !(P.fold && prev_byte - 'A' < 26u)) {
-            // 192 bytes that all repeat the byte in front of them (a gap of the reference: tens of thousands of N; a long homopolymer run): jump to
-            // the block that holds the next different byte -- nothing in between is a run head.  (Only behind three such blocks: a READ from a
-            // gap carries the simulator's or the sequencer's errors every ~100 bytes, and the scan costs more than the two blocks it would skip.
-            // nb1 / nb2 are raw bytes: with folding a letter's two cases would have to be told apart -- left to the ordinary walk)
-            const uint64_t q = next_byte_differing(seq, len, pos + 64u, prev_byte, P.fold != 0);
-            const uint64_t skip = ((q - (pos + 64u)) >> 6) << 6;
+        hm &= nin >= 16u ? 0xFFFFu : ((1u << nin) - 1u);
+        const uint32_t cnt = (uint32_t)__popc(hm);
+        // heads with raw index < b (the windows that START there are this segment's)
+        const uint32_t eb = at >= b ? 0u : (b - at >= 16u ? 0xFFFFu : ((1u << (uint32_t)(b - at)) - 1u));
+        const uint32_t incl2 = wave_incl_scan_u32(cnt | ((uint32_t)__popc(hm & eb) << 16));  // both counts in one scan (<= 1024 each)
+        const uint32_t tot2 = rdlane(incl2, 63);
+        const uint32_t total = tot2 & 0xFFFFu;
+        s_elig += tot2 >> 16;
+        const uint32_t excl = (incl2 & 0xFFFFu) - cnt;
+        const bool full = pos + 1024u <= len;
+        const uint32_t last_byte = rdlane(w[3] >> 24, 63);  // (used only when the step lies inside the sequence)
+        // the heads go into the ring in groups the ring has room for: all at once unless the step is dense (then 16 lanes = 256 bytes at a time)
+        const uint32_t ngrp = total <= 256u ? 1u : 4u, glanes = 64u / ngrp;
+        const uint32_t hb0 = hbase;  // the step's first head goes here
+        for (uint32_t gi = 0; gi < ngrp; ++gi) {
+            const bool mine = lane / glanes == gi;
+            uint32_t m = mine ? hm : 0u;
+            uint32_t o = hb0 + excl;
+            while (__ballot(m != 0u)) {
+                if (m) {
+                    const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
+                    const uint32_t wd = bit < 8u ? (bit < 4u ? w[0] : w[1]) : (bit < 12u ? w[2] : w[3]);
+                    const uint32_t bt = (wd >> (8u * (bit & 3u))) & 0xFFu;
+                    S.ring_code[o & (RING - 1)] = (uint8_t)base_code(bt);
+                    S.ring_pos[o & (RING - 1)] = (uint32_t)(at + bit);
+                    ++o;
+                    m &= m - 1u;
+                }
+            }
+            hbase += ngrp == 1u ? total : (rdlane(incl2, (int)(glanes * (gi + 1u) - 1u)) & 0xFFFFu) - (gi ? (rdlane(incl2, (int)(glanes * gi - 1u)) & 0xFFFFu) : 0u);
+            wave_sync();
+            while (hbase - hproc >= 64u) {
+                process_block(64u);
+                hproc += 64u;
+            }
+        }
+        prev_byte = last_byte;
+        if (P.use_hpc && total == 0u && full && pos + 2048u <= len) {
+            // 1 KB that repeats the byte in front of it (a gap of the reference: tens of thousands of N; a very long homopolymer run): jump to the
+            // KB that holds the next different byte -- nothing in between is a run head (bytes are compared as the walk compares them: folded)
+            const uint64_t q = next_byte_differing(seq, len, pos + 1024u, prev_byte, P.fold != 0);
+            const uint64_t skip = ((q - (pos + 1024u)) >> 10) << 10;
             if (skip) {
                 pos += skip;
 #pragma unroll
-                for (int j = 0; j < AHEAD; ++j) nb[j] = pos + 64u * (uint32_t)(j + 1) + lane < len ? (uint32_t)seq[pos + 64u * (uint32_t)(j + 1) + lane] : 0u;
+                for (int j = 0; j <= AHEAD; ++j) nb[j] = load16(pos + 1024u * (uint32_t)(j + 1) + 16u * lane);
             }
         }
-        const bool end_of_seq = pos + 64 >= len;
+        const bool end_of_seq = pos + 1024 >= len;
         // behind b: done once the last eligible window is complete -- or at once when no run head lies in [a, b) at all (a segment inside
         // a long homopolymer run has nothing to seed; without this it would read on to the end of the run, however far that is)
-        const bool past = (pos + 64 >= b) && (s_elig == 0u || hbase >= s_elig + l - 1u);
+        const bool past = (pos + 1024 >= b) && (s_elig == 0u || hbase >= s_elig + l - 1u);
         if (end_of_seq || past) break;
     }
     if (hbase > hproc) process_block(hbase - hproc);
@@ -749,8 +842,17 @@ struct MapSink {
     // (records_to_scratch() then moves the LDS ones there too).  An ordinary read's records never leave LDS: no store's
     // acknowledgement is outstanding when the map phase ends.
     __device__ __forceinline__ void put_rec(uint32_t i, const MatchRec &m) const {
-        if (i < MAP_LDS_RECS) lds_rec[i] = m;
-        else if (i < cap_matches) scratch[i] = m;
+        // a typed LDS store: left generic, the compiler folds the two branches into ONE flat store through a selected pointer (26 flat stores
+        // in round 5's map_kernel) -- which goes the memory path's way even when it lands in LDS and counts on both wait counters
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) u32x4 lds_u4;
+        if (i < MAP_LDS_RECS) {
+            lds_u4 *d = (lds_u4 *)(&lds_rec[i]);
+            d[0] = u32x4{m.q_start, m.q_end, m.r_start, m.r_end};
+            d[1] = u32x4{m.count, m.ref, m.rc, m.done};
+        } else if (i < cap_matches) {
+            scratch[i] = m;
+        }
     }
     __device__ __forceinline__ void records_to_scratch() const {
         const uint32_t n = n_matches < MAP_LDS_RECS ? n_matches : MAP_LDS_RECS, i = lane_id();
@@ -767,9 +869,9 @@ struct MapSink {
         if (act) {
             auto get = [&](uint32_t i) { return (uint64_t)mzh[i0 + i]; };
             // 5: the reference's default k (src/main.rs: -k 5); 7: experiments/table1.sh:50; 8: example/run_ecoli.sh:26
-            const bool re = rev_eq;
-            key = P.k == 5u ? kminmer_hash_fixed<5>(get, rev, re) : P.k == 7u ? kminmer_hash_fixed<7>(get, rev, re) : P.k == 8u ? kminmer_hash_fixed<8>(get, rev, re)
-                                                                                                                  : kminmer_hash(P.k, get, rev, re);
+            const bool re = rev_eq, fk = P.fast_kh != 0;
+            key = P.k == 5u ? kminmer_hash_fixed<5>(get, rev, re, fk) : P.k == 7u ? kminmer_hash_fixed<7>(get, rev, re, fk)
+                  : P.k == 8u ? kminmer_hash_fixed<8>(get, rev, re, fk) : kminmer_hash(P.k, get, rev, re, fk);
             q_start = mzp[i0];
             q_end = mzp[i0 + P.k - 1] + P.l - 1u;
         }

@@ -133,6 +133,8 @@ struct mq_index {
     Bucket *rsv_table = nullptr;
     uint64_t rsv_nslots = 0;
     int rsv_err = 0;                // hipError_t of the background allocation
+    double table_alloc_ms = 0;      // what allocating + clearing the table that is in use took (hipMalloc + memset + synchronize), wherever it ran
+    double rsv_ms = 0;              // the same for the reservation (becomes table_alloc_ms when finalize adopts the reserved table)
 };
 
 // slots of the table for n inserted k-min-mers: MQ_TABLE_FACTOR (default 8: load <= 0.125) times n, rounded up to a power of two
@@ -227,8 +229,11 @@ static int alloc_table(mq_index *idx, uint64_t nslots) {
         idx->table = nullptr;
     }
     if (nslots < 2) nslots = 2;  // whole buckets
+    const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(hipMalloc((void **)&idx->table, table_bytes_of(nslots)));
     HIPCHK(hipMemset(idx->table, 0, table_bytes_of(nslots)));
+    HIPCHK(hipDeviceSynchronize());
+    idx->table_alloc_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     idx->nslots = nslots;
     return MQ_OK;
 }

@@ -175,19 +175,30 @@ __device__ __forceinline__ uint32_t seed_read_general(const SplitArgs &A, WaveLd
 // that start in the last l - 1 run heads of a stretch and reach past its end (seed_segment's min_last filter drops the ones the fast seeder
 // listed).  Same list as the general seeder's over the whole read (tests: MQ_FORCE_GENERAL=1 takes that one).
 constexpr uint32_t HYB_MIN_CLEAN = 2048;
-// bit i: the 64-byte block at p + 64 i (p a multiple of 64) lies inside the sequence and holds only A C G T (a c g t too when folding); 4 KB a call
-__device__ __forceinline__ uint64_t clean_blocks(const uint8_t *__restrict__ seq, uint64_t len, uint64_t p, bool fold) {
+// bit i: the 64-byte block at p + 64 i (p a multiple of 64) lies inside the sequence and holds only A C G T (a c g t too when folding); 4 KB a call.
+// The bytes come in as a CleanPiece (requested one call ahead: the scan's next 4 KB are on their way while these are looked at -- every call
+// used to open with a memory round trip of its own, six of them for a 24-kb read).
+struct CleanPiece {
+    uint4 v[4];
+};
+__device__ __forceinline__ void clean_request(const uint8_t *__restrict__ seq, uint64_t len, uint64_t p, CleanPiece &c) {
+    const uint64_t at = p + 64u * lane_id();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c.v[j] = make_uint4(0u, 0u, 0u, 0u);
+    if (at + 64u <= len) {  // (a block that is not wholly inside the sequence is never looked at, and never read)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c.v[j] = *reinterpret_cast<const uint4_unaligned *>(seq + at + 16 * j);
+    }
+}
+__device__ __forceinline__ uint64_t clean_blocks(const CleanPiece &c, uint64_t len, uint64_t p, bool fold) {
     const uint64_t at = p + 64u * lane_id();
     bool ok = false;
     if (at + 64u <= len) {
         const uint32_t fm = fold ? 0xDFDFDFDFu : 0xFFFFFFFFu;
-        uint4 v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const uint4_unaligned *>(seq + at + 16 * j);
         uint32_t all = 0x80808080u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            const uint32_t w[4] = {c.v[j].x, c.v[j].y, c.v[j].z, c.v[j].w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint32_t x = w[i] & fm;
@@ -209,8 +220,12 @@ __device__ __forceinline__ uint64_t clean_blocks(const uint8_t *__restrict__ seq
 __device__ __forceinline__ bool next_clean_stretch(const uint8_t *__restrict__ seq, uint64_t len, uint64_t from, bool fold, uint64_t &s, uint64_t &d) {
     constexpr uint64_t NONE = ~(uint64_t)0;
     uint64_t run_s = NONE;
+    CleanPiece cur, nxt;
+    if (from < len) clean_request(seq, len, from, cur);
     for (uint64_t p = from; p < len; p += 4096u) {
-        const uint64_t m = clean_blocks(seq, len, p, fold);
+        if (p + 4096u < len) clean_request(seq, len, p + 4096u, nxt);
+        const uint64_t m = clean_blocks(cur, len, p, fold);
+        cur = nxt;
         uint32_t bit = 0;
         while (bit < 64u) {
             if (run_s == NONE) {
@@ -262,19 +277,30 @@ __device__ __forceinline__ uint64_t heads_back(const uint8_t *__restrict__ seq, 
     }
     return a0;
 }
+// tacc (instrumented launch only, else nullptr): cycles spent [0] finding stretches, [1] in the fast seeder, [2] in the general seeder
 template <bool VAR = true>
 __device__ __forceinline__ uint32_t seed_read_hybrid(const SplitArgs &A, const SeedTables &T, SeedLds &SF, WaveLds &SG, const uint8_t *seq, uint64_t len,
-                                                     uint64_t &base, uint32_t cap, uint32_t &n_moved) {
+                                                     uint64_t &base, uint32_t cap, uint32_t &n_moved, unsigned long long *tacc = nullptr) {
     const DevParams &P = A.P;
-    auto pass = [&](uint64_t base_, uint32_t cap_) -> uint32_t {
+    auto pass = [&](uint64_t base_, uint32_t cap_) __attribute__((always_inline)) -> uint32_t {
         uint32_t n_out = 0;
+        unsigned long long t_mark = tacc ? __builtin_amdgcn_s_memtime() : 0ull;
+        auto charge = [&](int i) {
+            if (tacc) {
+                const unsigned long long now = __builtin_amdgcn_s_memtime();
+                tacc[i] += now - t_mark;
+                t_mark = now;
+            }
+        };
         auto general = [&](uint64_t a, uint64_t b, uint64_t min_last) {
+            charge(0);
             wave_sync();
             SoaListSink sink(A.mz_hash + base_ + n_out, A.mz_pos + base_ + n_out, (VAR && A.mz_last) ? A.mz_last + base_ + n_out : nullptr, cap_ > n_out ? cap_ - n_out : 0u);
             uint32_t mzc = 0;
             seed_segment<VAR>(seq, len, a, b, P, SG, sink, mzc, min_last);
             n_out += sink.written;
             wave_sync();
+            charge(2);
         };
         if (A.force_general || len < 16u || (len >> 32)) {  // the test hook; the scanner's precondition; beyond the fast seeder's range
             general(0, len, 0);
@@ -298,10 +324,12 @@ __device__ __forceinline__ uint32_t seed_read_hybrid(const SplitArgs &A, const S
             V.pos_add = (uint32_t)s;
             V.more_after = 0u;
             const uint32_t left = cap_ > n_out ? cap_ - n_out : 0u;
+            charge(0);
             const uint32_t c = seed_sequence_fast<0, true, VAR>(seq + s, (uint32_t)(d - s), P, T, SF, A.mz_hash + base_ + n_out, A.mz_pos + base_ + n_out, left, pre, false, V,
                                                                 A.mz_last ? A.mz_last + base_ + n_out : nullptr);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wave_sync();
+            charge(1);
             if (c == SD_NOT_FAST) {  // (a candidate on the bound: the general seeder's test is exact) the stretch joins the general segment
                 seg_a = s;
                 seg_min_last = 0;
@@ -312,16 +340,22 @@ __device__ __forceinline__ uint32_t seed_read_hybrid(const SplitArgs &A, const S
             }
         }
         if (seg_a < len && seg_min_last < len) general(seg_a, len, seg_min_last);
+        charge(0);
         return n_out;
     };
-    uint32_t cnt = pass(base, cap);
-    if (cnt > cap) {  // denser than its region: once more, into an exact-size pool region
-        if (pool_take(A, cnt, base)) {
-            pass(base, cnt);
-            n_moved++;
-        } else {
+    // ONE call site, so that the pass is inlined here: as a function of its own (two call sites) it received T, SF and SG as generic pointers
+    // and every LDS access of both seeders in it became a FLAT instruction (524 flat loads, 24 ds_ in round 5's code object) -- a declined read
+    // cost 3-4 x what its instructions should
+    uint32_t cnt = 0, cap_now = cap;
+    for (int attempt = 0;; ++attempt) {
+        cnt = pass(base, cap_now);
+        if (cnt <= cap_now || attempt == 1) break;
+        if (!pool_take(A, cnt, base)) {  // denser than its region: once more, into an exact-size pool region
             cnt = LIST_OVERFLOW;
+            break;
         }
+        cap_now = cnt;
+        n_moved++;
     }
     return cnt;
 }
@@ -636,19 +670,21 @@ __global__ __launch_bounds__(64 * MAP_WAVES, MQ_MAP_MIN_WAVES) void map_declined
         uint64_t base;
         uint32_t cap;
         list_region(A, o0 - o_base, len, r, base, cap);
-        const uint32_t cnt = seed_read_hybrid<VAR>(A, W.T, S.seed, S.general, A.bases + o0, len, base, cap, n_moved);
-        const unsigned long long t_seeded = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
+        unsigned long long tacc[3] = {0ull, 0ull, 0ull};
+        const uint32_t cnt = seed_read_hybrid<VAR>(A, W.T, S.seed, S.general, A.bases + o0, len, base, cap, n_moved, TIMING ? tacc : nullptr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list stores have reached L2
         wave_sync();
         mq_hit h;
         map_read<CH, TIMING, VAR>(A, S.map, scratch, r, len, cnt, base, t_steps, t_lookups, h);
         wave_sync();
         store_hit(A, r, h);
-        if (TIMING && lane == 0) {  // mq_last_read_cycles: this read's cycles here (seeding in the high half of the start word's place: see tools/read_tail.py)
+        if (TIMING && lane == 0) {  // mq_last_read_cycles: this read's cycles here; in the start word's place bit 63 and the seeding split in
+            // units of 256 cycles: stretch finder | fast seeder << 21 | general seeder << 42 (tools/read_tail.py)
             const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_read0;
             A.mz_count[r] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
-            A.mz_base[r] = t_real0;
-            (void)t_seeded;
+            auto u21 = [](unsigned long long c) { return (c >> 8) > 0x1FFFFFull ? 0x1FFFFFull : (c >> 8); };
+            A.mz_base[r] = (1ull << 63) | u21(tacc[0]) | (u21(tacc[1]) << 21) | (u21(tacc[2]) << 42);
+            (void)t_real0;
         }
     }
     if (lane == 0) {

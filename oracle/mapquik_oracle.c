@@ -83,6 +83,7 @@ uint64_t mqo_ntc64(const uint8_t *s, size_t i, size_t l) {
  *    8  D5   a minimizer's position = raw index of the LAST base of its first base's homopolymer run (frozen: the run head)
  *   16  D6   end = raw position of the last compressed base of the last minimizer's l-mer (frozen: pos[k-1] + l - 1, raw l)
  *   32  D8   rev = reversed tuple <= forward tuple (frozen: strict <; differs on palindromic tuples only)
+ *   64  --   NOT a reading of the crate: the product's opt-in cheap tuple hash (MQ_FLAG_FAST_KH) in SipHash's place, see mqo_tuple_hash_fast
  * The product has the same six switches (mq_params.flags bits 8..13, include/mapquik_hip.h): tests/ set a variant here and the same
  * value there and compare the two, variant by variant; everything else in the repository runs the frozen reading. */
 static int g_variant = 0;
@@ -174,9 +175,32 @@ uint64_t mqo_siphash(const uint8_t *msg, size_t len, uint64_t k0, uint64_t k1, i
 
 /* Decision D9: KH = DefaultHasher(SipHash-1-3, key 0) over `mers.hash(&mut h)` for a [u64] slice:
  * Rust writes the length prefix (usize, 8 bytes LE) and then the elements' bytes. */
+/* variant bit 64 (the product's MQ_FLAG_FAST_KH, include/mapquik_hip.h): a cheap tuple hash in SipHash's place.  The PAF depends on KH
+ * only through equality (index hit / miss / duplicate: src/index.rs:100-104,118-126), so any 64-bit tuple hash without collisions in
+ * practice gives the same lines; this one is an add-rotate-xor chain on two 64-bit words, one step per element and six to finish
+ * (avalanche 0.45-0.53 per output bit for every input bit, 32-bit halves collide at the birthday rate: profiles/r06_fast_kh.txt). */
+static inline uint64_t rotl64_(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+uint64_t mqo_tuple_hash_fast(const uint64_t *mers, size_t k) {
+    static const int R[6] = {17, 21, 13, 16, 17, 21};
+    uint64_t x = 0x736f6d6570736575ULL ^ (uint64_t)k, y = 0x646f72616e646f6dULL;
+    for (size_t i = 0; i < k; i++) {
+        x ^= mers[i];
+        x += y;
+        y = rotl64_(y, 13) ^ x;
+        x = rotl64_(x, 32);
+    }
+    x ^= 0xff;
+    for (int j = 0; j < 6; j++) {
+        x += y;
+        y = rotl64_(y, R[j]) ^ x;
+        x = rotl64_(x, 32);
+    }
+    return x ^ y;
+}
 uint64_t mqo_tuple_hash(const uint64_t *mers, size_t k) {
     uint8_t buf[8 * 65];
     if (k > 64) k = 64;
+    if (g_variant & 64) return mqo_tuple_hash_fast(mers, k);
     uint64_t n = (uint64_t)k;
     for (int j = 0; j < 8; j++) buf[j] = (uint8_t)(n >> (8 * j));
     for (size_t i = 0; i < k; i++)

@@ -119,7 +119,8 @@ void mqo_set_variant(int v);
 int mqo_get_variant(void);
 uint64_t mqo_density_bound(double density);                        /* (density * u64::MAX as f64) as u64 */
 uint64_t mqo_siphash(const uint8_t *msg, size_t len, uint64_t k0, uint64_t k1, int c_rounds, int d_rounds);
-uint64_t mqo_tuple_hash(const uint64_t *mers, size_t k);           /* Rust DefaultHasher over a [u64] slice */
+uint64_t mqo_tuple_hash(const uint64_t *mers, size_t k);           /* Rust DefaultHasher over a [u64] slice (variant bit 64: mqo_tuple_hash_fast) */
+uint64_t mqo_tuple_hash_fast(const uint64_t *mers, size_t k);      /* the product's MQ_FLAG_FAST_KH mixer (not the reference's hash value) */
 
 /* Both return the count; if out == NULL only count.  cap = capacity of out. */
 size_t mqo_minimizers(const uint8_t *seq, size_t len, const mqo_params *p, mqo_minimizer *out, size_t cap);

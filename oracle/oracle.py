@@ -66,6 +66,8 @@ def lib():
     L.mqo_siphash.argtypes = [C.c_char_p, sz, u64, u64, C.c_int, C.c_int]
     L.mqo_tuple_hash.restype = u64
     L.mqo_tuple_hash.argtypes = [vp, sz]
+    L.mqo_tuple_hash_fast.restype = u64
+    L.mqo_tuple_hash_fast.argtypes = [vp, sz]
     for f in (L.mqo_minimizers, L.mqo_minimizers_naive, L.mqo_kminmers):
         f.restype = sz
         f.argtypes = [vp, sz, PP, vp, sz]

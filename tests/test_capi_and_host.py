@@ -30,7 +30,7 @@ def test_seam_header_holds_no_diagnostics():
     include/mapquik_hip_diag.h.  Together they are everything the library exports under the mq_ prefix."""
     seam, diag = set(_declared_functions(("mapquik_hip.h",))), set(_declared_functions(("mapquik_hip_diag.h",)))
     assert not (seam & diag)
-    assert diag == {"mq_last_map_path_counts", "mq_map_probe_stats", "mq_probe_rate", "mq_last_stage_clocks", "mq_last_map_ms", "mq_ctx_last_map_ms", "mq_last_read_cycles", "mq_last_map_order", "mq_map_launch_waves"}
+    assert diag == {"mq_last_map_path_counts", "mq_map_probe_stats", "mq_probe_rate", "mq_last_stage_clocks", "mq_last_map_ms", "mq_ctx_last_map_ms", "mq_last_read_cycles", "mq_last_map_order", "mq_map_launch_waves", "mq_index_table_alloc_ms"}
     integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for name in sorted(seam):
         assert name in integ, "INTEGRATION.md does not bind %s" % name

@@ -610,6 +610,16 @@ def test_fuzz_params_and_sequences(mq, oracle, simlib):
             else:
                 seg = bases[a:min(hi, a + 2000)]
                 seg[:] = np.where(np.arange(seg.size) % 2 == 0, ord("A"), ord("C"))
+        for i in range(3, 40, 7):  # reads from INSIDE a gap of the reference: N with an error every so often (substituted or inserted bases),
+            lo, hi = int(offs[i]), int(offs[i + 1])  # whole or from some point on, N or n -- the general seeder's walk finds two run heads per error
+            if hi - lo < 20:
+                continue
+            a = lo if (i // 7) % 2 == 0 else lo + int(rng.integers(0, hi - lo - 10))
+            seg = bases[a:hi]
+            seg[:] = ord("N") if (i // 7) % 3 else ord("n")
+            nerr = int(rng.integers(0, max(2, seg.size // int(rng.choice([30, 140, 1000])))))
+            at = rng.integers(0, seg.size, size=nerr)
+            seg[at] = rng.choice(np.frombuffer(b"ACGTacgtNR", dtype=np.uint8), size=nerr)
         reads2 = dict(reads)
         reads2["bases"] = bases
         # every third case under another reading of the third-party k-min-mer iterator (mq_params.flags bits 8..13 = the oracle's

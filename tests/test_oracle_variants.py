@@ -136,3 +136,61 @@ def test_the_twelve_combinations_of_the_upstream_check_are_distinct_readings(O):
     # the hash width and the two position conventions each give their own tuples
     assert sigs[0] == sigs[1] == sigs[32]
     assert len({sigs[0], sigs[4], sigs[8], sigs[16], sigs[24]}) == 5
+
+
+def _kh_fast_py(m):
+    """mqo_tuple_hash_fast restated: the product's MQ_FLAG_FAST_KH mixer (include/mapquik_hip.h)"""
+    M = (1 << 64) - 1
+    rotl = lambda x, r: ((x << r) | (x >> (64 - r))) & M
+    x, y = 0x736f6d6570736575 ^ len(m), 0x646f72616e646f6d
+    for w in m:
+        x ^= w
+        x = (x + y) & M
+        y = rotl(y, 13) ^ x
+        x = rotl(x, 32)
+    x ^= 0xFF
+    for r in (17, 21, 13, 16, 17, 21):
+        x = (x + y) & M
+        y = rotl(y, r) ^ x
+        x = rotl(x, 32)
+    return x ^ y
+
+
+def test_bit64_fast_tuple_hash_changes_the_hash_and_nothing_else(O):
+    """Variant bit 64 is the product's opt-in MQ_FLAG_FAST_KH, not a reading of the crate: the same tuples (positions, offsets, strands), another
+    hash value, the same partition of the tuples by hash -- hence the same index hits and the same PAF (the reference uses the hash through
+    equality only: src/index.rs:100-104,118-126)."""
+    import ctypes as C
+    rng = random.Random(3)
+    for k in (1, 2, 5, 7, 8, 13, 32):
+        m = [rng.getrandbits(58) for _ in range(k)]
+        arr = (C.c_uint64 * k)(*m)
+        assert int(O.lib().mqo_tuple_hash_fast(arr, k)) == _kh_fast_py(m)
+        O.lib().mqo_set_variant(64)
+        assert int(O.lib().mqo_tuple_hash(arr, k)) == _kh_fast_py(m)
+        O.lib().mqo_set_variant(0)
+        assert int(O.lib().mqo_tuple_hash(arr, k)) != _kh_fast_py(m)
+    seq = _rand_seq(60000, 9, runs=True) + _rand_seq(3000, 10, runs=True) * 3  # repeats: equal tuples exist
+    p = O.params()
+    t0, t1 = _tuples(O, seq, p, 0), _tuples(O, seq, p, 64)
+    assert len(t0) == len(t1) > 300 and [x[:4] for x in t0] == [x[:4] for x in t1]
+    assert sum(1 for a, b in zip(t0, t1) if a[4] != b[4]) == len(t0)
+    g0, g1 = {}, {}
+    for i, (a, b) in enumerate(zip(t0, t1)):
+        g0.setdefault(a[4], []).append(i)
+        g1.setdefault(b[4], []).append(i)
+    assert sorted(g0.values()) == sorted(g1.values()) and any(len(v) > 1 for v in g0.values())
+    # and the mapped result: every PAF column equal
+    ref = _rand_seq(200000, 21, runs=True)
+    reads = [ref[a:a + 9000] for a in range(1000, 180000, 7000)]
+    outs = []
+    for v in (0, 64):
+        O.lib().mqo_set_variant(v)
+        ox = O.Index()
+        ox.add_ref(0, "chr1", ref, p)
+        bases = np.frombuffer(b"".join(reads), dtype=np.uint8)
+        offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(r) for r in reads])
+        outs.append(ox.map_batch(bases, offs, p, threads=2).tobytes())
+        O.lib().mqo_set_variant(0)
+    assert outs[0] == outs[1]

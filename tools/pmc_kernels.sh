@@ -24,7 +24,7 @@ for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         kn = re.sub(r"\(.*", "", row.get("Kernel_Name", ""))
         kn = re.sub(r"^void ", "", kn)
-        if not any(t in kn for t in ("map_kernel", "seed_reads", "map_lists", "seed_general")) or "probe_rate" in kn:
+        if not any(t in kn for t in ("map_kernel", "map_declined", "order_reads", "seed_reads", "map_lists", "seed_general")) or "probe_rate" in kn:
             continue
         agg[(kn, row["Counter_Name"])][0] += float(row["Counter_Value"]); agg[(kn, row["Counter_Name"])][1] += 1
 with open(out + "/summary.txt", "w") as fo:

@@ -52,6 +52,17 @@ def main():
     torch.cuda.synchronize()
     print("instrumented launch: %.3f ms" % ix.last_map_ms())
     cyc, start = ix.last_read_cycles(n)
+    # reads map_declined_kernel took: bit 63 of the start word, and the seeding split (units of 256 cycles) in its place
+    declined = (start >> np.uint64(63)) != 0
+    if declined.any():
+        sv = start[declined]
+        find, fast, gen = [((sv >> np.uint64(sh)) & np.uint64(0x1FFFFF)).astype(np.float64) * 256 for sh in (0, 21, 42)]
+        cd = cyc[declined].astype(np.float64)
+        print("declined reads (map_declined_kernel): %d; cycles per read: mean %.0f median %.0f; of which stretch finder %.0f, fast seeder on clean stretches %.0f, "
+              "general seeder %.0f, the rest (map phase, list stores) %.0f" % (int(declined.sum()), cd.mean(), np.median(cd), find.mean(), fast.mean(), gen.mean(),
+                                                                              (cd - find - fast - gen).mean()))
+        start = start.copy()
+        start[declined] = np.median(start[~declined]) if (~declined).any() else 0  # (they carry no start tick)
     hits = np.frombuffer(out.cpu().numpy().tobytes(), dtype=mq.hit_dtype)
     c = cyc.astype(np.float64)
     print("cycles per read: mean %.0f  median %.0f  p99 %.0f  p99.9 %.0f  max %.0f  (sum %.4g)" % (c.mean(), np.median(c), np.percentile(c, 99), np.percentile(c, 99.9), c.max(), c.sum()))
