@@ -86,6 +86,29 @@ def test_bench_gpus_2_typed_as_the_driver_types_it():
     assert set(out[2]) - set(out[1]) <= {"per_rank_gbases_s"}, set(out[2]) ^ set(out[1])
 
 
+def test_bench_gpus_8_on_one_device_is_affordable():
+    """`python bench.py --gpus 8` as the driver's 8-GPU node will run it, here with every rank on the one device (MQ_BENCH_FAKE_RANKS=1) and
+    196,608 reads per rank: it has to finish, print ONE line with n_gpus 8, and stay small on the host -- the genome is synthesised once (rank 0,
+    into /dev/shm) and mapped by the others, a rank's reads are synthesised slice by slice straight into its device batch and kept nowhere else.
+    Bound: 12 GB of peak RSS per rank (the 3.1-GB genome mapping, two 0.9-GB page-locked slice buffers, the runtimes); before round 6 a rank
+    held the genome, a 39-GB capacity layout and the 37-GB batch at the default step."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(MQ_BENCH_FAKE_RANKS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--reads", "196608", "--steps", "2", "--warmup", "1"], capture_output=True, text=True,
+                       timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak" and j["value"] > 0 and j["overflow_reads"] == 0
+    assert len(j["per_rank_gbases_s"]) == 8 and len(j["per_rank_setup_s"]) == 8 and len(j["per_rank_peak_rss_gb"]) == 8
+    assert max(j["per_rank_peak_rss_gb"]) < 12.0, j["per_rank_peak_rss_gb"]
+    assert j["records_written"] == j["config"]["reads_per_step_per_gpu"] == 196608
+    assert j["config"]["index_table_bytes"] > 16 * 10**9  # the CHM13-sized index, replicated per rank
+    assert j["cpu_baseline"] is None and j["configs"] is None and j["end_to_end"] is None  # rank 0 at N = 1 only
+    print("bench.py --gpus 8 on one device: per-rank setup %s s, peak RSS %s GB" % (j["per_rank_setup_s"], j["per_rank_peak_rss_gb"]))
+
+
 def test_bench_more_ranks_than_gpus_fails_fast():
     """Without the fake-rank hook, --gpus 2 on a one-GPU box must say so at once (every rank, before any work), not hang in RCCL."""
     import torch

@@ -35,3 +35,71 @@ def test_overlap_ratio_edges():
     assert pc.overlap_ratio(0, 100, 50, 150) == 50 / 150
     assert pc.overlap_ratio(200, 100, 150, 250) == 50 / 150  # reversed coordinates
     assert pc.overlap_ratio(5, 5, 5, 5) == 1.0
+
+
+def _fasta(tmp_path, seed=5):
+    import random
+    rng = random.Random(seed)
+
+    def seq(n):
+        out = []
+        while len(out) < n:
+            out.extend(rng.choice("ACGT") * rng.choice([1, 1, 2, 3, 5]))
+        return "".join(out[:n])
+    rep = seq(4000)
+    recs = [("chrA", seq(60000) + rep + seq(20000) + rep), ("chrB some text", seq(30000) + "N" * 500 + seq(30000) + rep), ("tiny", "ACGT")]
+    p = tmp_path / "ref.fa"
+    with open(p, "w") as f:
+        for n, s in recs:
+            f.write(">" + n + "\n")
+            for i in range(0, len(s), 70):
+                f.write(s[i:i + 70] + "\n")
+    return str(p)
+
+
+def _dump(fa, variant, extra=()):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dump_kminmers.py"), fa, "--variant", str(variant)] + list(extra), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-500:]
+    return r.stdout
+
+
+def test_upstream_compare_is_not_blinded_by_another_tuple_hash(tmp_path):
+    """tools/upstream_compare.py (what tools/check_against_upstream.sh decides with): an "upstream" dump made by the oracle at variant 6 (32-bit
+    ntHash, f32 bound -- the crate's likeliest other reading) with ANOTHER tuple hash (the oracle's bit 64) must come back as variant 6:
+    positions identical, hash partition identical, hash values differ.  The same with the reference's real hash: all three identical.  A dump no
+    variant reproduces (one position moved) comes back with variant null and exit code 1; equal tuples merged by a colliding "hash" show as a
+    partition that differs."""
+    import json
+    fa = _fasta(tmp_path)
+    cmp_py = os.path.join(ROOT, "tools", "upstream_compare.py")
+
+    def run(dump_text, extra=()):
+        d = tmp_path / "up.kmm"
+        d.write_text(dump_text)
+        r = subprocess.run([sys.executable, cmp_py, str(d), fa, "--json-only"] + list(extra), capture_output=True, text=True)
+        return r.returncode, json.loads(r.stdout.strip().splitlines()[-1])
+
+    rc, j = run(_dump(fa, 6 | 64))
+    assert rc == 0 and j["variant"] == 6 and j["positions"] == "identical" and j["hash_partition"] == "identical" and j["hash_values"] == "differ"
+    assert j["variants_tried"] == 64 and 6 in j["matching_variants"] and 0 not in j["matching_variants"] and j["tuples"] > 500
+    rc, j = run(_dump(fa, 6))
+    assert rc == 0 and j["variant"] == 6 and j["hash_values"] == "identical"
+    rc, j = run(_dump(fa, 0))
+    assert rc == 0 and j["variant"] == 0 and j["hash_values"] == "identical"  # several readings may match an input: the frozen one is preferred
+    rc, j = run(_dump(fa, 24, ["-k", "7", "-l", "16"]), ["-k", "7", "-l", "16"])
+    assert rc == 0 and j["variant"] == 24
+    lines = _dump(fa, 0).splitlines()
+    p = lines[40].split("\t")
+    p[1] = str(int(p[1]) + 1)
+    rc, j = run("\n".join(lines[:40] + ["\t".join(p)] + lines[41:]) + "\n")
+    assert rc == 1 and j["variant"] is None and j["positions"] == "differ" and j["matching_variants"] == []
+    collide = ["\t".join(ln.split("\t")[:5] + [str(int(ln.split("\t")[5]) >> 54)]) for ln in lines]  # a 10-bit "hash": distinct tuples share values
+    rc, j = run("\n".join(collide) + "\n")
+    assert rc == 1 and j["variant"] == 0 and j["positions"] == "identical" and j["hash_partition"] == "differs"
+
+
+def test_check_against_upstream_script_is_well_formed():
+    r = subprocess.run(["bash", "-n", os.path.join(ROOT, "tools", "check_against_upstream.sh")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    txt = open(os.path.join(ROOT, "tools", "check_against_upstream.sh")).read()
+    assert "upstream_compare.py" in txt and "--nosimd" in txt and "--seeding-variant" in txt

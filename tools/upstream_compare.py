@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""upstream_compare.py -- which reading of the third-party k-min-mer iterator reproduces a dump of the REAL crate's reference k-min-mers?
+
+    python tools/upstream_compare.py <upstream.kmm> <reference.fa[.gz]> [-k K -l L -d D --nohpc] [--json-only]
+
+<upstream.kmm>: the lines the patched reference prints under MQ_DUMP (tools/check_against_upstream.sh), one per reference k-min-mer in file
+order:  KMM <TAB> start <TAB> end <TAB> offset <TAB> rev <TAB> hash.   The oracle's tuples of the same FASTA are compared with them for ALL 64
+combinations of the six switchable decisions (oracle/mapquik_oracle.c mqo_set_variant = mq_params.flags bits 8..13), in two layers:
+
+  positions       (start, end, offset, rev) of every tuple, in order -- decides D1-D8 (ntHash, bound, HPC positions, orientation);
+  hash partition  the hash column ONLY as a partition: two tuples carry the same hash upstream <=> they carry the same hash here.  That is all
+                  the reference ever asks of the tuple hash (Index::add_with_mer / ReadOnlyIndex::get key on it, src/index.rs:100-104,118-126):
+                  a crate that hashes tuples in another way than SURVEY D9 guesses (SipHash-1-3 over [len, m...]) still yields the same index
+                  and the same PAF, and must not blind the search.  Whether the hash VALUES agree too is reported beside it (D9 pinned or not).
+
+A variant "matches" when its positions are identical; among matching variants the frozen reading (0) is preferred, then the readings whose D2
+bits come as the crate's type pair (H = u32 with FH = f32: 6 rather than 4 or 2 alone -- the two bounds keep the same l-mers on real data), then
+the fewest bits; every matching variant is listed.
+Prints a table (unless --json-only) and ONE machine-readable line:
+  {"variant": v | null, "positions": "identical" | "differ", "hash_partition": "identical" | "differs" | null, "hash_values": ..., "matching_variants": [...], ...}
+Exit code 0 when a variant matches in positions AND partition, 1 otherwise.  Test / diagnostic infrastructure: imports oracle/."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def read_dump(path):
+    """-> dict of numpy columns start, end, offset (uint64), rev (uint8), hash (uint64), in file order"""
+    st, en, of, rv, hs = [], [], [], [], []
+    with open(path) as f:
+        for ln in f:
+            if not ln.startswith("KMM"):
+                continue
+            p = ln.rstrip("\n").split("\t")
+            st.append(int(p[1]))
+            en.append(int(p[2]))
+            of.append(int(p[3]))
+            rv.append(1 if p[4].strip().lower() in ("true", "1") else 0)
+            hs.append(int(p[5]) & 0xFFFFFFFFFFFFFFFF)
+    return dict(start=np.array(st, dtype=np.uint64), end=np.array(en, dtype=np.uint64), offset=np.array(of, dtype=np.uint64),
+                rev=np.array(rv, dtype=np.uint8), hash=np.array(hs, dtype=np.uint64))
+
+
+def partition_labels(h):
+    """canonical labels of the partition a hash column induces: label = index of the value's first occurrence"""
+    _, first, inv = np.unique(h, return_index=True, return_inverse=True)
+    return first[inv]
+
+
+def oracle_columns(O, records, p, variant, stop_after_mismatch_with=None):
+    """the oracle's tuples of all records at `variant`; with stop_after_mismatch_with = the upstream columns, stops at the first record whose
+    positions differ (a wrong reading is wrong within the first few tuples: no need to seed a whole genome 64 times) -> (columns, first_diff)"""
+    O.lib().mqo_set_variant(variant)
+    try:
+        cols = dict(start=[], end=[], offset=[], rev=[], hash=[])
+        n = 0
+        up = stop_after_mismatch_with
+        for name, seq in records:
+            if len(seq) < p.l + p.k - 1:
+                continue
+            km = O.kminmers(seq, p)
+            for c in cols:
+                cols[c].append(km[c].astype(np.uint8 if c == "rev" else np.uint64))
+            if up is not None:
+                m = len(km)
+                for c in ("start", "end", "offset", "rev"):
+                    a, b = up[c][n:n + m], cols[c][-1]
+                    if a.size != b.size or not np.array_equal(a, b):
+                        k = int(np.flatnonzero(a[:min(a.size, b.size)] != b[:min(a.size, b.size)])[0]) if (a[:min(a.size, b.size)] != b[:min(a.size, b.size)]).any() else min(a.size, b.size)
+                        return None, dict(record=name, tuple_in_record=k, column=c,
+                                          upstream=None if k >= a.size else int(a[k]), here=None if k >= b.size else int(b[k]))
+            n += len(km)
+        out = {c: (np.concatenate(v) if v else np.zeros(0, dtype=np.uint8 if c == "rev" else np.uint64)) for c, v in cols.items()}
+        if up is not None and out["start"].size != up["start"].size:
+            return None, dict(record=None, tuple_in_record=None, column="count", upstream=int(up["start"].size), here=int(out["start"].size))
+        return out, None
+    finally:
+        O.lib().mqo_set_variant(0)
+
+
+def compare(upstream, records, p, O, variants=range(64), use_l=None):
+    """-> the result dict (see the module docstring)"""
+    records = list(records)
+    rows = []
+    for v in variants:
+        if (v & 8) and p.l < 2:
+            continue
+        cols, diff = oracle_columns(O, records, p, v, stop_after_mismatch_with=upstream)
+        row = dict(variant=v, positions="identical" if cols is not None else "differ", first_difference=diff)
+        if cols is not None:
+            same_part = bool(np.array_equal(partition_labels(upstream["hash"]), partition_labels(cols["hash"])))
+            row["hash_partition"] = "identical" if same_part else "differs"
+            row["hash_values"] = "identical" if np.array_equal(upstream["hash"], cols["hash"]) else "differ"
+        rows.append(row)
+    match = [r for r in rows if r["positions"] == "identical"]
+
+    def d2_canonical(v):
+        # D2 is ONE decision upstream -- the crate's type parameters H and FH come as a pair (u64/f64 or u32/f32) -- but two
+        # bits here (4: H = u32, 2: FH = f32), and on real data the f32 bound and the exact 32-bit bound keep the same l-mers (at d = 0.01 they
+        # are the same number), so v and v ^ 2 both match: among such twins the paired form (both bits or neither) is the one reported
+        return ((v >> 1) & 1) == ((v >> 2) & 1)
+    match.sort(key=lambda r: (r.get("hash_partition") != "identical", r["variant"] != 0, not d2_canonical(r["variant"]), bin(r["variant"]).count("1"), r["variant"]))
+    best = match[0] if match else None
+    return dict(variant=best["variant"] if best else None, positions="identical" if best else "differ",
+                hash_partition=best.get("hash_partition") if best else None, hash_values=best.get("hash_values") if best else None,
+                matching_variants=[r["variant"] for r in match], tuples=int(upstream["start"].size), variants_tried=len(rows), rows=rows)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("dump")
+    ap.add_argument("fasta")
+    ap.add_argument("-k", type=int, default=5)
+    ap.add_argument("-l", type=int, default=31)
+    ap.add_argument("-d", "--density", type=float, default=0.01)
+    ap.add_argument("--nohpc", action="store_true")
+    ap.add_argument("--json-only", action="store_true")
+    ap.add_argument("--tag", default="", help="a label carried into the JSON line (e.g. simd / nosimd)")
+    a = ap.parse_args(argv)
+    from oracle import oracle as O
+    from tools.dump_kminmers import records
+    p = O.params(k=a.k, l=a.l, density=a.density, use_hpc=not a.nohpc)
+    up = read_dump(a.dump)
+    res = compare(up, records(a.fasta), p, O)
+    if not a.json_only:
+        for r in res["rows"]:
+            if r["positions"] == "identical":
+                print("variant %2d: positions IDENTICAL (%d tuples); hash partition %s; hash values %s" % (r["variant"], res["tuples"], r["hash_partition"], r["hash_values"]))
+            else:
+                d = r["first_difference"]
+                print("variant %2d: positions differ -- record %s tuple %s column %s: upstream %s, here %s" % (r["variant"], d["record"], d["tuple_in_record"], d["column"], d["upstream"], d["here"]))
+        if res["variant"] is None:
+            print("NO variant reproduces the crate's positions: start / end wrong => D5-D7 (HPC positions); a missing / extra tuple => D2 / D3 (bound) or D1 (ntHash); "
+                  "only rev wrong => D8")
+        elif res["variant"] == 0:
+            print("seeding stage PINNED: the frozen reading (variant 0) reproduces the crate" + ("" if res["hash_values"] == "identical" else
+                  " -- positions and hash partition; the tuple-hash VALUES differ (D9 is another function upstream: the PAF does not depend on it)"))
+        else:
+            print("the crate is reproduced by variant %d, not by the frozen reading: run the product with --seeding-variant %d" % (res["variant"], res["variant"]))
+    line = {k: v for k, v in res.items() if k != "rows"}
+    line["tag"] = a.tag
+    print(json.dumps(line))
+    return 0 if (res["variant"] is not None and res["hash_partition"] == "identical") else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
