@@ -148,6 +148,10 @@ __device__ __forceinline__ void mq_clk(int i) {
         C.last[w] = now;
     }
 }
+#elif defined(MQ_CODE_MARKS)
+// Diagnostic build (tools/code_sizes.sh, never loaded): every stage stamp becomes a symbol in the code object -- mq_mark_<stage>_<n> -- so that
+// llvm-readelf can say how many bytes of map_kernel lie between two stamps (which stage owns how much of the instruction cache's 64 KB).
+__device__ __forceinline__ void mq_clk(int i) { asm volatile("mq_mark_%c0_%=:" ::"n"(i + 1)); }
 #else
 __device__ __forceinline__ void mq_clk(int) {}
 #endif

@@ -2,7 +2,8 @@
 
   config 2  E. coli full pbsim set: 4,641,652-bp genome, depth 10 (~1.9 k reads), defaults and example/run_ecoli.sh:26 flags
   config 3  CHM13v2.0-like, scale 1.0 (3.117 Gbp, 25 contigs): oracle identity on 50 k reads, order independence and
-            idempotence on the full 196,608-read batch (the bench batch)
+            idempotence on a 196,608-read batch (rounds 1-4's bench step; the bench's step since round 5 -- 1,572,864 reads in one
+            launch -- is tests/test_gpu_poison.py::test_bench_step_size_launch_on_poisoned_output)
   config 5  maize-like: 2.13 Gbp, 10 contigs <= 308 Mbp, >= 80 % of the bases in transposon-like families (copies 1-5 %
             apart), runs of N in the reference, depth-30-shaped reads (experiments/simulate_maize.sh:1-12)
   config 4  its SHAPE (experiments/table1.sh:50-55: uncompressed FASTQ reads, -k 7 -l 31 -d 0.01, human-scale reference) through

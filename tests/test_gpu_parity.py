@@ -133,8 +133,8 @@ def test_crowded_table_long_probe_walks(mq, oracle, simlib, monkeypatch, tmp_pat
     assert np.array_equal(d_h.to_numpy(mq.hit_dtype, offs.size - 1).view(np.uint8), hits.view(np.uint8))
 
 
-def _map_both(mq, oracle, g, off, names, reads, ps, variant=0):
-    P, po = mq.Params(seeding_variant=variant, **ps), oracle.params(**ps)
+def _map_both(mq, oracle, g, off, names, reads, ps, variant=0, fast_kh=False):
+    P, po = mq.Params(seeding_variant=variant, fast_kh=fast_kh, **ps), oracle.params(**ps)
     ix, ox = mq.Index(P), oracle.Index()
     for r in range(off.size - 1):
         s = g[int(off[r]):int(off[r + 1])]
@@ -631,9 +631,10 @@ def test_fuzz_params_and_sequences(mq, oracle, simlib):
             variant = int(os.environ["MQ_FUZZ_VARIANT"])
         if l < 2:
             variant &= ~8
-        oracle.lib().mqo_set_variant(variant)
+        fast_kh = bool(os.environ.get("MQ_FUZZ_FAST_KH")) or it % 8 == 5  # MQ_FLAG_FAST_KH = the oracle's bit 64: every eighth case, or a whole campaign
+        oracle.lib().mqo_set_variant(variant | (64 if fast_kh else 0))
         try:
-            ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads2, ps, variant)
+            ix, ox, hits, want = _map_both(mq, oracle, g, off, names, reads2, ps, variant, fast_kh)
             _cmp_hits(hits, want)
             got = ix.kminmers_batch(bases, offs)
             po = oracle.params(**ps)
