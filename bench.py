@@ -545,8 +545,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     red_dev = torch.device("cpu") if fake else dev  # where the tensors of the two all-reduces live
-    if world > 1:
+    # MQ_BENCH_FORCE_DIST=1 (test hook): the process group and every collective of the N > 1 path also at N = 1 -- RCCL ("nccl") with device
+    # tensors on the one GPU a test box has: init, barrier, MAX / SUM all-reduce, all-gather (tests/test_bench_ranks.py)
+    use_dist = world > 1 or os.environ.get("MQ_BENCH_FORCE_DIST", "") not in ("", "0")
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if fake:
             dist.init_process_group(backend="gloo")
         else:
@@ -687,7 +697,7 @@ def main():
     torch.cuda.synchronize()
     t_first_step = time.time() - t_start
     rss_setup = peak_rss_gb()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -697,12 +707,12 @@ def main():
         step()
         ev[i][1].record(stream)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed_local = elapsed
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -1056,6 +1066,7 @@ def main():
             },
             "mreads_per_s": round(all_reads * args.steps / elapsed / 1e6, 4),
             "per_rank_gbases_s": per_rank,
+            "collectives": ("gloo, CPU tensors (MQ_BENCH_FAKE_RANKS)" if fake else "nccl (RCCL), device tensors") if use_dist else None,
             "mapped_frac": round(n_mapped / max(n, 1), 4),
             "overflow_reads": n_over,
             "records_written": n_written,
@@ -1078,7 +1089,7 @@ def main():
             "end_to_end": e2e,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

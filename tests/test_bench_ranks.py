@@ -84,6 +84,23 @@ def test_bench_gpus_2_typed_as_the_driver_types_it():
     for key in ("metric", "unit", "dtype", "data", "higher_is_better"):
         assert out[1][key] == out[2][key]
     assert set(out[2]) - set(out[1]) <= {"per_rank_gbases_s"}, set(out[2]) ^ set(out[1])
+    assert out[2]["collectives"].startswith("gloo") and out[1]["collectives"] is None
+
+
+def test_bench_rccl_collectives_on_the_one_gpu():
+    """The collectives of the N > 1 path with the backend a real multi-GPU run uses -- "nccl" = RCCL, device tensors -- on the one GPU a test
+    box has (MQ_BENCH_FORCE_DIST=1: a one-rank process group): init_process_group, barrier, the MAX and SUM all-reduces and the all-gather
+    execute and the line is the N = 1 line (value = the rank's own rate)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "MQ_BENCH_FAKE_RANKS")}
+    env.update(MQ_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--genome-scale", "0.02", "--reads", "20000", "--no-cpu-baseline", "--no-e2e",
+                        "--no-configs"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["collectives"].startswith("nccl") and len(j["per_rank_gbases_s"]) == 1
+    assert abs(j["per_rank_gbases_s"][0] - j["value"]) <= 0.02 * j["value"] and j["records_written"] == 20000
 
 
 def test_bench_gpus_8_on_one_device_is_affordable():
