@@ -39,6 +39,10 @@ def _reads(g, rng):
         cl(2047) + b"N" + cl(2048) + b"N" + cl(2049),              # around the stretch minimum
         cl(63) + b"N" + cl(64 * 33) + b"N" + cl(64 * 33 + 1),      # whole 64-byte blocks
         cl(30000).replace(b"G", b"R", 1),                          # one IUPAC byte in 30 kb
+        cl(8000) + b"n" * 6000 + cl(8000),                         # a lower-case gap: one run when folding, and a run of another byte when not
+        cl(5000) + b"nN" * 2500 + cl(5000),                        # one run when folding; 5,000 run heads in 5 KB when not (the walk's dense steps)
+        cl(3000) + b"N" * 1023 + b"A" + b"N" * 1024 + b"C" + b"N" * 1025 + cl(3000),  # runs around the walk's 1-KB step
+        cl(100) + b"N" * 40000 + cl(100),                          # a run long enough for the jump
     ]
     bases = np.frombuffer(b"".join(seqs), dtype=np.uint8)
     offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
