@@ -458,20 +458,40 @@ def peak_rss_gb():
 
 def shared_genome(make, dist, world, rank, tag):
     """The synthetic genome once per node: rank 0 synthesises it (with every granted thread) into /dev/shm, the other ranks map the
-    file (copy-on-write pages: shared until written, and nobody writes) -- not 3.1 GB and a synthesis per rank."""
+    file (copy-on-write pages: shared until written, and nobody writes) -- not 3.1 GB and a synthesis per rank.  Where no shared
+    directory takes the file (a container with a 64-MB /dev/shm and no room in /tmp) every rank synthesises its own, as before round 6."""
     if world == 1:
         return make()
-    path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp",
-                        "mq_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), tag))
+    import tempfile
+    box = [None]
+    g = off = None
     if rank == 0:
         g, off, names = make()
-        np.save(path + ".g.tmp.npy", g)
-        os.replace(path + ".g.tmp.npy", path + ".g.npy")
-        np.save(path + ".off.npy", off)
-        del g
-    dist.barrier()
-    off = np.load(path + ".off.npy")
-    g = np.load(path + ".g.npy", mmap_mode="c")
+        for d in ("/dev/shm", tempfile.gettempdir()):
+            path = os.path.join(d, "mq_bench_%s_%d_%s" % (os.environ.get("MASTER_PORT", "0"), os.getpid(), tag))
+            try:
+                st = os.statvfs(d)
+                if st.f_bavail * st.f_frsize < g.nbytes + (64 << 20):
+                    continue
+                np.save(path + ".g.npy", g)
+                np.save(path + ".off.npy", off)
+                box[0] = path
+                break
+            except OSError:
+                for sfx in (".g.npy", ".off.npy"):
+                    try:
+                        os.remove(path + sfx)
+                    except OSError:
+                        pass
+    dist.broadcast_object_list(box, src=0)
+    path = box[0]
+    if path is None:  # no shared file: every rank its own copy
+        if rank != 0:
+            g, off, names = make()
+        return g, off, ["chr%d" % (i + 1) for i in range(off.size - 1)]
+    if rank != 0:
+        off = np.load(path + ".off.npy")
+        g = np.load(path + ".g.npy", mmap_mode="c")
     names = ["chr%d" % (i + 1) for i in range(off.size - 1)]
     dist.barrier()
     if rank == 0:  # every rank has the file mapped: the name can go (the pages live as long as the mappings)
