@@ -390,10 +390,13 @@ class Feeder {
     }
 
     // uncompressed FASTQ, lean: chunk i owns the records whose first byte lies in [i*CH, (i+1)*CH) of the file and reads their header and
-    // sequence lines -- and nothing else -- straight into its page-locked buffer: one pread per record of about the record's header +
-    // sequence length (estimated from the records before it; what it reads too much, the start of the '+' and quality lines, is
-    // overwritten by the next record), the '+' line found in that surplus, and ONE byte read at the place where the quality line must
-    // end if it is as long as the sequence line (the validator's test, fastq_record_at).  Half the file's bytes never leave the page
+    // sequence lines -- and nothing else -- straight into its page-locked buffer: ONE pread per record of about the record's header +
+    // sequence length (the longest of the eight records before it and a margin; what it reads too much, the start of the '+' and
+    // quality lines, is overwritten by the next record), the '+' line found in that surplus.  The byte at the place where the quality
+    // line must end if it is as long as the sequence line (the validator's test, fastq_record_at) is the byte in FRONT of the next
+    // record: it comes with the next record's read (into the place of this record's own line end, which is put back) -- round 5 read
+    // it with a pread of its own, a second system call per record, and asked for 1.125 x the record before, which one record in six
+    // outgrew (a second, doubled read).  Half the file's bytes never leave the page
     // cache: 1 byte per base from the file and over the link instead of 2 (a reader that maps the file pays for the page tables of
     // all of it: 12-17 GB/s at any thread count, profiles/r04_file_h2d.txt; this one runs at pread's rate).
     void lean_fastq_worker() {
@@ -440,6 +443,8 @@ class Feeder {
                 return end;
             };
             uint64_t est = 32768;  // bytes to ask for per record: header + sequence line of the records before it, and a margin
+            uint64_t hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // header + sequence bytes of the last eight records
+            unsigned hist_at = 0;
             for (;;) {
                 Chunk *c = get_buffer(std::min<uint64_t>(chunk_bytes_ / 2 + (1u << 20) + 2, file_size_ + 2));
                 const size_t i = next_raw_.fetch_add(1);
@@ -455,9 +460,12 @@ class Feeder {
                 const uint64_t last = hi < end ? record_start_from(hi) : end;
                 if (p >= hi) p = last;  // no record starts in this chunk
                 uint64_t w = 0;  // bytes of the chunk in use
+                bool pending = false;     // the byte at p - 1 (where the record before must end) is still to be looked at: it comes with this record's read
+                uint64_t E3_prev = 0;     // end of the '+' line of the record before (where the search for its real end starts when that byte is no '\n')
                 while (p < last) {
                     // the record's header and sequence lines into the buffer at w: `est` bytes, more while a line end is missing
                     uint64_t got = 0, e1 = NEED_MORE, e2 = NEED_MORE;  // e1, e2: indices in c->buf of the two line ends (or of the data's end at EOF)
+                    bool redo = false;
                     for (;;) {
                         const uint64_t want = std::min<uint64_t>(got ? got * 2 : est, end - p);
                         if (w + want + 64 > c->cap) {  // records longer than the buffer: a private, larger one
@@ -469,7 +477,20 @@ class Feeder {
                             recycle(c);
                             c = big;
                         }
-                        rd(c->buf + w + got, p + got, want - got);
+                        if (pending) {  // (got == 0, w >= 1: buf[w - 1] is the line end of the record before)
+                            rd(c->buf + w - 1, p - 1, want + 1);
+                            const uint8_t chk = c->buf[w - 1];
+                            c->buf[w - 1] = '\n';
+                            pending = false;
+                            if (chk != '\n') {  // the quality line of the record before is not as long as its sequence line: to its real end
+                                const uint64_t E4r = E3_prev < end ? line_end_from(E3_prev + 1) : end;
+                                p = E4r < end ? E4r + 1 : end;
+                                redo = true;
+                                break;
+                            }
+                        } else {
+                            rd(c->buf + w + got, p + got, want - got);
+                        }
                         const uint64_t from = e1 == NEED_MORE ? w : e1 + 1;  // (what was searched already holds no line end)
                         got = want;
                         const bool at_eof = p + got >= end;
@@ -486,6 +507,7 @@ class Feeder {
                         }
                         if (e2 != NEED_MORE) break;
                     }
+                    if (redo) continue;
                     if (c->buf[w] == '\n' || c->buf[w] == '\r') {  // blank bytes between records (rare): step over them
                         ++p;
                         continue;
@@ -513,8 +535,17 @@ class Feeder {
                         E3 = e ? p + ((uint64_t)(e - c->buf) - w) : line_end_from(p + got);
                     }
                     uint64_t E4 = E3 < end ? E3 + 1 + (E2 - S) : end;
-                    if (E4 > end || (E4 < end && byte_at(E4) != '\n')) E4 = E3 < end ? line_end_from(E3 + 1) : end;
-                    est = std::max<uint64_t>(4096, (E2 - p) + (E2 - p) / 8 + 256);
+                    if (E4 > end) {
+                        E4 = E3 < end ? line_end_from(E3 + 1) : end;
+                    } else if (E4 < end) {
+                        if (E4 + 1 < last && e2 < w + got) pending = true;  // looked at with the next record's read
+                        else if (byte_at(E4) != '\n') E4 = line_end_from(E3 + 1);
+                    }
+                    E3_prev = E3;
+                    hist[hist_at++ & 7u] = E2 - p;
+                    uint64_t longest = 0;
+                    for (uint64_t hlen : hist) longest = std::max(longest, hlen);
+                    est = std::max<uint64_t>(4096, longest + longest / 32 + 256);
                     w = e2 < w + got ? e2 + 1 : e2;  // the next record overwrites what was read beyond the sequence line
                     p = E4 < end ? E4 + 1 : end;
                 }

@@ -282,3 +282,27 @@ def test_feeder_unparsed_fasta_chunks(tool, tmp_path, crlf):
                     assert ("mapped 1" in r.stderr) == bool(extra)
                     if multiline:
                         assert "irregular 0" not in r.stderr  # sequences over several lines: handed back to the parser
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+def test_feeder_fastq_quality_lines_of_another_length(tool, tmp_path, crlf):
+    """FASTQ records whose quality line is shorter or longer than the sequence line (not what a sequencer writes, but what parse_chunk accepts: the
+    quality line ends at the next line end).  The lean reader looks at the byte where an equally long quality line would end together with the
+    NEXT record's read; when that byte is no line end it searches the real one.  Lean = chunked reader = plain parser, at every chunk size."""
+    rng = random.Random(77 + crlf)
+    nl = "\r\n" if crlf else "\n"
+    recs, out = [], []
+    for i in range(300):
+        L = rng.choice([1, 5, 50, 200, 1000, 3000])
+        seq = "".join(rng.choice("ACGT") for _ in range(L))
+        ql = L if i % 3 == 0 else max(0, L + rng.choice([-40, -3, -1, 1, 2, 64]))
+        q = "".join(rng.choice("IJ>!") for _ in range(ql))
+        recs.append(("q%d" % i, seq))
+        out.append("@q%d%s%s%s+%s%s%s" % (i, nl, seq, nl, nl, q, nl))
+    text = "".join(out)
+    want = [[a, str(len(b)), b] for a, b in recs]
+    raw = tmp_path / "odd.fq"
+    raw.write_text(text, newline="")
+    for chunk, th in ((64, 4), (700, 3), (5000, 1), (1 << 28, 2)):
+        assert _dump(tool, raw, True, chunk, th) == want, ("lean", chunk, th)
+        assert _dump(tool, raw, True, chunk, th, {"MQ_FEEDER_NO_LEAN_FASTQ": "1"}) == want, ("chunked", chunk, th)
