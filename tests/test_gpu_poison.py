@@ -4,7 +4,7 @@ real reads are).  find_matches returns one result per read and has no cross-read
 distribution -- a wave's first two work items are its own, items w and n_waves + w, the atomic counter hands out the rest, the marked
 entries of reads that went first are skipped -- is the part that can drop one (round 5's own-work-items change did: commit 8215505).
 
-  * launches of n in {1, n_waves-1, n_waves, n_waves+1, 2 n_waves-1, 2 n_waves, 2 n_waves+1} reads (n_waves = the persistent waves of a
+  * launches of n in {1, n_waves-1, n_waves, n_waves+1, 1.5 n_waves, 2 n_waves-1, 2 n_waves, 2 n_waves+1} reads (n_waves = the persistent waves of a
     full grid, read from the library) with reads that go first (tandem-array reads) placed so that their marked entries ARE the own
     items w and / or n_waves + w of many waves: all records written, every column the oracle's;
   * the bench's step -- 1,572,864 reads in ONE launch -- on a small genome (the read count is what matters): all records written,
@@ -121,7 +121,9 @@ def test_wave_count_edges_on_poisoned_output(mq, oracle, simlib, small_world, sh
     nw_full = ix.launch_waves(1 << 20)
     assert nw_full >= 64 and nw_full % 8 == 0
     rng = np.random.default_rng(7)
-    for n in (1, nw_full - 1, nw_full, nw_full + 1, 2 * nw_full - 1, 2 * nw_full, 2 * nw_full + 1):
+    # (n_waves + n_waves / 2: between one and two items per wave, the counter empty from the start -- where round 5's bug lost one read per wave
+    # whose first own item was a marked entry)
+    for n in (1, nw_full - 1, nw_full, nw_full + 1, nw_full + nw_full // 2, 2 * nw_full - 1, 2 * nw_full, 2 * nw_full + 1):
         nw = ix.launch_waves(n)
         assert nw == min(nw_full, 8 * ((n + 7) // 8))
         waves = [int(w) for w in rng.choice(nw, size=min(nw, 96), replace=False)]
