@@ -773,7 +773,10 @@ def main():
         for m in (49152, 196608, 786432):
             if m < n:
                 tb = int(offs[m])
-                for _ in range(2):
+                # warm-up worth ~55 ms of launches (2 n / m of them): the checks above leave the GPU idle for a moment (torch loads its
+                # comparison kernels on first use) and an idle GPU clocks down -- the first dozen milliseconds after a pause run 20 % slow
+                # (tools/small_probe.py: 49,152 reads 1.11 ms per launch from idle, 0.92 ms once the clocks are up)
+                for _ in range(max(2, min(64, 2 * n // m))):
                     ix.map_batch_device(d_bases.data_ptr(), d_offs.data_ptr(), m, tb, d_out.data_ptr(), stream.cuda_stream)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
