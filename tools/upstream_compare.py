@@ -83,7 +83,7 @@ def oracle_columns(O, records, p, variant, stop_after_mismatch_with=None):
         O.lib().mqo_set_variant(0)
 
 
-def compare(upstream, records, p, O, variants=range(64), use_l=None):
+def compare(upstream, records, p, O, variants=range(64)):
     """-> the result dict (see the module docstring)"""
     records = list(records)
     rows = []
