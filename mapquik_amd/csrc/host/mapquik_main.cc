@@ -107,8 +107,10 @@ struct Opt {
     std::string second;  // "k2,l2,d2"
     long k2 = 0, l2 = 0;
     double d2 = 0;
-    unsigned long long batch_bases = 1ull << 25;  // raw input bytes per chunk (page-locked buffers this size; pinning memory is the
-                                                  // start-up cost of the read phase, so chunks are small)
+    unsigned long long batch_bases = 0;  // raw input bytes per chunk (page-locked buffers this size); 0 = by the size of the reads file: 32 MB, and
+                                         // 64 MB from 2 GB on (four reader threads: 28.5 -> 30.8 Gbases/s on the 4.6-GB FASTA of the bench, eight:
+                                         // 38-40 either way, tools/chunk_probe.py; pinning memory is the start-up cost of the read phase, so a
+                                         // small input keeps small chunks)
 };
 
 static void usage() {
@@ -171,7 +173,12 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         using feeder::Chunk;
         const int n_slots = 3;  // stream slots per GPU: copy-in, kernels and copy-out of consecutive chunks overlap
         const int n_format = std::max(2, std::min(8, n_parse));  // PAF formatters (the reader threads of a mapped FASTA file have next to nothing to do)
-        feeder::Feeder feed(reads_path, !reads_fasta, o.batch_bases, n_parse, n_parse + o.gpus * (n_slots + 1) + n_format + 2);
+        unsigned long long batch_bases = o.batch_bases;
+        if (batch_bases == 0) {
+            struct stat sb;
+            batch_bases = (stat(reads_path.c_str(), &sb) == 0 && (unsigned long long)sb.st_size >= (2ull << 30)) ? (1ull << 26) : (1ull << 25);
+        }
+        feeder::Feeder feed(reads_path, !reads_fasta, batch_bases, n_parse, n_parse + o.gpus * (n_slots + 1) + n_format + 2);
         // An uncompressed FASTA file goes to the GPU as it lies in the file: the reader threads only copy file bytes into page-locked
         // chunks (pread, cut at record starts), the records are found on the device (mq_ctx_submit_fasta) and the host reads a header
         // only to print it.  MQ_DRIVER_HOST_PARSE=1: every chunk is parsed by the reader threads as in earlier rounds (same PAF; tests compare).
@@ -221,7 +228,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
                 if (slots[gw][sl]) continue;
                 slots[gw][sl] = mq_ctx_new(h);
                 if (!slots[gw][sl]) return std::string("mq_ctx_new: ") + last_error();
-                const uint64_t cb = std::min<uint64_t>(o.batch_bases + o.batch_bases / 8 + (1u << 20), feed.bytes_in() + 64);
+                const uint64_t cb = std::min<uint64_t>(batch_bases + batch_bases / 8 + (1u << 20), feed.bytes_in() + 64);
                 if (mq_ctx_reserve(slots[gw][sl], (uint32_t)std::min<uint64_t>(cb / 16000 + 512, 1u << 24), cb) != MQ_OK)  // (sized for long reads; a chunk of short reads makes its slot grow once)
                     return std::string("mq_ctx_reserve: ") + last_error();
             }
