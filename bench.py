@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--seeding-variant", type=int, default=0,
                     help="reading of the third-party k-min-mer iterator's unpinned decisions (mq_params.flags bits 8..13, include/mapquik_hip.h; "
                          "0 = the frozen reading, the BASELINE configuration): the oracle is switched to the same variant for the column checks")
+    ap.add_argument("--fast-kh", action="store_true",
+                    help="MQ_FLAG_FAST_KH for the step itself (profiling the opt-in tuple hash; the line then says so in `config.fast_kh` and in `metric`: "
+                         "not the BASELINE configuration, whose tuple hash is SipHash-1-3); the oracle is switched to its bit 64 for the column checks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end measurements (host buffers -> hits, file -> PAF)")
     ap.add_argument("--e2e-file-reads", type=int, default=196608, help="reads written to the FASTA the native driver maps")
@@ -587,10 +590,10 @@ def main():
 
     ncpu = effective_cpus()
     threads = max(1, ncpu // world)
-    P = mq.Params(k=args.k, l=args.l, density=args.density, seeding_variant=args.seeding_variant)  # defaults k=5 l=31 d=0.01, HPC on, c=4 s=11 g=2000 (src/main.rs:174-188)
-    if args.seeding_variant:  # the checker follows (a process-wide switch of the oracle; legs with their own Params are skipped below)
+    P = mq.Params(k=args.k, l=args.l, density=args.density, seeding_variant=args.seeding_variant, fast_kh=args.fast_kh)  # defaults k=5 l=31 d=0.01, HPC on, c=4 s=11 g=2000 (src/main.rs:174-188)
+    if args.seeding_variant or args.fast_kh:  # the checker follows (a process-wide switch of the oracle; legs with their own Params are skipped below)
         from oracle import oracle as _O
-        _O.lib().mqo_set_variant(args.seeding_variant)
+        _O.lib().mqo_set_variant(args.seeding_variant | (64 if args.fast_kh else 0))
         args.no_configs = True
         args.no_e2e = True
 
@@ -826,7 +829,7 @@ def main():
         try:
             tj = json.load(open(tpath))
             if (tj.get("reads") == n and abs(tj.get("genome_scale", -1) - args.genome_scale) < 1e-9 and not real_ref and args.genome_preset == "planted-repeats"
-                    and args.k == 5 and args.l == 31 and not args.seeding_variant):  # (the counters were taken on the headline workload)
+                    and args.k == 5 and args.l == 31 and not args.seeding_variant and not args.fast_kh):  # (the counters were taken on the headline workload)
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_commit = tj.get("commit")
         except Exception:
@@ -844,7 +847,7 @@ def main():
         try:
             ij = json.load(open(ipath))
             if (ij.get("reads") == n and abs(ij.get("genome_scale", -1) - args.genome_scale) < 1e-9 and ij.get("k") == args.k and not strong and not real_ref
-                    and args.genome_preset == "planted-repeats" and args.l == 31 and not args.seeding_variant):
+                    and args.genome_preset == "planted-repeats" and args.l == 31 and not args.seeding_variant and not args.fast_kh):
                 n_simd = int(ij["n_simd"])
                 # cycles: the launch's busy cycles as the counters gave them (GRBM_GUI_ACTIVE / 8 XCDs) -- a property of the kernel on this
                 # workload; this run's launch time only says what shader clock that implies here (the clock moves with the power state:
@@ -1051,7 +1054,8 @@ def main():
         value = all_bases * args.steps / elapsed / 1e9
         line = {
             "metric": ("Gbases/s mapped (%s, k=%d l=%d d=%g)" % ("real reference" + (" + real reads" if args.reads_fastx else ", simulated HiFi reads"), args.k, args.l, args.density))
-                      if real_ref else "Gbases/s mapped (sim %s HiFi, k=%d l=%d d=%g)" % ("maize-B73-like" if args.genome_preset == "maize-like" else "CHM13v2-like", args.k, args.l, args.density),
+                      if real_ref else "Gbases/s mapped (sim %s HiFi, k=%d l=%d d=%g%s)" % ("maize-B73-like" if args.genome_preset == "maize-like" else "CHM13v2-like", args.k, args.l,
+                                                                                           args.density, ", MQ_FLAG_FAST_KH: not the BASELINE tuple hash" if args.fast_kh else ""),
             "value": round(value, 3),
             "unit": "Gbases/s",
             "n_gpus": world,
@@ -1079,6 +1083,7 @@ def main():
                                else "%g%% planted repeats + %g%% tandem arrays" % (100 * args.repeat_frac, 100 * args.tandem_frac),
                                args.k, args.l, args.density),
                 "seeding_variant": args.seeding_variant,
+                "fast_kh": bool(args.fast_kh),
                 "reads_per_step_per_gpu": n,
                 "bases_per_step_per_gpu": total_bases,
                 "index_unique_kminmers": int(n_unique),
