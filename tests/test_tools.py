@@ -103,3 +103,26 @@ def test_check_against_upstream_script_is_well_formed():
     assert r.returncode == 0, r.stderr
     txt = open(os.path.join(ROOT, "tools", "check_against_upstream.sh")).read()
     assert "upstream_compare.py" in txt and "--nosimd" in txt and "--seeding-variant" in txt
+
+
+def test_read_slices_are_the_reads_of_make_reads():
+    """tools/sim.py read_slices (what bench.py synthesises a batch with, slice by slice straight into device memory) yields the reads of
+    make_reads byte for byte -- bases, offsets and truth columns -- whatever the slice size, and from any first read (a strong-scaling shard)."""
+    import numpy as np
+    from tools import sim
+    g, off, names = sim.make_genome([300_000, 200_000], seed=5, repeat_frac=0.05)
+    want = sim.make_reads(g, off, 1500, seed=9, threads=4, len_mean=3000, len_sd=900, len_min=50, len_max=6000)
+    for slice_reads, first in ((64, 0), (700, 0), (4096, 0), (333, 401)):
+        bs, offs, tr = [], [np.zeros(1, dtype=np.uint64)], {}
+        for r0, r1, b, o, t in sim.read_slices(g, off, 1500 - first, seed=9, slice_reads=slice_reads, threads=3, len_mean=3000, len_sd=900, len_min=50, len_max=6000,
+                                               first_read=first):
+            assert r1 - r0 == o.size - 1 and b.size == int(o[-1])
+            bs.append(b.copy())
+            offs.append(o[1:] + offs[-1][-1])
+            for k, v in t.items():
+                tr.setdefault(k, []).append(v)
+        lo = int(want["offsets"][first])
+        assert np.array_equal(np.concatenate(bs), want["bases"][lo:])
+        assert np.array_equal(np.concatenate(offs), want["offsets"][first:] - np.uint64(lo))
+        for k in ("ctg", "start", "end", "strand"):
+            assert np.array_equal(np.concatenate(tr[k]), want[k][first:]), k
