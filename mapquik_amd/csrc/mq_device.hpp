@@ -732,6 +732,13 @@ __device__ __forceinline__ void chain_stage(MatchRec *__restrict__ scratch, uint
             // pass B: filter_matches_max (src/chain.rs:123-129) when len > 1; first/last kept, score
             uint32_t nkept = 0, score = 0;
             MatchRec first = {}, last = {};
+            if (n_in == 1u) {
+                // a reference with ONE Match (the stray hit of a repeat copy: most of the extra candidates of a repetitive genome): Chain::len
+                // == 1, nothing to filter -- that Match (the anchor: this chunk's lead lane) is the first and the last, its count the score
+                nkept = 1u;
+                score = best_cnt;
+                first = last = anchor;
+            } else
             for (uint32_t c = c0; c < nm; c += CH) {
                 const bool v = lane < (uint32_t)CH && c + lane < nm;
                 MatchRec x = {};
@@ -741,7 +748,7 @@ __device__ __forceinline__ void chain_stage(MatchRec *__restrict__ scratch, uint
                 const uint64_t im = __ballot(in);
                 if (!im) continue;
                 if (c != c0 && in) scratch[c + lane].done = 1u;
-                const bool keep = in && (n_in <= 1u || match_compatible(anchor, x, P.g));
+                const bool keep = in && match_compatible(anchor, x, P.g);
                 const uint64_t km = __ballot(keep);
                 if (!km) continue;
                 if (nkept == 0) first = rd_match(x, __ffsll((long long)km) - 1);
