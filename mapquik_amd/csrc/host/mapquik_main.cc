@@ -107,10 +107,10 @@ struct Opt {
     std::string second;  // "k2,l2,d2"
     long k2 = 0, l2 = 0;
     double d2 = 0;
-    unsigned long long batch_bases = 0;  // raw input bytes per chunk (page-locked buffers this size); 0 = by the size of the reads file: 32 MB, and
-                                         // 64 MB from 2 GB on (four reader threads: 28.5 -> 30.8 Gbases/s on the 4.6-GB FASTA of the bench, eight:
-                                         // 38-40 either way, tools/chunk_probe.py; pinning memory is the start-up cost of the read phase, so a
-                                         // small input keeps small chunks)
+    unsigned long long batch_bases = 0;  // raw input bytes per chunk (page-locked buffers this size); 0 = 32 MB, and 64 MB for a reads file of 2 GB or
+                                         // more read by at most four threads (28.5 -> 30.8 Gbases/s on the 4.6-GB FASTA of the bench on one box, no
+                                         // change on another; with eight or more readers the rate does not move and the job's wall time grows by
+                                         // 0.06-0.13 s: twice the page-locked memory to set up; tools/chunk_probe.py, profiles/NOTES.md)
 };
 
 static void usage() {
@@ -176,7 +176,7 @@ static int run_pass(const Opt &o, const Params &P, const std::string &reads_path
         unsigned long long batch_bases = o.batch_bases;
         if (batch_bases == 0) {
             struct stat sb;
-            batch_bases = (stat(reads_path.c_str(), &sb) == 0 && (unsigned long long)sb.st_size >= (2ull << 30)) ? (1ull << 26) : (1ull << 25);
+            batch_bases = (n_parse <= 4 && stat(reads_path.c_str(), &sb) == 0 && (unsigned long long)sb.st_size >= (2ull << 30)) ? (1ull << 26) : (1ull << 25);
         }
         feeder::Feeder feed(reads_path, !reads_fasta, batch_bases, n_parse, n_parse + o.gpus * (n_slots + 1) + n_format + 2);
         // An uncompressed FASTA file goes to the GPU as it lies in the file: the reader threads only copy file bytes into page-locked
